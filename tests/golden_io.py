@@ -1,0 +1,33 @@
+"""Reader for the array bundles written by oracle/harness/bundle.js (<base>.json + <base>.bin)."""
+import json
+import os
+
+import numpy as np
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+class Bundle(dict):
+    meta: dict
+
+
+def load_bundle(name: str) -> Bundle:
+    base = os.path.join(GOLDEN, name)
+    with open(base + ".json") as f:
+        man = json.load(f)
+    raw = np.fromfile(base + ".bin", dtype=np.uint8)
+    out = Bundle()
+    for k, a in man["arrays"].items():
+        dt = np.dtype("<" + a["dtype"])
+        arr = raw[a["offset"]:a["offset"] + a["nbytes"]].view(dt).reshape(a["shape"])
+        out[k] = arr
+    out.meta = man.get("meta", {})
+    return out
+
+
+def load_scene(preset, width=None, height=None):
+    from raytracer_amd.scene import FlatScene
+    sc = FlatScene.from_json(os.path.join(GOLDEN, f"scene_preset{preset}_flat.json"))
+    if width is not None:
+        sc = sc.with_size(width, height)
+    return sc
