@@ -1,0 +1,183 @@
+/*
+ * rt355 -- C ABI of the MI355X ray-tracing / photon-mapping core (librt355.so).
+ *
+ * The reference (TheophileMot/raytracer) is one JavaScript realm with no FFI of its own, so
+ * each entry point below names the reference function(s) it stands in for; the Node host
+ * (raytracer_amd/host) calls them through the N-API shim and keeps the reference's
+ * JavaScript-visible surface (Scene, Ray, KdTree ...) on top.
+ *
+ * Conventions
+ *   - every function returns an int status (RT_OK = 0); rt_last_error() gives the message.
+ *     "No hit" is a value (index -1, t = +inf), never an error -- as `undefined` is in the
+ *     reference.
+ *   - array arguments may be host pointers or device pointers of the context's GPU; the
+ *     library detects which.  Host arrays are borrowed for the duration of the call only.
+ *   - all kernels of one context run on one HIP stream (rt_stream()).
+ *   - nothing here allocates through, or exposes, any framework type: plain pointers/sizes.
+ */
+#ifndef RT355_H
+#define RT355_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_ABI_VERSION 1
+
+enum { RT_OK = 0, RT_ERR_INVALID = -1, RT_ERR_HIP = -2, RT_ERR_NO_DEVICE = -3, RT_ERR_EMPTY_TREE = -4,
+       RT_ERR_ATTEMPT_CAP = -5, RT_ERR_MATERIAL_STACK = -6, RT_ERR_UNKNOWN_SHAPE = -7, RT_ERR_TOO_LARGE = -8 };
+
+/* primitive types: the `type` strings of rayphoton.js:353-481 */
+enum { RT_PLANE = 0, RT_SPHERE, RT_HEMISPHERE, RT_CYLINDER, RT_TRIANGLE, RT_SQUARE, RT_DISC, RT_ANNULUS, RT_NUM_TYPES };
+enum { RT_FLAG_CONVEX = 1, RT_FLAG_LIGHT = 2, RT_FLAG_TRUNC_MAX = 4, RT_FLAG_HALF_HEIGHT = 8 };
+/* procedural albedo closures of the presets (rayphoton.js:746-755, :756-768, :784-792, :871-874) */
+enum { RT_PROC_NONE = 0, RT_PROC_STRIPE_CHECKER = 1, RT_PROC_EIGHT_BALL = 2, RT_PROC_TILE_GRID = 3, RT_PROC_ROTATED_CHECKER = 4 };
+enum { RT_PRECISION_F32 = 0, RT_PRECISION_F64 = 1 };
+enum { RT_MODE_PHOTON = 0 /* rayphoton.js traceRay */, RT_MODE_WHITTED = 1 /* ray.js traceRay */ };
+enum { RT_SCAN_CLOSEST = 0, RT_SCAN_CLOSEST_NOLIGHT = 1, RT_SCAN_ANY = 2 };
+/* RNG stream domains: key=(seed), counter=(draw>>2, a, b, domain); U=(word[draw&3]>>8)*2^-24 */
+enum { RT_DOMAIN_RENDER = 0, RT_DOMAIN_EMIT_PHASE1 = 1, RT_DOMAIN_EMIT_PHASE2 = 2, RT_DOMAIN_AUX = 3 };
+
+typedef struct rt_ctx rt_ctx;
+typedef struct rt_scene rt_scene;
+typedef struct rt_photon_map rt_photon_map;
+
+/* Flat scene: what `new Scene(ctx)` + `loadPreset` leave in scene.shapes / scene.lights /
+ * scene.camera (rayphoton.js:715-727, :1313-1324), flattened by the host. */
+typedef struct rt_scene_desc {
+  uint32_t n_shapes;
+  const uint8_t *shape_meta;    /* n_shapes x 4: type, material (255 = none), flags, procedural colour id */
+  const double *shape_geom;     /* n_shapes x 12, slot assignment documented in raytracer_amd/scene.py */
+  const double *shape_colour;   /* n_shapes x 4: baseColour r g b (0..255) a (0..1; NaN = absent) */
+  uint32_t n_lights;
+  const uint32_t *light_shape;  /* n_lights: index of the light's disc in the shape list (rayphoton.js:322) */
+  const double *light_data;     /* n_lights x 8: wattage, area, prob, lightColour r g b a, reserved */
+  double camera[16];            /* origin3 ONBu3 ONBv3 ONBw3 fovScaleWidth fovScaleHeight, 2 reserved */
+  uint32_t width, height;       /* canvas size */
+  double materials[4][8];       /* rows: transparent(0/1), refrIndex, reflectance, specular; NaN = undefined */
+} rt_scene_desc;
+
+/* The reference's top-of-file constants (rayphoton.js:6-23) plus run controls. */
+typedef struct rt_params {
+  double epsilon;               /* EPSILON 1e-6 */
+  double max_trace_dist;        /* MAX_TRACE_DIST 20 (ray.js: 100) */
+  int32_t max_depth;            /* MAX_DEPTH 5 (ray.js: 20) */
+  int32_t sub_sample;           /* SUB_SAMPLE: sub_sample^2 paths per pixel */
+  uint32_t num_photons_diffuse; /* NUM_PHOTONS_DIFFUSE */
+  uint32_t num_photons_caustic; /* NUM_PHOTONS_CAUSTIC */
+  double diffuse_radius;        /* DIFFUSE_RADIUS 0.40 */
+  double caustic_radius;        /* CAUSTIC_RADIUS 0.15 */
+  double standard_lamp_area;    /* STANDARD_LAMP_AREA 100 */
+  uint64_t seed;                /* Philox key */
+  int32_t use_direct_light;     /* 0: skip directLight (rayphoton.js:1750-1752) */
+  int32_t use_photon_maps;      /* 0: skip both radius gathers (rayphoton.js:1765, :1788) */
+  int32_t precision;            /* RT_PRECISION_F32 (throughput) or RT_PRECISION_F64 (parity) */
+  int32_t mode;                 /* RT_MODE_PHOTON or RT_MODE_WHITTED */
+  double shadow_bias;           /* offset along the normal for shadow rays; 0 = epsilon (rayphoton.js:1751) */
+  int32_t max_bounces;          /* hard cap on path segments (0 = 64); the reference has none */
+  int32_t reserved;
+} rt_params;
+
+typedef struct rt_trace_stats {
+  uint64_t rays;                /* closest-hit segments traced (one per reference traceRay call that scans) */
+  uint64_t shadow_rays;         /* any-hit segments (directLight) */
+  uint64_t gathers;             /* photon-map queries (one per map per opaque hit) */
+  uint64_t bounces;             /* wavefront iterations */
+  uint64_t stack_overflows;     /* paths whose material stack exceeded the fixed capacity */
+} rt_trace_stats;
+
+typedef struct rt_emit_stats {
+  uint64_t attempts_phase1, attempts_phase2;
+  uint64_t segments;            /* emitPhoton calls */
+  uint32_t n_diffuse, n_caustic;
+  int32_t capped;               /* 1 when an attempt cap was hit (rayphoton.js:1365-1368, :1377-1380) */
+  int32_t errors;               /* attempts that would throw "photon exited all materials" (rayphoton.js:1489) */
+} rt_emit_stats;
+
+/* ---- context ---- */
+void rt_default_params(rt_params *p);
+/* device_ids: HIP ordinals; n == 0 or NULL means device 0.  One context drives one GPU
+ * (multi-GPU = one process and one context per GPU). */
+int rt_init(const int *device_ids, int n, rt_ctx **out);
+void rt_shutdown(rt_ctx *ctx);
+const char *rt_last_error(rt_ctx *ctx);     /* ctx may be NULL: last rt_init failure */
+void *rt_stream(rt_ctx *ctx);               /* the hipStream_t all work is launched on */
+int rt_synchronize(rt_ctx *ctx);
+/* Per-kernel HIP-event timing (off by default).  rt_profile_get sums the launches of one
+ * kernel name since the last reset; it synchronises the stream. */
+int rt_profile_enable(rt_ctx *ctx, int on);
+int rt_profile_reset(rt_ctx *ctx);
+int rt_profile_get(rt_ctx *ctx, const char *kernel, double *total_ms, uint64_t *launches);
+
+/* ---- scene: `new Scene(ctx)` + `loadPreset` + `initLights` (rayphoton.js:715-727, :1313-1324) ---- */
+int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *desc, rt_scene **out);
+void rt_scene_free(rt_scene *scene);
+
+/* ---- geometry kernel: `new Ray(o,d).intersectDist(shape)` (rayphoton.js:483-645) ----
+ * pairwise: ray i against shape record i (n shapes given inline). t = NaN for `undefined`. */
+int rt_intersect_pairs(rt_ctx *ctx, const rt_params *p, uint32_t n, const double *ray_o, const double *ray_d,
+                       int normalize_dir, const uint8_t *shape_meta, const double *shape_geom, double *t_out);
+/* scene scans: the closest-hit loops (rayphoton.js:1642-1650, :1467-1475) and the any-hit
+ * shadow loop (:1853-1857).  idx = -1 / t = +inf on a miss; mode RT_SCAN_ANY writes 0/1 to idx. */
+int rt_intersect(rt_scene *scene, const rt_params *p, int mode, uint32_t n, const double *ray_o,
+                 const double *ray_d, const double *source_dist, double *t_out, int32_t *idx_out);
+
+/* ---- photon emission: `emitManyPhotons` / `createPhoton` / `emitPhoton` / `storePhoton`
+ *      (rayphoton.js:1326-1383, :1461-1557) ----
+ * One RNG stream per attempt: (RT_DOMAIN_EMIT_PHASE<phase>, attempt).  Records are 11 doubles:
+ * origin3 dir3 power colour_rgba (rayphoton.js:647-654). */
+/* attempts [begin,end) of one phase, compacted in attempt order.  kind: 1 diffuse, 2 caustic.
+ * cap = capacity of the output arrays in records (end-begin always suffices). */
+int rt_emit_photons(rt_scene *scene, const rt_params *p, int phase, uint64_t attempt_begin, uint64_t attempt_end,
+                    uint32_t cap, double *rec_out, int64_t *attempt_out, uint8_t *kind_out, uint32_t *n_out,
+                    rt_emit_stats *stats);
+/* the whole two-phase loop with the reference's caps; lists come back in store order.
+ * diffuse/caustic hold num_photons_* x 11 doubles; *_attempt hold (phase, attempt) pairs. */
+int rt_emit_many(rt_scene *scene, const rt_params *p, double *diffuse, int64_t *diffuse_attempt,
+                 double *caustic, int64_t *caustic_attempt, rt_emit_stats *stats);
+
+/* ---- photon map: `new KdTree(photons)` (kdtree.js:1-8, :82-124) ---- */
+/* rec: n x 11 doubles as above.  Positions are rounded to fp32 for the device record
+ * (pos 3xf32, dir 3xf32, power*colour 3xf32); the tree is the reference's left-balanced
+ * tree over those rounded positions.  n == 0 -> RT_ERR_EMPTY_TREE (kdtree.js:6). */
+int rt_photon_map_build(rt_ctx *ctx, const double *rec, uint32_t n, rt_photon_map **out);
+void rt_photon_map_free(rt_photon_map *map);
+uint32_t rt_photon_map_size(const rt_photon_map *map);
+/* nodes[pos] for pos = 1..n: perm[pos-1] = index of nodes[pos].photon in the input list,
+ * dim[pos-1] = nodes[pos].dim (kdtree.js:104) */
+int rt_photon_map_nodes(rt_photon_map *map, int32_t *perm, uint8_t *dim);
+/* tree build alone, on fp32 positions (n x 3) */
+int rt_kd_build(rt_ctx *ctx, const float *pos, uint32_t n, int32_t *perm, uint8_t *dim);
+uint32_t rt_find_median(uint32_t n);        /* kdtree.js:109-124 */
+
+/* `nearestNeighbours(x, r)` (kdtree.js:64-80): count[q] hits, the first min(count, cap) input
+ * indices in the reference's pre-order at idx[q*cap ...]. queries: nq x 3 fp32. */
+int rt_kd_radius(rt_photon_map *map, const float *queries, uint32_t nq, double r, uint32_t cap,
+                 uint32_t *count, int32_t *idx);
+/* k nearest photons ordered by (squared distance, input index); slots beyond n hold -1 / +inf.
+ * The reference has no k-NN query; the order is defined by brute force (oracle/rt_oracle.c). */
+int rt_kd_knn(rt_photon_map *map, const float *queries, uint32_t nq, uint32_t k, int32_t *idx, double *d2);
+/* fused radiance estimate at nq surface points (rayphoton.js:1779-1784, :1808-1815):
+ *   rgb = sum_p colour_p * power_p * max(0, dir_p . normal) * albedo/255 / (pi r^2)
+ * over the photons within r (k == 0) or over the k nearest with r^2 = the k-th squared
+ * distance (k > 0).  hits: nq x 9 fp32 = pos3 normal3 albedo3; rgb_out: nq x 3 fp32. */
+int rt_gather_radiance(rt_photon_map *map, const float *hits, uint32_t nq, double r, uint32_t k, float *rgb_out);
+
+/* ---- renderer: `traceTile` / `traceOnCanvas` / `traceRay` / `directLight`
+ *      (rayphoton.js:1573-1880; ray.js:801-993 for RT_MODE_WHITTED) ----
+ * Renders pixels [x0,x0+w) x [y0,y0+h) of the scene's canvas with superSampleScale 0.
+ * RNG stream per path: (RT_DOMAIN_RENDER, pixel index, sub-sample index).
+ *   pre_rgba  : w*h*4 doubles, the traceRay colour of the pixel's last sub-sample before
+ *               clamping (with sub_sample == 1: the pixel's radiance), alpha NaN-able
+ *   post_rgba : w*h*4 doubles, what putPixel receives (rayphoton.js:1618-1623)
+ *   rgba8     : w*h*4 bytes, post_rgba as 8-bit RGBA (alpha*255)
+ * any of the three may be NULL. diffuse/caustic may be NULL (no map). */
+int rt_trace_tile(rt_scene *scene, const rt_params *p, rt_photon_map *diffuse, rt_photon_map *caustic,
+                  int x0, int y0, int w, int h, double *pre_rgba, double *post_rgba, uint8_t *rgba8,
+                  rt_trace_stats *stats);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT355_H */

@@ -1,0 +1,316 @@
+"""ctypes binding of librt355.so (include/rt355.h) -- the Python mirror of the Node host.
+
+Everything here calls the HIP library; there is no CPU fallback.  If the shared library is
+missing, or no GPU is visible, the calls raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from .scene import FlatScene
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "librt355.so")
+
+PRECISION_F32, PRECISION_F64 = 0, 1
+MODE_PHOTON, MODE_WHITTED = 0, 1
+SCAN_CLOSEST, SCAN_CLOSEST_NOLIGHT, SCAN_ANY = 0, 1, 2
+
+EXPORTS = [
+    "rt_default_params", "rt_init", "rt_shutdown", "rt_last_error", "rt_stream", "rt_synchronize",
+    "rt_profile_enable", "rt_profile_reset", "rt_profile_get", "rt_scene_upload", "rt_scene_free",
+    "rt_intersect_pairs", "rt_intersect", "rt_emit_photons", "rt_emit_many", "rt_photon_map_build",
+    "rt_photon_map_free", "rt_photon_map_size", "rt_photon_map_nodes", "rt_kd_build", "rt_find_median",
+    "rt_kd_radius", "rt_kd_knn", "rt_gather_radiance", "rt_trace_tile",
+]
+
+
+class RtError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"rt355 error {code}: {msg}")
+        self.code = code
+
+
+class SceneDesc(C.Structure):
+    _fields_ = [("n_shapes", C.c_uint32), ("shape_meta", C.c_void_p), ("shape_geom", C.c_void_p),
+                ("shape_colour", C.c_void_p), ("n_lights", C.c_uint32), ("light_shape", C.c_void_p),
+                ("light_data", C.c_void_p), ("camera", C.c_double * 16), ("width", C.c_uint32),
+                ("height", C.c_uint32), ("materials", (C.c_double * 8) * 4)]
+
+
+class Params(C.Structure):
+    _fields_ = [("epsilon", C.c_double), ("max_trace_dist", C.c_double), ("max_depth", C.c_int32),
+                ("sub_sample", C.c_int32), ("num_photons_diffuse", C.c_uint32),
+                ("num_photons_caustic", C.c_uint32), ("diffuse_radius", C.c_double),
+                ("caustic_radius", C.c_double), ("standard_lamp_area", C.c_double), ("seed", C.c_uint64),
+                ("use_direct_light", C.c_int32), ("use_photon_maps", C.c_int32), ("precision", C.c_int32),
+                ("mode", C.c_int32), ("shadow_bias", C.c_double), ("max_bounces", C.c_int32),
+                ("reserved", C.c_int32)]
+
+
+class TraceStats(C.Structure):
+    _fields_ = [("rays", C.c_uint64), ("shadow_rays", C.c_uint64), ("gathers", C.c_uint64),
+                ("bounces", C.c_uint64), ("stack_overflows", C.c_uint64)]
+
+
+class EmitStats(C.Structure):
+    _fields_ = [("attempts_phase1", C.c_uint64), ("attempts_phase2", C.c_uint64), ("segments", C.c_uint64),
+                ("n_diffuse", C.c_uint32), ("n_caustic", C.c_uint32), ("capped", C.c_int32), ("errors", C.c_int32)]
+
+
+_LIB = None
+
+
+def load_library():
+    """dlopen librt355.so; raises if it has not been built (never falls back to anything)."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing: build it with `make -C raytracer_amd/csrc` "
+                               "(or __graft_entry__.build()); there is no CPU path")
+        lib = C.CDLL(LIB_PATH)
+        lib.rt_last_error.restype = C.c_char_p
+        lib.rt_last_error.argtypes = [C.c_void_p]
+        lib.rt_stream.restype = C.c_void_p
+        lib.rt_stream.argtypes = [C.c_void_p]
+        lib.rt_find_median.restype = C.c_uint32
+        lib.rt_photon_map_size.restype = C.c_uint32
+        lib.rt_photon_map_size.argtypes = [C.c_void_p]
+        for name in ("rt_shutdown", "rt_scene_free", "rt_photon_map_free"):
+            getattr(lib, name).argtypes = [C.c_void_p]
+            getattr(lib, name).restype = None
+        _LIB = lib
+    return _LIB
+
+
+def default_params(**kw) -> Params:
+    p = Params()
+    load_library().rt_default_params(C.byref(p))
+    for k, v in kw.items():
+        if not hasattr(p, k):
+            raise AttributeError(k)
+        setattr(p, k, v)
+    return p
+
+
+def _ptr(a):
+    """host numpy array, torch tensor (host or device) or None -> void*"""
+    if a is None:
+        return C.c_void_p(None)
+    if isinstance(a, np.ndarray):
+        assert a.flags["C_CONTIGUOUS"]
+        return a.ctypes.data_as(C.c_void_p)
+    if hasattr(a, "data_ptr"):
+        assert a.is_contiguous()
+        return C.c_void_p(a.data_ptr())
+    raise TypeError(type(a))
+
+
+def _c(a, dtype):
+    return np.ascontiguousarray(a, dtype=dtype)
+
+
+class Context:
+    def __init__(self, device: int = 0):
+        self.lib = load_library()
+        h = C.c_void_p()
+        ids = (C.c_int * 1)(device)
+        rc = self.lib.rt_init(ids, 1, C.byref(h))
+        if rc != 0:
+            raise RtError(rc, self.lib.rt_last_error(None).decode())
+        self.h = h
+        self.device = device
+
+    def check(self, rc):
+        if rc != 0:
+            raise RtError(rc, self.lib.rt_last_error(self.h).decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.rt_shutdown(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def stream(self) -> int:
+        return self.lib.rt_stream(self.h) or 0
+
+    def synchronize(self):
+        self.check(self.lib.rt_synchronize(self.h))
+
+    # -- profiling
+    def profile_enable(self, on=True):
+        self.check(self.lib.rt_profile_enable(self.h, int(on)))
+
+    def profile_reset(self):
+        self.check(self.lib.rt_profile_reset(self.h))
+
+    def profile_get(self, kernel: str):
+        ms, n = C.c_double(), C.c_uint64()
+        self.check(self.lib.rt_profile_get(self.h, kernel.encode(), C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    # -- geometry kernel
+    def intersect_pairs(self, params, ray_o, ray_d, shape_meta, shape_geom, normalize_dir=False):
+        o, d = _c(ray_o, np.float64), _c(ray_d, np.float64)
+        meta, geom = _c(shape_meta, np.uint8), _c(shape_geom, np.float64)
+        n = o.shape[0]
+        t = np.empty(n, np.float64)
+        self.check(self.lib.rt_intersect_pairs(self.h, C.byref(params), C.c_uint32(n), _ptr(o), _ptr(d),
+                                               C.c_int(int(normalize_dir)), _ptr(meta), _ptr(geom), _ptr(t)))
+        return t
+
+    def kd_build(self, pos):
+        pos = _c(pos, np.float32)
+        n = pos.shape[0]
+        perm = np.empty(n, np.int32)
+        dim = np.empty(n, np.uint8)
+        self.check(self.lib.rt_kd_build(self.h, _ptr(pos), C.c_uint32(n), _ptr(perm), _ptr(dim)))
+        return perm, dim
+
+    def find_median(self, n):
+        return self.lib.rt_find_median(C.c_uint32(n))
+
+    def upload(self, flat: FlatScene) -> "Scene":
+        return Scene(self, flat)
+
+    def photon_map(self, rec) -> "PhotonMap":
+        return PhotonMap(self, rec)
+
+
+class Scene:
+    def __init__(self, ctx: Context, flat: FlatScene):
+        flat.validate()
+        self.ctx, self.flat = ctx, flat
+        keep = [_c(flat.shape_meta, np.uint8), _c(flat.shape_geom, np.float64), _c(flat.shape_colour, np.float64),
+                _c(flat.light_shape, np.uint32), _c(flat.light_data, np.float64)]
+        d = SceneDesc()
+        d.n_shapes = flat.n_shapes
+        d.shape_meta, d.shape_geom, d.shape_colour = (a.ctypes.data for a in keep[:3])
+        d.n_lights = flat.n_lights
+        d.light_shape, d.light_data = keep[3].ctypes.data, keep[4].ctypes.data
+        for i in range(16):
+            d.camera[i] = float(flat.camera[i])
+        d.width, d.height = flat.width, flat.height
+        for r in range(4):
+            for k in range(8):
+                d.materials[r][k] = float(flat.materials[r, k])
+        h = C.c_void_p()
+        ctx.check(ctx.lib.rt_scene_upload(ctx.h, C.byref(d), C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None) and self.ctx.h:
+            self.ctx.lib.rt_scene_free(self.h)
+        self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def intersect(self, params, mode, ray_o, ray_d, source_dist=None):
+        o, d = _c(ray_o, np.float64), _c(ray_d, np.float64)
+        n = o.shape[0]
+        sd = _c(source_dist, np.float64) if source_dist is not None else None
+        t = np.empty(n, np.float64)
+        idx = np.empty(n, np.int32)
+        self.ctx.check(self.ctx.lib.rt_intersect(self.h, C.byref(params), C.c_int(mode), C.c_uint32(n), _ptr(o), _ptr(d),
+                                                 _ptr(sd), _ptr(t), _ptr(idx)))
+        return t, idx
+
+    def trace_tile(self, params, diffuse=None, caustic=None, x0=0, y0=0, w=None, h=None, want=("pre", "post"),
+                   out_pre=None, out_post=None, out_rgba8=None):
+        """Renders a tile.  `want` selects host outputs to allocate; out_* accept caller buffers
+        (numpy arrays or device tensors), in which case nothing is allocated for that output."""
+        w = self.flat.width if w is None else w
+        h = self.flat.height if h is None else h
+        pre = out_pre if out_pre is not None else (np.empty((h, w, 4), np.float64) if "pre" in want else None)
+        post = out_post if out_post is not None else (np.empty((h, w, 4), np.float64) if "post" in want else None)
+        rgba8 = out_rgba8 if out_rgba8 is not None else (np.empty((h, w, 4), np.uint8) if "rgba8" in want else None)
+        st = TraceStats()
+        self.ctx.check(self.ctx.lib.rt_trace_tile(
+            self.h, C.byref(params), C.c_void_p(diffuse.h.value if diffuse else None),
+            C.c_void_p(caustic.h.value if caustic else None), C.c_int(x0), C.c_int(y0), C.c_int(w), C.c_int(h),
+            _ptr(pre), _ptr(post), _ptr(rgba8), C.byref(st)))
+        return dict(pre=pre, post=post, rgba8=rgba8, stats={k: getattr(st, k) for k, _ in TraceStats._fields_})
+
+    def emit_photons(self, params, phase, a0, a1):
+        cap = max(a1 - a0, 1)
+        rec = np.zeros((cap, 11), np.float64)
+        att = np.zeros(cap, np.int64)
+        kind = np.zeros(cap, np.uint8)
+        n = C.c_uint32()
+        st = EmitStats()
+        self.ctx.check(self.ctx.lib.rt_emit_photons(self.h, C.byref(params), C.c_int(phase), C.c_uint64(a0), C.c_uint64(a1),
+                                                    C.c_uint32(cap), _ptr(rec), _ptr(att), _ptr(kind), C.byref(n), C.byref(st)))
+        k = n.value
+        return rec[:k], att[:k], kind[:k], {f: getattr(st, f) for f, _ in EmitStats._fields_}
+
+    def emit_many(self, params, strict=True):
+        nd, nc = params.num_photons_diffuse, params.num_photons_caustic
+        diffuse = np.zeros((nd, 11), np.float64)
+        caustic = np.zeros((nc, 11), np.float64)
+        da = np.zeros((nd, 2), np.int64)
+        ca = np.zeros((nc, 2), np.int64)
+        st = EmitStats()
+        rc = self.ctx.lib.rt_emit_many(self.h, C.byref(params), _ptr(diffuse), _ptr(da), _ptr(caustic), _ptr(ca), C.byref(st))
+        if rc != 0 and strict:
+            self.ctx.check(rc)
+        stats = {f: getattr(st, f) for f, _ in EmitStats._fields_}
+        stats["rc"] = rc
+        return dict(diffuse=diffuse[:st.n_diffuse], diffuse_attempt=da[:st.n_diffuse], caustic=caustic[:st.n_caustic],
+                    caustic_attempt=ca[:st.n_caustic], stats=stats)
+
+
+class PhotonMap:
+    """`new KdTree(photons)`: rec is (n, 11) float64 records origin3 dir3 power rgba."""
+
+    def __init__(self, ctx: Context, rec):
+        self.ctx = ctx
+        if isinstance(rec, np.ndarray):
+            rec = _c(rec, np.float64)
+        n = rec.shape[0]
+        h = C.c_void_p()
+        ctx.check(ctx.lib.rt_photon_map_build(ctx.h, _ptr(rec) if n else C.c_void_p(None), C.c_uint32(n), C.byref(h)))
+        self.h = h
+        self.n = n
+
+    def close(self):
+        if getattr(self, "h", None) and self.ctx.h:
+            self.ctx.lib.rt_photon_map_free(self.h)
+        self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def nodes(self):
+        perm = np.empty(self.n, np.int32)
+        dim = np.empty(self.n, np.uint8)
+        self.ctx.check(self.ctx.lib.rt_photon_map_nodes(self.h, _ptr(perm), _ptr(dim)))
+        return perm, dim
+
+    def radius(self, queries, r, cap=256):
+        q = _c(queries, np.float32) if isinstance(queries, np.ndarray) else queries
+        nq = q.shape[0]
+        count = np.empty(nq, np.uint32)
+        idx = np.full((nq, cap), -1, np.int32)
+        self.ctx.check(self.ctx.lib.rt_kd_radius(self.h, _ptr(q), C.c_uint32(nq), C.c_double(r), C.c_uint32(cap), _ptr(count), _ptr(idx)))
+        return count, idx
+
+    def knn(self, queries, k, out_idx=None, out_d2=None):
+        q = _c(queries, np.float32) if isinstance(queries, np.ndarray) else queries
+        nq = q.shape[0]
+        idx = out_idx if out_idx is not None else np.empty((nq, k), np.int32)
+        d2 = out_d2 if out_d2 is not None else np.empty((nq, k), np.float64)
+        self.ctx.check(self.ctx.lib.rt_kd_knn(self.h, _ptr(q), C.c_uint32(nq), C.c_uint32(k), _ptr(idx), _ptr(d2)))
+        return idx, d2
+
+    def gather(self, hits, r=0.0, k=0, out=None):
+        h = _c(hits, np.float32) if isinstance(hits, np.ndarray) else hits
+        nq = h.shape[0]
+        rgb = out if out is not None else np.empty((nq, 3), np.float32)
+        self.ctx.check(self.ctx.lib.rt_gather_radiance(self.h, _ptr(h), C.c_uint32(nq), C.c_double(r), C.c_uint32(k), _ptr(rgb)))
+        return rgb

@@ -1,0 +1,387 @@
+// C ABI of librt355.so (include/rt355.h): context, scene upload, and the entry points that
+// dispatch to the fp32 / fp64 pipelines.  No CPU fallback exists: every entry point runs HIP
+// kernels or fails.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdarg.h>
+#include <string.h>
+#include <algorithm>
+#include "rt_emit.h"
+#include "rt_pipeline.h"
+
+static std::string g_init_error;
+
+int rt_fail(rt_ctx *ctx, int code, const char *fmt, ...) {
+  char buf[1024];
+  va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+  if (ctx) ctx->err = buf; else g_init_error = buf;
+  return code;
+}
+
+bool rt_is_device_ptr(const void *p) {
+  if (!p) return false;
+  hipPointerAttribute_t attr;
+  hipError_t e = hipPointerGetAttributes(&attr, p);
+  if (e != hipSuccess) { (void)hipGetLastError(); return false; }     // plain host memory is "invalid value": clear it
+  return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged;
+}
+
+int rt_stage_in(rt_ctx *ctx, const void *src, size_t bytes, DevMem &tmp, const void **out) {
+  if (!src && bytes) return rt_fail(ctx, RT_ERR_INVALID, "null input array");
+  if (rt_is_device_ptr(src)) { *out = src; return RT_OK; }
+  RT_HIP(ctx, tmp.alloc(bytes));
+  if (bytes) RT_HIP(ctx, hipMemcpyAsync(tmp.p, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+  *out = tmp.p;
+  return RT_OK;
+}
+int rt_stage_out_begin(rt_ctx *ctx, void *dst, size_t bytes, DevMem &tmp, void **out) {
+  if (!dst) { *out = nullptr; return RT_OK; }
+  if (rt_is_device_ptr(dst)) { *out = dst; return RT_OK; }
+  RT_HIP(ctx, tmp.alloc(bytes));
+  *out = tmp.p;
+  return RT_OK;
+}
+int rt_stage_out_end(rt_ctx *ctx, void *dst, size_t bytes, DevMem &tmp) {
+  if (dst && tmp.p && bytes) RT_HIP(ctx, hipMemcpyAsync(dst, tmp.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return RT_OK;
+}
+
+// (the entry points below take C linkage from their declarations in rt355.h)
+
+void rt_default_params(rt_params *p) {
+  memset(p, 0, sizeof *p);
+  p->epsilon = 1e-6; p->max_trace_dist = 20; p->max_depth = 5; p->sub_sample = 1;
+  p->num_photons_diffuse = 20000; p->num_photons_caustic = 50000;
+  p->diffuse_radius = 0.40; p->caustic_radius = 0.15; p->standard_lamp_area = 100;
+  p->seed = 12345; p->use_direct_light = 1; p->use_photon_maps = 1;
+  p->precision = RT_PRECISION_F32; p->mode = RT_MODE_PHOTON; p->shadow_bias = 0; p->max_bounces = 64;
+}
+
+int rt_init(const int *device_ids, int n, rt_ctx **out) {
+  if (!out) return RT_ERR_INVALID;
+  *out = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count == 0) {
+    (void)hipGetLastError();
+    return rt_fail(nullptr, RT_ERR_NO_DEVICE, "no HIP device visible: librt355 has no CPU path");
+  }
+  int dev = (device_ids && n > 0) ? device_ids[0] : 0;
+  if (dev < 0 || dev >= count) return rt_fail(nullptr, RT_ERR_NO_DEVICE, "device %d out of range (%d visible)", dev, count);
+  rt_ctx *ctx = new rt_ctx();
+  ctx->device = dev;
+  if (hipSetDevice(dev) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
+      hipHostMalloc((void **)&ctx->pinned, 256, hipHostMallocDefault) != hipSuccess) {
+    rt_fail(nullptr, RT_ERR_HIP, "context creation failed: %s", hipGetErrorString(hipGetLastError()));
+    delete ctx;
+    return RT_ERR_HIP;
+  }
+  *out = ctx;
+  return RT_OK;
+}
+
+void rt_shutdown(rt_ctx *ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  for (auto &kv : ctx->events) for (auto &ev : kv.second) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+  if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+  (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+const char *rt_last_error(rt_ctx *ctx) { return ctx ? ctx->err.c_str() : g_init_error.c_str(); }
+void *rt_stream(rt_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+int rt_synchronize(rt_ctx *ctx) {
+  if (!ctx) return RT_ERR_INVALID;
+  RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return RT_OK;
+}
+
+int rt_profile_enable(rt_ctx *ctx, int on) { if (!ctx) return RT_ERR_INVALID; ctx->profiling = on != 0; return RT_OK; }
+int rt_profile_reset(rt_ctx *ctx) {
+  if (!ctx) return RT_ERR_INVALID;
+  RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  for (auto &kv : ctx->events) for (auto &ev : kv.second) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+  ctx->events.clear();
+  return RT_OK;
+}
+int rt_profile_get(rt_ctx *ctx, const char *kernel, double *total_ms, uint64_t *launches) {
+  if (!ctx || !kernel) return RT_ERR_INVALID;
+  RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  double tot = 0; uint64_t n = 0;
+  auto it = ctx->events.find(kernel);
+  if (it != ctx->events.end())
+    for (auto &ev : it->second) { float ms = 0; if (hipEventElapsedTime(&ms, ev.first, ev.second) == hipSuccess) { tot += ms; n++; } }
+  if (total_ms) *total_ms = tot;
+  if (launches) *launches = n;
+  return RT_OK;
+}
+
+// ------------------------------------------------------------------ scene
+template <typename T> static int upload_typed(rt_ctx *ctx, const rt_scene_desc *d, const std::vector<uint32_t> &order, DevMem &geom,
+                                              DevMem &colour, DevMem &sgeom, DevScene<T> &S, rt_scene *sc) {
+  const uint32_t n = d->n_shapes;
+  std::vector<T> g((size_t)n * 12), c((size_t)n * 4), sg((size_t)n * 12);
+  for (size_t i = 0; i < (size_t)n * 12; i++) g[i] = (T)d->shape_geom[i];
+  for (size_t i = 0; i < (size_t)n * 4; i++) c[i] = (T)d->shape_colour[i];
+  for (uint32_t s = 0; s < n; s++) for (int k = 0; k < 12; k++) sg[(size_t)s * 12 + k] = g[(size_t)order[s] * 12 + k];
+  RT_HIP(ctx, geom.alloc(g.size() * sizeof(T))); RT_HIP(ctx, colour.alloc(c.size() * sizeof(T))); RT_HIP(ctx, sgeom.alloc(sg.size() * sizeof(T)));
+  RT_HIP(ctx, hipMemcpy(geom.p, g.data(), g.size() * sizeof(T), hipMemcpyHostToDevice));
+  RT_HIP(ctx, hipMemcpy(colour.p, c.data(), c.size() * sizeof(T), hipMemcpyHostToDevice));
+  RT_HIP(ctx, hipMemcpy(sgeom.p, sg.data(), sg.size() * sizeof(T), hipMemcpyHostToDevice));
+  memset(&S, 0, sizeof S);
+  S.n_shapes = n; S.n_lights = d->n_lights;
+  S.meta = sc->meta.as<uint8_t>(); S.geom = geom.as<T>(); S.colour = colour.as<T>(); S.sgeom = sgeom.as<T>();
+  S.sorig = sc->sorig.as<uint32_t>(); S.sflags = sc->sflags.as<uint8_t>();
+  for (uint32_t l = 0; l < d->n_lights; l++) {
+    S.light_shape[l] = d->light_shape[l];
+    for (int k = 0; k < 8; k++) S.light_data[l][k] = (T)d->light_data[(size_t)l * 8 + k];
+  }
+  for (int k = 0; k < 16; k++) S.camera[k] = (T)d->camera[k];
+  S.width = d->width; S.height = d->height;
+  for (int r = 0; r < 4; r++) for (int k = 0; k < 8; k++) S.mat[r][k] = (T)d->materials[r][k];
+  for (int k = 0; k < 8; k++) { S.refl_k[k] = rt_threshold_u24(d->materials[2][k]); S.spec_k[k] = rt_threshold_u24(d->materials[3][k]); }
+  return RT_OK;
+}
+
+int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *d, rt_scene **out) {
+  if (!ctx || !d || !out) return RT_ERR_INVALID;
+  *out = nullptr;
+  if (d->n_shapes == 0 || !d->shape_meta || !d->shape_geom || !d->shape_colour) return rt_fail(ctx, RT_ERR_INVALID, "scene has no shapes");
+  if (d->n_lights > RT_MAX_LIGHTS) return rt_fail(ctx, RT_ERR_TOO_LARGE, "at most %d lights", RT_MAX_LIGHTS);
+  if (d->n_lights && (!d->light_shape || !d->light_data)) return rt_fail(ctx, RT_ERR_INVALID, "light arrays missing");
+  if (d->width == 0 || d->height == 0) return rt_fail(ctx, RT_ERR_INVALID, "canvas size is zero");
+  const uint32_t n = d->n_shapes;
+  for (uint32_t i = 0; i < n; i++)
+    if (d->shape_meta[4 * i] >= RT_NUM_TYPES)                               // rayphoton.js:639-642 throws
+      return rt_fail(ctx, RT_ERR_UNKNOWN_SHAPE, "I didn't recognize the shape! (%d)", (int)d->shape_meta[4 * i]);
+  for (uint32_t l = 0; l < d->n_lights; l++) {
+    uint32_t s = d->light_shape[l];
+    if (s >= n || d->shape_meta[4 * s] != RT_DISC || !(d->shape_meta[4 * s + 2] & RT_FLAG_LIGHT))
+      return rt_fail(ctx, RT_ERR_INVALID, "light %u does not point at a light disc", l);
+  }
+  RT_HIP(ctx, hipSetDevice(ctx->device));
+  rt_scene *sc = new rt_scene();
+  sc->ctx = ctx;
+  // type-sorted order, stable in the original index
+  std::vector<uint32_t> order(n);
+  for (uint32_t i = 0; i < n; i++) order[i] = i;
+  std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return d->shape_meta[4 * a] < d->shape_meta[4 * b]; });
+  std::vector<uint8_t> sflags(n);
+  uint32_t seg[RT_NUM_TYPES + 1] = { 0 };
+  for (uint32_t s = 0; s < n; s++) { sflags[s] = d->shape_meta[4 * order[s] + 2]; seg[d->shape_meta[4 * order[s]] + 1]++; }
+  for (int t = 0; t < RT_NUM_TYPES; t++) seg[t + 1] += seg[t];
+  int rc = RT_OK;
+  auto up = [&](DevMem &m, const void *src, size_t bytes) -> int {
+    RT_HIP(ctx, m.alloc(bytes)); RT_HIP(ctx, hipMemcpy(m.p, src, bytes, hipMemcpyHostToDevice)); return RT_OK;
+  };
+  if ((rc = up(sc->meta, d->shape_meta, (size_t)n * 4)) || (rc = up(sc->sorig, order.data(), (size_t)n * 4)) ||
+      (rc = up(sc->sflags, sflags.data(), n)) ||
+      (rc = upload_typed<float>(ctx, d, order, sc->geom32, sc->colour32, sc->sgeom32, sc->d32, sc)) ||
+      (rc = upload_typed<double>(ctx, d, order, sc->geom64, sc->colour64, sc->sgeom64, sc->d64, sc))) {
+    delete sc; return rc;
+  }
+  memcpy(sc->d32.seg, seg, sizeof seg); memcpy(sc->d64.seg, seg, sizeof seg);
+  *out = sc;
+  return RT_OK;
+}
+void rt_scene_free(rt_scene *sc) { if (sc) { (void)hipSetDevice(sc->ctx->device); delete sc; } }
+
+// ------------------------------------------------------------------ geometry kernel surfaces
+int rt_intersect_pairs(rt_ctx *ctx, const rt_params *p, uint32_t n, const double *ray_o, const double *ray_d, int normalize_dir,
+                       const uint8_t *shape_meta, const double *shape_geom, double *t_out) {
+  if (!ctx || !p || !t_out) return RT_ERR_INVALID;
+  if (n == 0) return RT_OK;
+  RT_HIP(ctx, hipSetDevice(ctx->device));
+  DevMem to, td, tm, tg, tt; const void *o, *d, *m, *g; void *t;
+  RT_TRY(rt_stage_in(ctx, ray_o, (size_t)n * 24, to, &o)); RT_TRY(rt_stage_in(ctx, ray_d, (size_t)n * 24, td, &d));
+  RT_TRY(rt_stage_in(ctx, shape_meta, (size_t)n * 4, tm, &m)); RT_TRY(rt_stage_in(ctx, shape_geom, (size_t)n * 96, tg, &g));
+  RT_TRY(rt_stage_out_begin(ctx, t_out, (size_t)n * 8, tt, &t));
+  if (p->precision == RT_PRECISION_F64)
+    RT_TRY(pl_intersect_pairs<double>(ctx, p, n, (const double *)o, (const double *)d, normalize_dir, (const uint8_t *)m, (const double *)g, (double *)t));
+  else
+    RT_TRY(pl_intersect_pairs<float>(ctx, p, n, (const double *)o, (const double *)d, normalize_dir, (const uint8_t *)m, (const double *)g, (double *)t));
+  return rt_stage_out_end(ctx, t_out, (size_t)n * 8, tt);
+}
+
+int rt_intersect(rt_scene *sc, const rt_params *p, int mode, uint32_t n, const double *ray_o, const double *ray_d,
+                 const double *source_dist, double *t_out, int32_t *idx_out) {
+  if (!sc || !p || !idx_out) return RT_ERR_INVALID;
+  rt_ctx *ctx = sc->ctx;
+  if (mode < 0 || mode > 2) return rt_fail(ctx, RT_ERR_INVALID, "unknown scan mode %d", mode);
+  if (mode == RT_SCAN_ANY && !source_dist) return rt_fail(ctx, RT_ERR_INVALID, "any-hit scan needs source_dist");
+  if (n == 0) return RT_OK;
+  RT_HIP(ctx, hipSetDevice(ctx->device));
+  DevMem to, td, ts, tt, ti; const void *o, *d, *s = nullptr; void *t, *i;
+  RT_TRY(rt_stage_in(ctx, ray_o, (size_t)n * 24, to, &o)); RT_TRY(rt_stage_in(ctx, ray_d, (size_t)n * 24, td, &d));
+  if (source_dist) RT_TRY(rt_stage_in(ctx, source_dist, (size_t)n * 8, ts, &s));
+  RT_TRY(rt_stage_out_begin(ctx, t_out, (size_t)n * 8, tt, &t)); RT_TRY(rt_stage_out_begin(ctx, idx_out, (size_t)n * 4, ti, &i));
+  if (p->precision == RT_PRECISION_F64)
+    RT_TRY(pl_intersect_scene<double>(sc, p, mode, n, (const double *)o, (const double *)d, (const double *)s, (double *)t, (int32_t *)i));
+  else
+    RT_TRY(pl_intersect_scene<float>(sc, p, mode, n, (const double *)o, (const double *)d, (const double *)s, (double *)t, (int32_t *)i));
+  RT_TRY(rt_stage_out_end(ctx, t_out, (size_t)n * 8, tt));
+  return rt_stage_out_end(ctx, idx_out, (size_t)n * 4, ti);
+}
+
+// ------------------------------------------------------------------ renderer
+int rt_trace_tile(rt_scene *sc, const rt_params *p, rt_photon_map *diffuse, rt_photon_map *caustic, int x0, int y0, int w, int h,
+                  double *pre_rgba, double *post_rgba, uint8_t *rgba8, rt_trace_stats *stats) {
+  if (!sc || !p) return RT_ERR_INVALID;
+  rt_ctx *ctx = sc->ctx;
+  if (w <= 0 || h <= 0 || x0 < 0 || y0 < 0 || (uint32_t)(x0 + w) > sc->d32.width || (uint32_t)(y0 + h) > sc->d32.height)
+    return rt_fail(ctx, RT_ERR_INVALID, "tile [%d,%d)+[%d,%d) outside the %ux%u canvas", x0, y0, w, h, sc->d32.width, sc->d32.height);
+  if (p->sub_sample < 1 || p->sub_sample > 64) return rt_fail(ctx, RT_ERR_INVALID, "sub_sample must be in 1..64");
+  if (p->mode != RT_MODE_PHOTON) return rt_fail(ctx, RT_ERR_INVALID, "mode %d not available", p->mode);
+  if ((diffuse && diffuse->ctx != ctx) || (caustic && caustic->ctx != ctx)) return rt_fail(ctx, RT_ERR_INVALID, "photon map belongs to another context");
+  RT_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t npx = (size_t)w * h;
+  DevMem t1, t2, t3; void *pre, *post, *r8;
+  RT_TRY(rt_stage_out_begin(ctx, pre_rgba, npx * 32, t1, &pre));
+  RT_TRY(rt_stage_out_begin(ctx, post_rgba, npx * 32, t2, &post));
+  RT_TRY(rt_stage_out_begin(ctx, rgba8, npx * 4, t3, &r8));
+  DevMap md, mc; memset(&md, 0, sizeof md); memset(&mc, 0, sizeof mc);
+  if (diffuse) md = diffuse->view();
+  if (caustic) mc = caustic->view();
+  if (p->precision == RT_PRECISION_F64)
+    RT_TRY(pl_trace_tile<double>(sc, p, md, mc, x0, y0, w, h, (double *)pre, (double *)post, (uint8_t *)r8, stats));
+  else
+    RT_TRY(pl_trace_tile<float>(sc, p, md, mc, x0, y0, w, h, (double *)pre, (double *)post, (uint8_t *)r8, stats));
+  RT_TRY(rt_stage_out_end(ctx, pre_rgba, npx * 32, t1));
+  RT_TRY(rt_stage_out_end(ctx, post_rgba, npx * 32, t2));
+  return rt_stage_out_end(ctx, rgba8, npx * 4, t3);
+}
+
+// ------------------------------------------------------------------ emission
+int pl_emit_counters(rt_scene *sc, bool reset, uint64_t *segments, uint64_t *errors) {
+  rt_ctx *ctx = sc->ctx;
+  EmitCounters hc; memset(&hc, 0, sizeof hc);
+  if (sc->ws_misc.p) {
+    RT_HIP(ctx, hipMemcpyAsync(&hc, sc->ws_misc.p, sizeof hc, hipMemcpyDeviceToHost, ctx->stream));
+    if (reset) RT_HIP(ctx, hipMemsetAsync(sc->ws_misc.p, 0, sizeof hc, ctx->stream));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  if (segments) *segments = hc.segments;
+  if (errors) *errors = hc.errors;
+  return RT_OK;
+}
+
+static int emit_batch(rt_scene *sc, const rt_params *p, int phase, uint64_t a0, uint32_t count) {
+  return p->precision == RT_PRECISION_F64 ? pl_emit_batch<double>(sc, p, phase, a0, count) : pl_emit_batch<float>(sc, p, phase, a0, count);
+}
+static int emit_compact(rt_scene *sc, const rt_params *p, uint32_t count, int want, uint64_t a0, uint32_t base, uint32_t cap,
+                        double *rec, int64_t *att, uint8_t *kind, uint32_t *n) {
+  return p->precision == RT_PRECISION_F64 ? pl_emit_compact<double>(sc, count, want, a0, base, cap, rec, att, kind, n)
+                                          : pl_emit_compact<float>(sc, count, want, a0, base, cap, rec, att, kind, n);
+}
+
+int rt_emit_photons(rt_scene *sc, const rt_params *p, int phase, uint64_t attempt_begin, uint64_t attempt_end, uint32_t cap,
+                    double *rec_out, int64_t *attempt_out, uint8_t *kind_out, uint32_t *n_out, rt_emit_stats *stats) {
+  if (!sc || !p || !rec_out || !n_out) return RT_ERR_INVALID;
+  rt_ctx *ctx = sc->ctx;
+  if (phase != 1 && phase != 2) return rt_fail(ctx, RT_ERR_INVALID, "phase must be 1 or 2");
+  if (attempt_end < attempt_begin || attempt_end - attempt_begin > 0x7FFFFFFFull) return rt_fail(ctx, RT_ERR_INVALID, "bad attempt range");
+  if (sc->d32.n_lights == 0) return rt_fail(ctx, RT_ERR_INVALID, "No lights! Can't emit photons.");     // rayphoton.js:1355-1358
+  *n_out = 0;
+  const uint32_t count = (uint32_t)(attempt_end - attempt_begin);
+  if (count == 0) return RT_OK;
+  RT_HIP(ctx, hipSetDevice(ctx->device));
+  DevMem t1, t2, t3; void *rec, *att, *kind;
+  RT_TRY(rt_stage_out_begin(ctx, rec_out, (size_t)cap * 88, t1, &rec));
+  RT_TRY(rt_stage_out_begin(ctx, attempt_out, (size_t)cap * 8, t2, &att));
+  RT_TRY(rt_stage_out_begin(ctx, kind_out, (size_t)cap, t3, &kind));
+  RT_TRY(pl_emit_counters(sc, true, nullptr, nullptr));
+  RT_TRY(emit_batch(sc, p, phase, attempt_begin, count));
+  uint32_t n = 0;
+  RT_TRY(emit_compact(sc, p, count, 0, attempt_begin, 0, cap, (double *)rec, (int64_t *)att, (uint8_t *)kind, &n));
+  *n_out = n < cap ? n : cap;
+  if (stats) {
+    memset(stats, 0, sizeof *stats);
+    uint64_t seg = 0, err = 0;
+    RT_TRY(pl_emit_counters(sc, true, &seg, &err));
+    stats->segments = seg; stats->errors = (int32_t)err;
+    if (phase == 1) stats->attempts_phase1 = count; else stats->attempts_phase2 = count;
+  }
+  RT_TRY(rt_stage_out_end(ctx, rec_out, (size_t)*n_out * 88, t1));
+  RT_TRY(rt_stage_out_end(ctx, attempt_out, (size_t)*n_out * 8, t2));
+  return rt_stage_out_end(ctx, kind_out, (size_t)*n_out, t3);
+}
+
+// emitManyPhotons (rayphoton.js:1354-1383) in batches.  A batch's stored photons come back as two
+// attempt-ordered lists; list caps are then applied exactly as the sequential loop would:
+// phase 1 ends with the attempt that stores the N_D-th diffuse photon, caustic photons of
+// phase-1 attempts up to that one are kept (up to N_C), phase 2 stops at the N_C-th caustic.
+int rt_emit_many(rt_scene *sc, const rt_params *p, double *diffuse, int64_t *diffuse_attempt, double *caustic,
+                 int64_t *caustic_attempt, rt_emit_stats *stats) {
+  if (!sc || !p) return RT_ERR_INVALID;
+  rt_ctx *ctx = sc->ctx;
+  rt_emit_stats st; memset(&st, 0, sizeof st);
+  if (stats) *stats = st;
+  if (sc->d32.n_lights == 0) return rt_fail(ctx, RT_ERR_INVALID, "No lights! Can't emit photons.");
+  const uint32_t ND = p->num_photons_diffuse, NC = p->num_photons_caustic;
+  RT_HIP(ctx, hipSetDevice(ctx->device));
+  DevMem t1, t2, bd, bc, bda, bca; void *drec, *crec;
+  RT_TRY(rt_stage_out_begin(ctx, diffuse, (size_t)ND * 88, t1, &drec));
+  RT_TRY(rt_stage_out_begin(ctx, caustic, (size_t)NC * 88, t2, &crec));
+  if (!drec) { RT_HIP(ctx, t1.alloc((size_t)ND * 88)); drec = t1.p; }
+  if (!crec) { RT_HIP(ctx, t2.alloc((size_t)NC * 88)); crec = t2.p; }
+  std::vector<int64_t> d_att, c_att;     // (phase, attempt) pairs of the accepted photons
+  RT_TRY(pl_emit_counters(sc, true, nullptr, nullptr));
+  uint32_t nd = 0, nc = 0;
+  int rc = RT_OK;
+  for (int phase = 1; phase <= 2 && !st.capped; phase++) {
+    uint64_t attempt = 0;
+    const uint64_t cap = 100ull * (phase == 1 ? ND : NC);
+    while (phase == 1 ? nd < ND : nc < NC) {
+      const uint32_t need = phase == 1 ? ND - nd : NC - nc;
+      uint64_t batch = std::min<uint64_t>(std::max<uint64_t>(4ull * need, 65536), 4u << 20);
+      batch = std::min<uint64_t>(batch, cap + 1 - attempt);
+      const uint32_t count = (uint32_t)batch;
+      RT_TRY(emit_batch(sc, p, phase, attempt, count));
+      // attempt-ordered lists of this batch
+      RT_HIP(ctx, bd.reserve((size_t)count * 88)); RT_HIP(ctx, bc.reserve((size_t)count * 88));
+      RT_HIP(ctx, bda.reserve((size_t)count * 8)); RT_HIP(ctx, bca.reserve((size_t)count * 8));
+      uint32_t bnd = 0, bnc = 0;
+      RT_TRY(emit_compact(sc, p, count, 1, attempt, 0, count, bd.as<double>(), bda.as<int64_t>(), nullptr, &bnd));
+      RT_TRY(emit_compact(sc, p, count, 2, attempt, 0, count, bc.as<double>(), bca.as<int64_t>(), nullptr, &bnc));
+      std::vector<int64_t> hda(bnd), hca(bnc);
+      if (bnd) RT_HIP(ctx, hipMemcpy(hda.data(), bda.p, (size_t)bnd * 8, hipMemcpyDeviceToHost));
+      if (bnc) RT_HIP(ctx, hipMemcpy(hca.data(), bca.p, (size_t)bnc * 8, hipMemcpyDeviceToHost));
+      uint64_t last_attempt = attempt + count - 1;      // last attempt of this batch the sequential loop would run
+      uint32_t take_d = 0, take_c = 0;
+      if (phase == 1) {
+        take_d = std::min<uint32_t>(bnd, ND - nd);
+        if (nd + take_d == ND) last_attempt = (uint64_t)hda[take_d - 1];
+        uint32_t upto = (uint32_t)(std::upper_bound(hca.begin(), hca.end(), (int64_t)last_attempt) - hca.begin());
+        take_c = std::min<uint32_t>(upto, NC - nc);
+      } else {
+        take_c = std::min<uint32_t>(bnc, NC - nc);
+        if (nc + take_c == NC) last_attempt = (uint64_t)hca[take_c - 1];
+        // non-caustic absorptions of phase 2 would go to the diffuse list, which is already full
+      }
+      if (take_d) RT_HIP(ctx, hipMemcpyAsync((double *)drec + (size_t)nd * 11, bd.p, (size_t)take_d * 88, hipMemcpyDeviceToDevice, ctx->stream));
+      if (take_c) RT_HIP(ctx, hipMemcpyAsync((double *)crec + (size_t)nc * 11, bc.p, (size_t)take_c * 88, hipMemcpyDeviceToDevice, ctx->stream));
+      RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      for (uint32_t i = 0; i < take_d; i++) { d_att.push_back(phase); d_att.push_back(hda[i]); }
+      for (uint32_t i = 0; i < take_c; i++) { c_att.push_back(phase); c_att.push_back(hca[i]); }
+      nd += take_d; nc += take_c;
+      attempt = last_attempt + 1;
+      if (attempt > cap) { st.capped = 1; break; }      // `attempt++; if (attempt > 100 * N) return` (:1364-1368)
+    }
+    if (phase == 1) st.attempts_phase1 = attempt; else st.attempts_phase2 = attempt;
+  }
+  uint64_t seg = 0, err = 0;
+  RT_TRY(pl_emit_counters(sc, true, &seg, &err));
+  st.segments = seg; st.errors = (int32_t)err; st.n_diffuse = nd; st.n_caustic = nc;
+  if (stats) *stats = st;
+  if (diffuse_attempt) memcpy(diffuse_attempt, d_att.data(), d_att.size() * 8);
+  if (caustic_attempt) memcpy(caustic_attempt, c_att.data(), c_att.size() * 8);
+  if (diffuse) RT_TRY(rt_stage_out_end(ctx, diffuse, (size_t)nd * 88, t1));
+  if (caustic) RT_TRY(rt_stage_out_end(ctx, caustic, (size_t)nc * 88, t2));
+  if (err) rc = rt_fail(ctx, RT_ERR_MATERIAL_STACK, "photon exited all materials? check consistency of objects? (%llu attempts)",
+                        (unsigned long long)err);                                  // rayphoton.js:1489
+  else if (st.capped) rc = rt_fail(ctx, RT_ERR_ATTEMPT_CAP, "I tried many times but only created %u diffuse / %u caustic photons.", nd, nc);
+  return rc;
+}
+

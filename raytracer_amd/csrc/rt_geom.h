@@ -1,0 +1,229 @@
+// Geometry kernel: ray / primitive distance for the eight primitive types, surface normals,
+// albedo lookup and the three scene scans (closest, closest-without-lights, any-hit).
+// Templated on the working precision; the fp64 instantiation follows the reference's
+// operation order (Ray.intersectDist, rayphoton.js:490-644) so that it rounds identically.
+#pragma once
+#include "rt_math.h"
+#include "rt_trig.h"
+#include "../../include/rt355.h"
+
+#define RT_MAX_LIGHTS 16
+#define RT_GEOM_STRIDE 12
+
+// Device view of an uploaded scene.  Shapes are kept twice: in the host's order (for shading:
+// normals, colours, materials by original index) and sorted by primitive type (for the scan
+// loops: one branch-free inner loop per type, wave-uniform primitive loads).
+template <typename T> struct DevScene {
+  uint32_t n_shapes, n_lights;
+  const uint8_t *meta;        // n x 4, original order
+  const T *geom;              // n x 12, original order
+  const T *colour;            // n x 4, original order
+  const T *sgeom;             // n x 12, type-sorted
+  const uint32_t *sorig;      // sorted slot -> original index
+  const uint8_t *sflags;      // sorted slot -> flags
+  uint32_t seg[RT_NUM_TYPES + 1];   // type t occupies sorted slots [seg[t], seg[t+1])
+  uint32_t light_shape[RT_MAX_LIGHTS];
+  T light_data[RT_MAX_LIGHTS][8];   // wattage area prob r g b a reserved
+  T camera[16];
+  uint32_t width, height;
+  T mat[4][8];                // transparent, refrIndex, reflectance, specular (NaN = undefined)
+  uint32_t refl_k[8], spec_k[8];    // integer thresholds of `U < reflectance`, `U < specular`
+};
+
+// A miss is reported as -1 (every accepted distance is > epsilon > 0).
+template <typename T> RT_D T miss() { return T(-1); }
+
+// qRoots (rayphoton.js:1883-1898).  a == 0 makes the reference return a scalar, which its
+// callers index as an array and get `undefined`: a miss.
+template <typename T> RT_D bool q_roots(T a, T halfB, T c, T &t0, T &t1) {
+  if (a == T(0)) return false;
+  T disc = halfB * halfB - a * c;
+  if (disc < T(0)) return false;
+  disc = rt_sqrt(disc);
+  t0 = (-halfB - disc) / a; t1 = (-halfB + disc) / a;
+  return true;
+}
+
+template <typename T> RT_D T isect_plane(V3<T> o, V3<T> d, const T *g, T eps) {           // :492-501
+  V3<T> a = ld3(g), n = ld3(g + 3);
+  T dn = dot(d, n);
+  if (rt_abs(dn) < eps) return miss<T>();
+  T t = dot(a - o, n) / dn;
+  return t > eps ? t : miss<T>();
+}
+template <typename T> RT_D T isect_sphere(V3<T> o, V3<T> d, const T *g, T eps) {          // :502-519
+  V3<T> oc = o - ld3(g); T r = g[6], t0, t1;
+  T halfB = dot(d, oc);
+  T c = sqlen(oc) - r * r;
+  if (!q_roots<T>(T(1), halfB, c, t0, t1)) return miss<T>();
+  if (t0 > eps) return t0;
+  if (t1 > eps) return t1;
+  return miss<T>();
+}
+template <typename T> RT_D T isect_hemisphere(V3<T> o, V3<T> d, const T *g, int flags, T eps) {   // :520-539
+  V3<T> c = ld3(g), n = ld3(g + 3); T r = g[6], tmin = g[7], tmax = g[8], t0, t1;
+  V3<T> oc = o - c;
+  T halfB = dot(d, oc);
+  T cc = sqlen(oc) - r * r;
+  if (!q_roots<T>(T(1), halfB, cc, t0, t1)) return miss<T>();
+  bool has_max = flags & RT_FLAG_TRUNC_MAX;
+  if (t0 > eps) {
+    T proj = dot((o + t0 * d) - c, n);
+    if (proj > tmin && (!has_max || proj < tmax)) return t0;
+  }
+  if (t1 > eps) {
+    T proj = dot((o + t1 * d) - c, n);
+    if (proj > tmin && (!has_max || proj < tmax)) return t1;
+  }
+  return miss<T>();
+}
+template <typename T> RT_D T isect_cylinder(V3<T> o, V3<T> d, const T *g, int flags, T eps) {     // :540-567
+  V3<T> c = ld3(g), axis = ld3(g + 3); T r = g[6], h = g[7], t0, t1;
+  V3<T> v = o - c;
+  T vd = dot(v, d), va = dot(v, axis), da = dot(d, axis);
+  T a = T(1) - da * da;
+  T halfB = vd - va * da;
+  T cc = sqlen(v) - va * va - r * r;
+  if (!q_roots<T>(a, halfB, cc, t0, t1)) return miss<T>();
+  bool finite = flags & RT_FLAG_HALF_HEIGHT;
+  if (t0 > eps) {
+    if (!finite) return t0;
+    if (rt_abs(dot((o + t0 * d) - c, axis)) < h - eps) return t0;
+  }
+  if (t1 > eps) {
+    if (!finite) return t1;
+    if (rt_abs(dot((o + t1 * d) - c, axis)) < h - eps) return t1;
+  }
+  return miss<T>();
+}
+// Moeller-Trumbore for triangle (:568-588) and parallelogram "square" (:589-609)
+template <typename T, bool SQUARE> RT_D T isect_tri(V3<T> o, V3<T> d, const T *g, T eps) {
+  V3<T> A = ld3(g), AB = ld3(g + 3), AC = ld3(g + 6);
+  V3<T> h = cross(d, AC);
+  T a = dot(AB, h);
+  if (a > -eps && a < eps) return miss<T>();
+  T f = T(1) / a;
+  V3<T> s = o - A;
+  T u = f * dot(s, h);
+  if (u < T(0) || u > T(1)) return miss<T>();
+  V3<T> q = cross(s, AB);
+  T v = f * dot(d, q);
+  if (SQUARE) { if (v < T(0) || v > T(1)) return miss<T>(); }
+  else { if (v < T(0) || u + v > T(1)) return miss<T>(); }
+  T t = f * dot(AC, q);
+  return t > eps ? t : miss<T>();
+}
+template <typename T, bool ANNULUS> RT_D T isect_disc(V3<T> o, V3<T> d, const T *g, T eps) {      // :610-638
+  V3<T> c = ld3(g), n = ld3(g + 3);
+  T dn = dot(d, n);
+  if (rt_abs(dn) < eps) return miss<T>();
+  T t = dot(c - o, n) / dn;
+  if (!(t > eps)) return miss<T>();
+  T rSq = sqlen(c - (o + t * d));
+  if (ANNULUS) return (rSq + eps < g[6] * g[6] && rSq - eps > g[7] * g[7]) ? t : miss<T>();
+  return (rSq + eps < g[6] * g[6]) ? t : miss<T>();
+}
+
+template <typename T> RT_D T isect_any_type(V3<T> o, V3<T> d, int type, int flags, const T *g, T eps) {
+  switch (type) {
+    case RT_PLANE: return isect_plane<T>(o, d, g, eps);
+    case RT_SPHERE: return isect_sphere<T>(o, d, g, eps);
+    case RT_HEMISPHERE: return isect_hemisphere<T>(o, d, g, flags, eps);
+    case RT_CYLINDER: return isect_cylinder<T>(o, d, g, flags, eps);
+    case RT_TRIANGLE: return isect_tri<T, false>(o, d, g, eps);
+    case RT_SQUARE: return isect_tri<T, true>(o, d, g, eps);
+    case RT_DISC: return isect_disc<T, false>(o, d, g, eps);
+    case RT_ANNULUS: return isect_disc<T, true>(o, d, g, eps);
+  }
+  return miss<T>();
+}
+
+struct Hit { int idx; };
+
+// Scan all primitives in type-sorted order.  MODE 0: closest incl. lights (rayphoton.js:1642-1650),
+// MODE 1: closest excluding lights (:1467-1475), MODE 2: any occluder closer than limit - eps
+// (:1853-1857).  The reference scans in index order and keeps the first of equal distances
+// (strict `<`), so ties go to the lowest original index here too.
+template <typename T, int MODE> RT_D int scan_scene(const DevScene<T> &S, V3<T> o, V3<T> d, T eps, T limit, T &t_out) {
+  T best = Limits<T>::inf(); int best_idx = -1;
+  const T lim = (MODE == 2) ? limit - eps : T(0);
+#define RT_SCAN_LOOP(TYPE, EXPR)                                                        \
+  for (uint32_t s = S.seg[TYPE]; s < S.seg[TYPE + 1]; s++) {                            \
+    const T *g = S.sgeom + (size_t)s * RT_GEOM_STRIDE;                                  \
+    const int flags = S.sflags[s]; (void)flags;                                         \
+    T t = EXPR;                                                                         \
+    if (MODE != 0 && (flags & RT_FLAG_LIGHT)) continue;                                 \
+    if (MODE == 2) { if (t > eps && t < lim) { t_out = t; return 1; } }                 \
+    else {                                                                              \
+      int orig = (int)S.sorig[s];                                                       \
+      if (t > eps && (t < best || (t == best && orig < best_idx))) { best = t; best_idx = orig; } \
+    }                                                                                   \
+  }
+  RT_SCAN_LOOP(RT_PLANE, isect_plane<T>(o, d, g, eps))
+  RT_SCAN_LOOP(RT_SPHERE, isect_sphere<T>(o, d, g, eps))
+  RT_SCAN_LOOP(RT_HEMISPHERE, isect_hemisphere<T>(o, d, g, flags, eps))
+  RT_SCAN_LOOP(RT_CYLINDER, isect_cylinder<T>(o, d, g, flags, eps))
+  RT_SCAN_LOOP(RT_TRIANGLE, (isect_tri<T, false>(o, d, g, eps)))
+  RT_SCAN_LOOP(RT_SQUARE, (isect_tri<T, true>(o, d, g, eps)))
+  RT_SCAN_LOOP(RT_DISC, (isect_disc<T, false>(o, d, g, eps)))
+  RT_SCAN_LOOP(RT_ANNULUS, (isect_disc<T, true>(o, d, g, eps)))
+#undef RT_SCAN_LOOP
+  if (MODE == 2) return 0;
+  t_out = best;
+  return best_idx;
+}
+
+// shape.normal(p) (rayphoton.js:368-371, :385, :403, :417, :433, :449, :464, :480); not renormalised
+template <typename T> RT_D V3<T> shape_normal(const DevScene<T> &S, int i, V3<T> p) {
+  const T *g = S.geom + (size_t)i * RT_GEOM_STRIDE;
+  const int type = S.meta[4 * i], flags = S.meta[4 * i + 2];
+  const T sign = (flags & RT_FLAG_CONVEX) ? T(1) : T(-1);
+  switch (type) {
+    case RT_TRIANGLE: case RT_SQUARE: return ld3(g + 9);
+    case RT_SPHERE: return (T(1) / g[6]) * (p - ld3(g));
+    case RT_HEMISPHERE: return (sign / g[6]) * (p - ld3(g));
+    case RT_CYLINDER: {
+      V3<T> v = p - ld3(g), axis = ld3(g + 3);
+      return (sign / g[6]) * (v - dot(v, axis) * axis);
+    }
+    default: return ld3(g + 3);   // plane, disc, annulus
+  }
+}
+
+// JavaScript ToInt32 of a sum of two floors, as the checker patterns' `& 1` sees it
+template <typename T> RT_D int js_parity(T x) { return (int)((long long)x & 1LL); }
+
+// shape.colour(p): the base colour (rayphoton.js:350) or one of the presets' closures
+template <typename T> RT_D V3<T> shape_colour(const DevScene<T> &S, int i, V3<T> p) {
+  const T *c = S.colour + (size_t)i * 4;
+  const int proc = S.meta[4 * i + 3];
+  if (proc == RT_PROC_NONE) return mk<T>(c[0], c[1], c[2]);
+  const V3<T> WHITE = mk<T>(255, 255, 255), BLACK = mk<T>(0, 0, 0);
+  switch (proc) {
+    case RT_PROC_STRIPE_CHECKER: {                                        // rayphoton.js:746-755
+      T f = rt_sin(p.x) + p.y;
+      if (f > T(0) && f < T(1)) return mk<T>(255, 32, 144);
+      int idx = 1 + js_parity<T>(rt_floor(p.x / T(4)) + rt_floor(p.y / T(4)));
+      return idx == 1 ? mk<T>(128, 128, 128) : BLACK;
+    }
+    case RT_PROC_EIGHT_BALL: {                                            // rayphoton.js:756-768
+      const T *g = S.geom + (size_t)i * RT_GEOM_STRIDE;
+      V3<T> pc = p - ld3(g); T r = g[6];
+      T c1 = dot(pc, normalize<T>(mk<T>(-1, -1, 0), T(1e-6))) / r;
+      if (c1 < T(0.905)) return BLACK;
+      c1 = dot(pc, normalize<T>(mk<T>(-1, -1, T(0.15)), T(1e-6))) / r;
+      T c2 = dot(pc, normalize<T>(mk<T>(-1, -1, T(-0.12)), T(1e-6))) / r;
+      return ((c1 > T(0.9920) && c1 < T(0.999)) || (c2 > T(0.9900) && c2 < T(0.9980))) ? BLACK : WHITE;
+    }
+    case RT_PROC_TILE_GRID: {                                             // rayphoton.js:784-792
+      T x = rt_abs(rt_fmod(p.x + T(100.7), T(2.3)) - T(1.15)), y = rt_abs(rt_fmod(p.y + T(102.7), T(2.3)) - T(1.15));
+      return (x < T(0.03) || y < T(0.03) || x + y < T(0.6)) ? BLACK : WHITE;
+    }
+    case RT_PROC_ROTATED_CHECKER: {                                       // rayphoton.js:871-874
+      int idx = js_parity<T>(rt_floor((T(0.6) * p.x + T(0.8) * p.y + T(0.7)) / T(3.2)) +
+                             rt_floor((T(0.8) * p.x - T(0.6) * p.y + T(0.2)) / T(3.2)));
+      return idx ? BLACK : WHITE;
+    }
+  }
+  return mk<T>(c[0], c[1], c[2]);
+}

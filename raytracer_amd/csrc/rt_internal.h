@@ -1,0 +1,97 @@
+// Host-side plumbing shared by the translation units of librt355.so: context, error capture,
+// device buffers, host/device pointer staging and per-kernel HIP-event timing.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <map>
+#include <string>
+#include <utility>
+#include <vector>
+#include "../../include/rt355.h"
+#include "rt_geom.h"
+#include "rt_kdq.h"
+
+struct rt_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  bool profiling = false;
+  std::map<std::string, std::vector<std::pair<hipEvent_t, hipEvent_t>>> events;
+  uint32_t *pinned = nullptr;    // small pinned scratch for counters read back each bounce
+};
+
+int rt_fail(rt_ctx *ctx, int code, const char *fmt, ...);
+
+#define RT_HIP(ctx, call)                                                                      \
+  do {                                                                                         \
+    hipError_t e_ = (call);                                                                    \
+    if (e_ != hipSuccess) return rt_fail((ctx), RT_ERR_HIP, "%s failed: %s (%s:%d)", #call,    \
+                                         hipGetErrorString(e_), __FILE__, __LINE__);           \
+  } while (0)
+
+#define RT_TRY(expr) do { int rc_ = (expr); if (rc_ != RT_OK) return rc_; } while (0)
+
+// RAII device allocation
+struct DevMem {
+  void *p = nullptr; size_t bytes = 0;
+  DevMem() = default;
+  DevMem(const DevMem &) = delete;
+  DevMem &operator=(const DevMem &) = delete;
+  ~DevMem() { release(); }
+  void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+  hipError_t alloc(size_t n) { release(); if (n == 0) n = 16; hipError_t e = hipMalloc(&p, n); if (e == hipSuccess) bytes = n; return e; }
+  hipError_t reserve(size_t n) { return (n <= bytes) ? hipSuccess : alloc(n); }    // grow-only, contents dropped
+  template <typename T> T *as() const { return (T *)p; }
+};
+
+bool rt_is_device_ptr(const void *p);
+
+// Returns a device pointer holding `bytes` from `src` (device pointers pass through; host
+// pointers are copied into `tmp` on the context's stream).
+int rt_stage_in(rt_ctx *ctx, const void *src, size_t bytes, DevMem &tmp, const void **out);
+// Device buffer to write results into: `dst` itself if it is a device pointer, else `tmp`.
+int rt_stage_out_begin(rt_ctx *ctx, void *dst, size_t bytes, DevMem &tmp, void **out);
+// Copies `tmp` back to a host `dst` (no-op for device `dst`); synchronises the stream.
+int rt_stage_out_end(rt_ctx *ctx, void *dst, size_t bytes, DevMem &tmp);
+
+struct KernelTimer {
+  rt_ctx *ctx; hipEvent_t a = nullptr, b = nullptr; const char *name;
+  KernelTimer(rt_ctx *c, const char *n) : ctx(c), name(n) {
+    if (ctx->profiling) { (void)hipEventCreate(&a); (void)hipEventCreate(&b); (void)hipEventRecord(a, ctx->stream); }
+  }
+  ~KernelTimer() {
+    if (a) { (void)hipEventRecord(b, ctx->stream); ctx->events[name].push_back({ a, b }); }
+  }
+};
+
+// launch on the context's stream, timed under `name` when profiling is on
+#define RT_LAUNCH(ctx, name, kernel, grid, block, ...)                                         \
+  do {                                                                                         \
+    KernelTimer timer_((ctx), (name));                                                         \
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, (ctx)->stream, __VA_ARGS__);        \
+  } while (0)
+
+static inline uint32_t div_up(uint64_t a, uint32_t b) { return (uint32_t)((a + b - 1) / b); }
+
+// ---- scene ----
+struct rt_scene {
+  rt_ctx *ctx = nullptr;
+  DevMem meta, geom32, geom64, colour32, colour64, sgeom32, sgeom64, sorig, sflags;
+  DevScene<float> d32; DevScene<double> d64;
+  // per-scene workspaces (grow-only) so that steady-state calls do not allocate
+  DevMem ws_paths, ws_queue, ws_ctr, ws_emit_kind, ws_emit_rec, ws_emit_blocks, ws_misc;
+};
+
+// ---- photon map ----
+struct rt_photon_map {
+  rt_ctx *ctx = nullptr;
+  uint32_t n = 0;
+  DevMem node, pay, rec64, perm, dim;
+  DevMap view() const {
+    DevMap m; m.n = n; m.node = node.as<float4>(); m.pay = pay.as<float>(); m.rec64 = rec64.as<double>(); m.perm = perm.as<int32_t>();
+    return m;
+  }
+};
+
+int rt_kd_build_device(rt_ctx *ctx, const float *d_pos, uint32_t n, int32_t *d_perm, uint8_t *d_dim);

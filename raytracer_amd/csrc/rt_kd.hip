@@ -1,0 +1,437 @@
+// Photon map on the GPU: the reference's left-balanced kd-tree (kdtree.js) built level by level,
+// the fixed-radius query (nearestNeighbours, kdtree.js:64-80), a k-nearest query with an
+// LDS-resident top-k heap per lane, and the fused radiance gathers built on them.
+//
+// Build.  makeTree (kdtree.js:82-107) recursively (1) takes the bounding box of its subset,
+// (2) picks the widest axis (ties -> lowest axis), (3) stably sorts the subset by that axis,
+// (4) makes element findMedian(len) the node and recurses on the two sides.  The size of every
+// subtree is a function of N alone (findMedian is), so all nodes of one level can be processed
+// at once: the N photons sit in one array in which every subtree owns a contiguous segment and
+// every finished node stays where its parent's sort left it.  One level =
+//   bbox reduce per segment -> key = (segment start, sortable(coord[axis])) -> one stable radix
+//   sort of the whole array -> the element at start + findMedian(len) of each segment becomes
+//   nodes[pos]; the two sides become the segments of 2*pos and 2*pos+1.
+// Finished nodes get key (own index, 0) and therefore never move.  The sort is stable, like
+// the reference's Array.prototype.sort, so ties keep the order the parent's sort left them in.
+//
+// All accept/prune comparisons of the queries are evaluated in fp64 without FMA contraction on
+// the exactly converted fp32 coordinates, so the returned index sets are exactly the
+// reference's for the same (fp32-representable) photon positions.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <string.h>
+#include <cstring>
+#include <rocprim/rocprim.hpp>
+#include "rt_internal.h"
+
+// (compiled with -ffp-contract=off, see Makefile)
+
+// ------------------------------------------------------------------ findMedian
+__host__ __device__ static inline uint32_t find_median(uint32_t n) {     // kdtree.js:109-124
+  if (n <= 1) return 0;
+  uint32_t power_two = 1, two_bits = n;
+  for (;;) {
+    if (two_bits == 2) return n - power_two;
+    if (two_bits == 3) return 2 * power_two - 1;
+    power_two <<= 1; two_bits >>= 1;
+  }
+}
+extern "C" uint32_t rt_find_median(uint32_t n) { return find_median(n); }
+
+// ------------------------------------------------------------------ build kernels
+__device__ __forceinline__ uint32_t sortable(float x) {
+  if (x == 0.0f) x = 0.0f;                         // -0 and +0 compare equal in the reference's comparator
+  uint32_t u = __float_as_uint(x);
+  return u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+}
+__device__ __forceinline__ float unsortable(uint32_t u) {
+  return __uint_as_float(u ^ ((u >> 31) ? 0x80000000u : 0xFFFFFFFFu));
+}
+
+struct SegState { uint32_t *pos, *start, *len; };   // per array position: heap pos of its segment (0 = finished node)
+
+__global__ void __launch_bounds__(256) k_kd_init(uint32_t n, uint32_t *idx, SegState sg) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  idx[i] = i; sg.pos[i] = 1; sg.start[i] = 0; sg.len[i] = n;
+}
+
+__global__ void __launch_bounds__(256) k_kd_bbox_clear(uint32_t first, uint32_t count, uint32_t *bbmin, uint32_t *bbmax) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count * 3) return;
+  bbmin[(size_t)first * 3 + i] = 0xFFFFFFFFu; bbmax[(size_t)first * 3 + i] = 0u;
+}
+
+// min/max of every active segment (kdtree.js:85-92).  Waves that lie inside one segment reduce
+// across lanes first and issue one atomic per axis; mixed waves fall back to per-lane atomics.
+__global__ void __launch_bounds__(256) k_kd_bbox(uint32_t n, const float *pos3, const uint32_t *idx, SegState sg,
+                                                 uint32_t *bbmin, uint32_t *bbmax) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t sp = (i < n) ? sg.pos[i] : 0;
+  uint32_t lo[3] = { 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu }, hi[3] = { 0, 0, 0 };
+  if (sp) {
+    const float *p = pos3 + (size_t)idx[i] * 3;
+    for (int d = 0; d < 3; d++) { uint32_t u = sortable(p[d]); lo[d] = u; hi[d] = u; }
+  }
+  uint32_t sp0 = __shfl(sp, 0, 64);
+  bool uniform = __all(sp == sp0 || sp == 0) && sp0 != 0;
+  if (uniform) {
+    for (int off = 32; off > 0; off >>= 1)
+      for (int d = 0; d < 3; d++) {
+        uint32_t a = __shfl_xor(lo[d], off, 64), b = __shfl_xor(hi[d], off, 64);
+        lo[d] = min(lo[d], a); hi[d] = max(hi[d], b);
+      }
+    if ((threadIdx.x & 63) == 0)
+      for (int d = 0; d < 3; d++) { atomicMin(&bbmin[(size_t)sp0 * 3 + d], lo[d]); atomicMax(&bbmax[(size_t)sp0 * 3 + d], hi[d]); }
+  } else if (sp) {
+    for (int d = 0; d < 3; d++) { atomicMin(&bbmin[(size_t)sp * 3 + d], lo[d]); atomicMax(&bbmax[(size_t)sp * 3 + d], hi[d]); }
+  }
+}
+
+// widest axis in fp64, `>` strict so ties go to the lowest axis (kdtree.js:93-100)
+__device__ __forceinline__ int widest_dim(const uint32_t *bbmin, const uint32_t *bbmax, uint32_t sp) {
+  double w[3];
+  for (int d = 0; d < 3; d++)
+    w[d] = (double)unsortable(bbmax[(size_t)sp * 3 + d]) - (double)unsortable(bbmin[(size_t)sp * 3 + d]);
+  int best = 0; double mw = w[0];
+  for (int d = 1; d < 3; d++) if (w[d] > mw) { best = d; mw = w[d]; }
+  return best;
+}
+
+__global__ void __launch_bounds__(256) k_kd_keys(uint32_t n, const float *pos3, const uint32_t *idx, SegState sg,
+                                                 const uint32_t *bbmin, const uint32_t *bbmax, uint8_t *segdim, uint64_t *keys) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t sp = sg.pos[i];
+  if (!sp) { keys[i] = (uint64_t)i << 32; return; }
+  int d = widest_dim(bbmin, bbmax, sp);
+  if (i == sg.start[i]) segdim[sp] = (uint8_t)d;
+  keys[i] = ((uint64_t)sg.start[i] << 32) | sortable(pos3[(size_t)idx[i] * 3 + d]);
+}
+
+__global__ void __launch_bounds__(256) k_kd_split(uint32_t n, const uint32_t *idx, SegState sg, const uint8_t *segdim,
+                                                  int32_t *perm, uint8_t *dim) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t sp = sg.pos[i];
+  if (!sp) return;
+  uint32_t s = sg.start[i], len = sg.len[i], m = find_median(len);
+  if (i == s + m) { perm[sp - 1] = (int32_t)idx[i]; dim[sp - 1] = segdim[sp]; sg.pos[i] = 0; }
+  else if (i < s + m) { sg.pos[i] = 2 * sp; sg.len[i] = m; }
+  else { sg.pos[i] = 2 * sp + 1; sg.start[i] = s + m + 1; sg.len[i] = len - m - 1; }
+}
+
+int rt_kd_build_device(rt_ctx *ctx, const float *d_pos, uint32_t n, int32_t *d_perm, uint8_t *d_dim) {
+  if (n == 0) return rt_fail(ctx, RT_ERR_EMPTY_TREE, "tried to build a k-d tree with no data!");   // kdtree.js:6
+  if (n >= 0x7FFFFFFFu) return rt_fail(ctx, RT_ERR_TOO_LARGE, "photon map too large");
+  DevMem idxA, idxB, keyA, keyB, spos, sstart, slen, bbmin, bbmax, segdim, tmp;
+  RT_HIP(ctx, idxA.alloc((size_t)n * 4)); RT_HIP(ctx, idxB.alloc((size_t)n * 4));
+  RT_HIP(ctx, keyA.alloc((size_t)n * 8)); RT_HIP(ctx, keyB.alloc((size_t)n * 8));
+  RT_HIP(ctx, spos.alloc((size_t)n * 4)); RT_HIP(ctx, sstart.alloc((size_t)n * 4)); RT_HIP(ctx, slen.alloc((size_t)n * 4));
+  RT_HIP(ctx, bbmin.alloc(((size_t)n + 1) * 12)); RT_HIP(ctx, bbmax.alloc(((size_t)n + 1) * 12));
+  RT_HIP(ctx, segdim.alloc((size_t)n + 1));
+  SegState sg = { spos.as<uint32_t>(), sstart.as<uint32_t>(), slen.as<uint32_t>() };
+  const uint32_t grid = div_up(n, 256);
+  RT_LAUNCH(ctx, "kd_init", k_kd_init, grid, 256, n, idxA.as<uint32_t>(), sg);
+  int seg_bits = 1; while (((uint64_t)1 << seg_bits) < (uint64_t)n) seg_bits++;
+  const unsigned end_bit = 32 + seg_bits;
+  size_t tmp_bytes = 0;
+  RT_HIP(ctx, rocprim::radix_sort_pairs(nullptr, tmp_bytes, keyA.as<uint64_t>(), keyB.as<uint64_t>(), idxA.as<uint32_t>(),
+                                        idxB.as<uint32_t>(), n, 0, end_bit, ctx->stream));
+  RT_HIP(ctx, tmp.alloc(tmp_bytes));
+  uint32_t *idx_cur = idxA.as<uint32_t>(), *idx_nxt = idxB.as<uint32_t>();
+  for (uint32_t first = 1; first <= n; first <<= 1) {                   // heap positions [first, 2*first) form one level
+    uint32_t count = (2 * (uint64_t)first - 1 <= n) ? first : n - first + 1;
+    RT_LAUNCH(ctx, "kd_bbox_clear", k_kd_bbox_clear, div_up((uint64_t)count * 3, 256), 256, first, count, bbmin.as<uint32_t>(), bbmax.as<uint32_t>());
+    RT_LAUNCH(ctx, "kd_bbox", k_kd_bbox, grid, 256, n, d_pos, idx_cur, sg, bbmin.as<uint32_t>(), bbmax.as<uint32_t>());
+    RT_LAUNCH(ctx, "kd_keys", k_kd_keys, grid, 256, n, d_pos, idx_cur, sg, bbmin.as<uint32_t>(), bbmax.as<uint32_t>(),
+              segdim.as<uint8_t>(), keyA.as<uint64_t>());
+    {
+      KernelTimer timer_(ctx, "kd_sort");
+      RT_HIP(ctx, rocprim::radix_sort_pairs(tmp.p, tmp_bytes, keyA.as<uint64_t>(), keyB.as<uint64_t>(), idx_cur, idx_nxt, n, 0,
+                                            end_bit, ctx->stream));
+    }
+    std::swap(idx_cur, idx_nxt);
+    RT_LAUNCH(ctx, "kd_split", k_kd_split, grid, 256, n, idx_cur, sg, segdim.as<uint8_t>(), d_perm, d_dim);
+  }
+  RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return RT_OK;
+}
+
+extern "C" int rt_kd_build(rt_ctx *ctx, const float *pos, uint32_t n, int32_t *perm, uint8_t *dim) {
+  if (!ctx) return RT_ERR_INVALID;
+  if (n == 0) return rt_fail(ctx, RT_ERR_EMPTY_TREE, "tried to build a k-d tree with no data!");
+  RT_HIP(ctx, hipSetDevice(ctx->device));
+  DevMem tpos, tperm, tdim; const void *dpos; void *dperm, *ddim;
+  RT_TRY(rt_stage_in(ctx, pos, (size_t)n * 12, tpos, &dpos));
+  RT_TRY(rt_stage_out_begin(ctx, perm, (size_t)n * 4, tperm, &dperm));
+  RT_TRY(rt_stage_out_begin(ctx, dim, (size_t)n, tdim, &ddim));
+  RT_TRY(rt_kd_build_device(ctx, (const float *)dpos, n, (int32_t *)dperm, (uint8_t *)ddim));
+  RT_TRY(rt_stage_out_end(ctx, perm, (size_t)n * 4, tperm));
+  RT_TRY(rt_stage_out_end(ctx, dim, (size_t)n, tdim));
+  return RT_OK;
+}
+
+// ------------------------------------------------------------------ photon map object
+__global__ void __launch_bounds__(256) k_map_extract_pos(uint32_t n, const double *rec, float *pos3) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  for (int d = 0; d < 3; d++) pos3[(size_t)i * 3 + d] = (float)rec[(size_t)i * 11 + d];
+}
+__global__ void __launch_bounds__(256) k_map_permute(uint32_t n, const double *rec, const int32_t *perm, const uint8_t *dim,
+                                                     float4 *node, float *pay, double *rec64) {
+  uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n) return;
+  const double *r = rec + (size_t)perm[s] * 11;
+  node[s] = make_float4((float)r[0], (float)r[1], (float)r[2], __int_as_float((int)dim[s]));
+  float *p = pay + (size_t)s * 6;
+  p[0] = (float)r[3]; p[1] = (float)r[4]; p[2] = (float)r[5];
+  p[3] = (float)(r[7] * r[6]); p[4] = (float)(r[8] * r[6]); p[5] = (float)(r[9] * r[6]);
+  if (rec64) for (int c = 0; c < 11; c++) rec64[(size_t)s * 11 + c] = r[c];
+}
+
+extern "C" int rt_photon_map_build(rt_ctx *ctx, const double *rec, uint32_t n, rt_photon_map **out) {
+  if (!ctx || !out) return RT_ERR_INVALID;
+  *out = nullptr;
+  if (n == 0) return rt_fail(ctx, RT_ERR_EMPTY_TREE, "tried to build a k-d tree with no data!");
+  RT_HIP(ctx, hipSetDevice(ctx->device));
+  DevMem trec, tpos; const void *drec;
+  RT_TRY(rt_stage_in(ctx, rec, (size_t)n * 88, trec, &drec));
+  RT_HIP(ctx, tpos.alloc((size_t)n * 12));
+  rt_photon_map *m = new rt_photon_map();
+  m->ctx = ctx; m->n = n;
+  hipError_t e = m->node.alloc((size_t)n * 16);
+  if (e == hipSuccess) e = m->pay.alloc((size_t)n * 24);
+  if (e == hipSuccess) e = m->perm.alloc((size_t)n * 4);
+  if (e == hipSuccess) e = m->dim.alloc((size_t)n);
+  // fp64 copy of the records for the parity (fp64) renderer; skipped for very large maps
+  const bool keep64 = n <= (1u << 24);
+  if (e == hipSuccess && keep64) e = m->rec64.alloc((size_t)n * 88);
+  if (e != hipSuccess) { delete m; return rt_fail(ctx, RT_ERR_HIP, "photon map allocation failed: %s", hipGetErrorString(e)); }
+  const uint32_t grid = div_up(n, 256);
+  RT_LAUNCH(ctx, "map_extract_pos", k_map_extract_pos, grid, 256, n, (const double *)drec, tpos.as<float>());
+  int rc = rt_kd_build_device(ctx, tpos.as<float>(), n, m->perm.as<int32_t>(), m->dim.as<uint8_t>());
+  if (rc != RT_OK) { delete m; return rc; }
+  RT_LAUNCH(ctx, "map_permute", k_map_permute, grid, 256, n, (const double *)drec, m->perm.as<int32_t>(), m->dim.as<uint8_t>(),
+            m->node.as<float4>(), m->pay.as<float>(), keep64 ? m->rec64.as<double>() : (double *)nullptr);
+  if (hipStreamSynchronize(ctx->stream) != hipSuccess) { delete m; return rt_fail(ctx, RT_ERR_HIP, "photon map build failed"); }
+  *out = m;
+  return RT_OK;
+}
+extern "C" void rt_photon_map_free(rt_photon_map *m) { delete m; }
+extern "C" uint32_t rt_photon_map_size(const rt_photon_map *m) { return m ? m->n : 0; }
+extern "C" int rt_photon_map_nodes(rt_photon_map *m, int32_t *perm, uint8_t *dim) {
+  if (!m) return RT_ERR_INVALID;
+  rt_ctx *ctx = m->ctx;
+  RT_HIP(ctx, hipSetDevice(ctx->device));
+  if (perm) RT_HIP(ctx, hipMemcpy(perm, m->perm.p, (size_t)m->n * 4, hipMemcpyDefault));
+  if (dim) RT_HIP(ctx, hipMemcpy(dim, m->dim.p, (size_t)m->n, hipMemcpyDefault));
+  return RT_OK;
+}
+
+// ------------------------------------------------------------------ radius query
+__global__ void __launch_bounds__(256) k_kd_radius(DevMap M, const float *q3, uint32_t nq, double r, uint32_t cap,
+                                                   uint32_t *count, int32_t *idx) {
+  uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= nq) return;
+  const double x0 = q3[(size_t)q * 3], x1 = q3[(size_t)q * 3 + 1], x2 = q3[(size_t)q * 3 + 2];
+  const double r2 = r * r;
+  uint32_t c = 0;
+  kd_radius_walk(M, x0, x1, x2, r, [&](uint32_t slot, float4 nd) {
+    if (sq_dist(x0, x1, x2, (double)nd.x, (double)nd.y, (double)nd.z) < r2) {
+      if (c < cap) idx[(size_t)q * cap + c] = M.perm[slot];
+      c++;
+    }
+  });
+  count[q] = c;
+}
+
+extern "C" int rt_kd_radius(rt_photon_map *m, const float *queries, uint32_t nq, double r, uint32_t cap, uint32_t *count, int32_t *idx) {
+  if (!m) return RT_ERR_INVALID;
+  rt_ctx *ctx = m->ctx;
+  if (nq == 0) return RT_OK;
+  RT_HIP(ctx, hipSetDevice(ctx->device));
+  DevMem tq, tc, ti; const void *dq; void *dc, *di;
+  RT_TRY(rt_stage_in(ctx, queries, (size_t)nq * 12, tq, &dq));
+  RT_TRY(rt_stage_out_begin(ctx, count, (size_t)nq * 4, tc, &dc));
+  RT_TRY(rt_stage_out_begin(ctx, idx, (size_t)nq * cap * 4, ti, &di));
+  RT_LAUNCH(ctx, "kd_radius", k_kd_radius, div_up(nq, 256), 256, m->view(), (const float *)dq, nq, r, cap, (uint32_t *)dc, (int32_t *)di);
+  RT_TRY(rt_stage_out_end(ctx, count, (size_t)nq * 4, tc));
+  RT_TRY(rt_stage_out_end(ctx, idx, (size_t)nq * cap * 4, ti));
+  return RT_OK;
+}
+
+// ------------------------------------------------------------------ k-nearest query
+// One lane per query; each lane owns a max-heap of k (squared distance, slot) entries in LDS,
+// laid out [entry][lane] so that the 64 lanes of a wave touch 64 consecutive words.  Order is
+// (d2, input index): the worst element is the largest d2 and, among equal d2, the largest index.
+#define KNN_LANES 64
+struct KnnHeap {
+  double *d2; uint32_t *slot; const int32_t *perm; uint32_t k, size; int lane;
+  __device__ __forceinline__ double &D(uint32_t i) { return d2[(size_t)i * KNN_LANES + lane]; }
+  __device__ __forceinline__ uint32_t &S(uint32_t i) { return slot[(size_t)i * KNN_LANES + lane]; }
+  __device__ __forceinline__ bool worse(double da, uint32_t sa, double db, uint32_t sb) const {
+    return da > db || (da == db && perm[sa] > perm[sb]);
+  }
+  __device__ __forceinline__ void sift_down(uint32_t i, uint32_t n, double dv, uint32_t sv) {
+    for (;;) {
+      uint32_t c = 2 * i + 1;
+      if (c >= n) break;
+      double dc = D(c); uint32_t sc = S(c);
+      if (c + 1 < n) { double dr = D(c + 1); uint32_t sr = S(c + 1); if (worse(dr, sr, dc, sc)) { c++; dc = dr; sc = sr; } }
+      if (!worse(dc, sc, dv, sv)) break;
+      D(i) = dc; S(i) = sc; i = c;
+    }
+    D(i) = dv; S(i) = sv;
+  }
+  __device__ __forceinline__ void offer(double dv, uint32_t sv) {
+    if (size < k) {                                   // sift up
+      uint32_t i = size++;
+      while (i > 0) {
+        uint32_t p = (i - 1) / 2;
+        double dp = D(p); uint32_t sp = S(p);
+        if (!worse(dv, sv, dp, sp)) break;
+        D(i) = dp; S(i) = sp; i = p;
+      }
+      D(i) = dv; S(i) = sv;
+    } else if (worse(D(0), S(0), dv, sv)) {
+      sift_down(0, size, dv, sv);
+    }
+  }
+  __device__ __forceinline__ bool full() const { return size == k; }
+};
+
+template <typename F> __device__ __forceinline__ void knn_search(const DevMap &M, double x0, double x1, double x2, KnnHeap &H, F &&dist2) {
+  const uint32_t n = M.n;
+  uint32_t pos = 1; int depth = 0; uint64_t pending = 0;
+  for (;;) {
+    if (pos <= n) {
+      float4 nd = M.node[pos - 1];
+      H.offer(dist2(nd), pos - 1);
+      int dim = node_dim(nd);
+      double diff = ((dim == 0) ? x0 : (dim == 1) ? x1 : x2) - (double)((dim == 0) ? nd.x : (dim == 1) ? nd.y : nd.z);
+      if (2 * (uint64_t)pos <= n) pending |= (uint64_t)1 << depth;        // has at least one child
+      pos = (diff < 0) ? 2 * pos : 2 * pos + 1;
+      depth++;
+      continue;
+    }
+    bool resumed = false;
+    while (pending) {
+      int k = 63 - __clzll((long long)pending);
+      pending &= ~((uint64_t)1 << k);
+      uint32_t anc = pos >> (depth - k);
+      float4 nd = M.node[anc - 1];
+      int dim = node_dim(nd);
+      double diff = ((dim == 0) ? x0 : (dim == 1) ? x1 : x2) - (double)((dim == 0) ? nd.x : (dim == 1) ? nd.y : nd.z);
+      // every point beyond the plane has d2 >= diff*diff (also after rounding), so `>` prunes safely, ties included
+      if (!H.full() || !(diff * diff > H.D(0))) { pos = (diff < 0) ? 2 * anc + 1 : 2 * anc; depth = k + 1; resumed = true; break; }
+      pos = anc; depth = k;
+    }
+    if (!resumed) break;
+  }
+}
+
+__global__ void __launch_bounds__(KNN_LANES) k_kd_knn(DevMap M, const float *q3, uint32_t nq, uint32_t k, int32_t *idx, double *d2out) {
+  extern __shared__ double knn_lds[];
+  uint32_t q = blockIdx.x * KNN_LANES + threadIdx.x;
+  KnnHeap H; H.d2 = knn_lds; H.slot = (uint32_t *)(knn_lds + (size_t)k * KNN_LANES); H.perm = M.perm; H.k = k; H.size = 0; H.lane = threadIdx.x;
+  if (q >= nq) return;
+  const double x0 = q3[(size_t)q * 3], x1 = q3[(size_t)q * 3 + 1], x2 = q3[(size_t)q * 3 + 2];
+  knn_search(M, x0, x1, x2, H, [&](float4 nd) { return sq_dist(x0, x1, x2, (double)nd.x, (double)nd.y, (double)nd.z); });
+  // heap sort: repeatedly move the worst to the tail -> ascending (d2, index)
+  for (uint32_t j = k; j > H.size; j--) { idx[(size_t)q * k + j - 1] = -1; d2out[(size_t)q * k + j - 1] = __builtin_huge_val(); }
+  for (uint32_t m = H.size; m > 0; m--) {
+    double dw = H.D(0); uint32_t sw = H.S(0);
+    idx[(size_t)q * k + m - 1] = M.perm[sw]; d2out[(size_t)q * k + m - 1] = dw;
+    if (m > 1) { double dl = H.D(m - 1); uint32_t sl = H.S(m - 1); H.sift_down(0, m - 1, dl, sl); }
+  }
+}
+
+static int knn_lds_bytes(uint32_t k) { return (int)((size_t)k * KNN_LANES * 12); }
+
+extern "C" int rt_kd_knn(rt_photon_map *m, const float *queries, uint32_t nq, uint32_t k, int32_t *idx, double *d2) {
+  if (!m) return RT_ERR_INVALID;
+  rt_ctx *ctx = m->ctx;
+  if (k == 0 || k > 192) return rt_fail(ctx, RT_ERR_INVALID, "k must be in 1..192 (LDS-resident heap), got %u", k);
+  if (nq == 0) return RT_OK;
+  RT_HIP(ctx, hipSetDevice(ctx->device));
+  DevMem tq, ti, td; const void *dq; void *di, *dd;
+  RT_TRY(rt_stage_in(ctx, queries, (size_t)nq * 12, tq, &dq));
+  RT_TRY(rt_stage_out_begin(ctx, idx, (size_t)nq * k * 4, ti, &di));
+  RT_TRY(rt_stage_out_begin(ctx, d2, (size_t)nq * k * 8, td, &dd));
+  RT_HIP(ctx, hipFuncSetAttribute((const void *)k_kd_knn, hipFuncAttributeMaxDynamicSharedMemorySize, knn_lds_bytes(k)));
+  {
+    KernelTimer timer_(ctx, "kd_knn");
+    hipLaunchKernelGGL(k_kd_knn, dim3(div_up(nq, KNN_LANES)), dim3(KNN_LANES), knn_lds_bytes(k), ctx->stream, m->view(),
+                       (const float *)dq, nq, k, (int32_t *)di, (double *)dd);
+  }
+  RT_TRY(rt_stage_out_end(ctx, idx, (size_t)nq * k * 4, ti));
+  RT_TRY(rt_stage_out_end(ctx, d2, (size_t)nq * k * 8, td));
+  return RT_OK;
+}
+
+// ------------------------------------------------------------------ fused radiance gathers
+// hits: pos3 normal3 albedo3 (fp32); rgb = sum * albedo/255 / (pi r^2)   (rayphoton.js:1779-1784, :1808-1815)
+__global__ void __launch_bounds__(256) k_gather_radius(DevMap M, const float *hits, uint32_t nq, double r, float *rgb) {
+  uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= nq) return;
+  const float *h = hits + (size_t)q * 9;
+  const double x0 = h[0], x1 = h[1], x2 = h[2];
+  const float nx = h[3], ny = h[4], nz = h[5];
+  const double r2 = r * r;
+  float sr = 0, sg = 0, sb = 0;
+  kd_radius_walk(M, x0, x1, x2, r, [&](uint32_t slot, float4 nd) {
+    if (sq_dist(x0, x1, x2, (double)nd.x, (double)nd.y, (double)nd.z) < r2) {
+      const float *pp = M.pay + (size_t)slot * 6;
+      float w = fmaxf(0.0f, pp[0] * nx + pp[1] * ny + pp[2] * nz);
+      sr += pp[3] * w; sg += pp[4] * w; sb += pp[5] * w;
+    }
+  });
+  const float inv_area = (float)(1.0 / (3.141592653589793 * r2));
+  rgb[(size_t)q * 3] = sr * (h[6] / 255.0f) * inv_area;
+  rgb[(size_t)q * 3 + 1] = sg * (h[7] / 255.0f) * inv_area;
+  rgb[(size_t)q * 3 + 2] = sb * (h[8] / 255.0f) * inv_area;
+}
+
+__global__ void __launch_bounds__(KNN_LANES) k_gather_knn(DevMap M, const float *hits, uint32_t nq, uint32_t k, float *rgb) {
+  extern __shared__ double knn_lds[];
+  uint32_t q = blockIdx.x * KNN_LANES + threadIdx.x;
+  KnnHeap H; H.d2 = knn_lds; H.slot = (uint32_t *)(knn_lds + (size_t)k * KNN_LANES); H.perm = M.perm; H.k = k; H.size = 0; H.lane = threadIdx.x;
+  if (q >= nq) return;
+  const float *h = hits + (size_t)q * 9;
+  const double x0 = h[0], x1 = h[1], x2 = h[2];
+  const float nx = h[3], ny = h[4], nz = h[5];
+  knn_search(M, x0, x1, x2, H, [&](float4 nd) { return sq_dist(x0, x1, x2, (double)nd.x, (double)nd.y, (double)nd.z); });
+  float sr = 0, sg = 0, sb = 0;
+  for (uint32_t j = 0; j < H.size; j++) {
+    const float *pp = M.pay + (size_t)H.S(j) * 6;
+    float w = fmaxf(0.0f, pp[0] * nx + pp[1] * ny + pp[2] * nz);
+    sr += pp[3] * w; sg += pp[4] * w; sb += pp[5] * w;
+  }
+  const double r2 = H.size ? H.D(0) : 1.0;          // squared distance of the k-th nearest
+  const float inv_area = (float)(1.0 / (3.141592653589793 * r2));
+  rgb[(size_t)q * 3] = sr * (h[6] / 255.0f) * inv_area;
+  rgb[(size_t)q * 3 + 1] = sg * (h[7] / 255.0f) * inv_area;
+  rgb[(size_t)q * 3 + 2] = sb * (h[8] / 255.0f) * inv_area;
+}
+
+extern "C" int rt_gather_radiance(rt_photon_map *m, const float *hits, uint32_t nq, double r, uint32_t k, float *rgb_out) {
+  if (!m) return RT_ERR_INVALID;
+  rt_ctx *ctx = m->ctx;
+  if (k > 192) return rt_fail(ctx, RT_ERR_INVALID, "k must be <= 192, got %u", k);
+  if (nq == 0) return RT_OK;
+  RT_HIP(ctx, hipSetDevice(ctx->device));
+  DevMem th, to; const void *dh; void *dout;
+  RT_TRY(rt_stage_in(ctx, hits, (size_t)nq * 36, th, &dh));
+  RT_TRY(rt_stage_out_begin(ctx, rgb_out, (size_t)nq * 12, to, &dout));
+  if (k == 0) {
+    RT_LAUNCH(ctx, "gather_radius", k_gather_radius, div_up(nq, 256), 256, m->view(), (const float *)dh, nq, r, (float *)dout);
+  } else {
+    RT_HIP(ctx, hipFuncSetAttribute((const void *)k_gather_knn, hipFuncAttributeMaxDynamicSharedMemorySize, knn_lds_bytes(k)));
+    KernelTimer timer_(ctx, "gather_knn");
+    hipLaunchKernelGGL(k_gather_knn, dim3(div_up(nq, KNN_LANES)), dim3(KNN_LANES), knn_lds_bytes(k), ctx->stream, m->view(),
+                       (const float *)dh, nq, k, (float *)dout);
+  }
+  RT_TRY(rt_stage_out_end(ctx, rgb_out, (size_t)nq * 12, to));
+  return RT_OK;
+}

@@ -1,0 +1,19 @@
+// Host-side drivers of the templated kernels; instantiated once per working precision
+// (rt_pipeline_f32.hip with FMA contraction for throughput, rt_pipeline_f64.hip without it for
+// bit parity with the reference's fp64 arithmetic).  All pointers are device pointers.
+#pragma once
+#include "rt_internal.h"
+
+template <typename T> int pl_intersect_pairs(rt_ctx *ctx, const rt_params *p, uint32_t n, const double *o, const double *d,
+                                             int normalize_dir, const uint8_t *meta, const double *geom, double *t_out);
+template <typename T> int pl_intersect_scene(rt_scene *sc, const rt_params *p, int mode, uint32_t n, const double *o,
+                                             const double *d, const double *source_dist, double *t_out, int32_t *idx_out);
+template <typename T> int pl_trace_tile(rt_scene *sc, const rt_params *p, DevMap md, DevMap mc, int x0, int y0, int w, int h,
+                                        double *pre, double *post, uint8_t *rgba8, rt_trace_stats *stats);
+// runs attempts [a0, a0+count) of one phase into the scene's emission workspace
+template <typename T> int pl_emit_batch(rt_scene *sc, const rt_params *p, int phase, uint64_t a0, uint32_t count);
+// ordered compaction of the workspace: records whose kind matches `want` (0 = any stored) go to
+// out_rec[out_base + rank]; *n_match = number of matches (device-side scan result, read back)
+template <typename T> int pl_emit_compact(rt_scene *sc, uint32_t count, int want, uint64_t a0, uint32_t out_base, uint32_t out_cap,
+                                          double *out_rec, int64_t *out_attempt, uint8_t *out_kind, uint32_t *n_match);
+int pl_emit_counters(rt_scene *sc, bool reset, uint64_t *segments, uint64_t *errors);

@@ -1,0 +1,174 @@
+// Definitions of the pl_* drivers; included by rt_pipeline_f32.hip / rt_pipeline_f64.hip, which
+// instantiate them for one precision each.
+#pragma once
+#include "rt_emit.h"
+#include "rt_pipeline.h"
+#include "rt_trace.h"
+
+template <typename T> struct SceneOf;
+template <> struct SceneOf<float> { static DevScene<float> &get(rt_scene *s) { return s->d32; } };
+template <> struct SceneOf<double> { static DevScene<double> &get(rt_scene *s) { return s->d64; } };
+
+// ------------------------------------------------------------------ unit-test surfaces
+template <typename T>
+__global__ void __launch_bounds__(256) k_intersect_pairs(uint32_t n, const double *o, const double *d, int normalize_dir,
+                                                         const uint8_t *meta, const double *geom, T eps, double *t_out) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  V3<T> ro = mk<T>(T(o[3 * i]), T(o[3 * i + 1]), T(o[3 * i + 2]));
+  V3<T> rd = mk<T>(T(d[3 * i]), T(d[3 * i + 1]), T(d[3 * i + 2]));
+  if (normalize_dir) rd = normalize<T>(rd, eps);                        // Ray ctor, rayphoton.js:484-487
+  T g[RT_GEOM_STRIDE];
+  for (int k = 0; k < RT_GEOM_STRIDE; k++) g[k] = T(geom[(size_t)i * RT_GEOM_STRIDE + k]);
+  T t = isect_any_type<T>(ro, rd, meta[4 * i], meta[4 * i + 2], g, eps);
+  t_out[i] = (t > T(0)) ? (double)t : __builtin_nan("");
+}
+
+template <typename T, int MODE>
+__global__ void __launch_bounds__(256) k_scan_rays(DevScene<T> S, uint32_t n, const double *o, const double *d,
+                                                   const double *source_dist, T eps, double *t_out, int32_t *idx_out) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  V3<T> ro = mk<T>(T(o[3 * i]), T(o[3 * i + 1]), T(o[3 * i + 2]));
+  V3<T> rd = mk<T>(T(d[3 * i]), T(d[3 * i + 1]), T(d[3 * i + 2]));
+  T t = Limits<T>::inf();
+  int idx = scan_scene<T, MODE>(S, ro, rd, eps, MODE == 2 ? T(source_dist[i]) : T(0), t);
+  idx_out[i] = idx;
+  if (t_out) t_out[i] = (MODE == 2) ? 0.0 : (double)t;
+}
+
+template <typename T>
+int pl_intersect_pairs(rt_ctx *ctx, const rt_params *p, uint32_t n, const double *o, const double *d, int normalize_dir,
+                       const uint8_t *meta, const double *geom, double *t_out) {
+  RT_LAUNCH(ctx, "intersect_pairs", k_intersect_pairs<T>, div_up(n, 256), 256, n, o, d, normalize_dir, meta, geom, T(p->epsilon), t_out);
+  RT_HIP(ctx, hipGetLastError());
+  return RT_OK;
+}
+
+template <typename T>
+int pl_intersect_scene(rt_scene *sc, const rt_params *p, int mode, uint32_t n, const double *o, const double *d,
+                       const double *source_dist, double *t_out, int32_t *idx_out) {
+  rt_ctx *ctx = sc->ctx;
+  DevScene<T> &S = SceneOf<T>::get(sc);
+  const uint32_t grid = div_up(n, 256);
+  const T eps = T(p->epsilon);
+  if (mode == RT_SCAN_CLOSEST) RT_LAUNCH(ctx, "scan_closest", (k_scan_rays<T, 0>), grid, 256, S, n, o, d, source_dist, eps, t_out, idx_out);
+  else if (mode == RT_SCAN_CLOSEST_NOLIGHT) RT_LAUNCH(ctx, "scan_closest_nolight", (k_scan_rays<T, 1>), grid, 256, S, n, o, d, source_dist, eps, t_out, idx_out);
+  else RT_LAUNCH(ctx, "scan_any", (k_scan_rays<T, 2>), grid, 256, S, n, o, d, source_dist, eps, t_out, idx_out);
+  RT_HIP(ctx, hipGetLastError());
+  return RT_OK;
+}
+
+// ------------------------------------------------------------------ renderer
+template <typename T> static size_t path_bytes(size_t n) { return n * (15 * sizeof(T) + 4 + 4 + 4 + 8) + 64 * 32; }
+
+template <typename T> static PathSoA<T> carve_paths(void *base, size_t n) {
+  // 256-byte aligned sub-arrays out of one allocation
+  char *p = (char *)base;
+  auto take = [&](size_t bytes) { char *r = p; p += (bytes + 255) & ~(size_t)255; return (void *)r; };
+  PathSoA<T> P;
+  P.ox = (T *)take(n * sizeof(T)); P.oy = (T *)take(n * sizeof(T)); P.oz = (T *)take(n * sizeof(T));
+  P.dx = (T *)take(n * sizeof(T)); P.dy = (T *)take(n * sizeof(T)); P.dz = (T *)take(n * sizeof(T));
+  P.max_dist = (T *)take(n * sizeof(T)); P.importance = (T *)take(n * sizeof(T));
+  P.acc_r = (T *)take(n * sizeof(T)); P.acc_g = (T *)take(n * sizeof(T)); P.acc_b = (T *)take(n * sizeof(T));
+  P.hit_t = (T *)take(n * sizeof(T)); P.hit_idx = (int32_t *)take(n * 4);
+  P.draw = (uint32_t *)take(n * 4); P.depth = (int32_t *)take(n * 4); P.stack = (uint64_t *)take(n * 8);
+  P.out = (T *)take(n * 4 * sizeof(T));
+  return P;
+}
+
+template <typename T>
+int pl_trace_tile(rt_scene *sc, const rt_params *p, DevMap md, DevMap mc, int x0, int y0, int w, int h,
+                  double *pre, double *post, uint8_t *rgba8, rt_trace_stats *stats) {
+  rt_ctx *ctx = sc->ctx;
+  DevScene<T> &S = SceneOf<T>::get(sc);
+  const size_t n_pixels = (size_t)w * h;
+  const size_t n_paths = n_pixels * p->sub_sample * p->sub_sample;
+  if (n_paths == 0) return RT_OK;
+  if (n_paths > 0x7FFFFFFFull) return rt_fail(ctx, RT_ERR_TOO_LARGE, "tile has too many paths (%zu)", n_paths);
+  RT_HIP(ctx, sc->ws_paths.reserve(path_bytes<T>(n_paths)));
+  RT_HIP(ctx, sc->ws_queue.reserve(n_paths * 8));
+  RT_HIP(ctx, sc->ws_ctr.reserve(sizeof(TraceCounters)));
+  PathSoA<T> P = carve_paths<T>(sc->ws_paths.p, n_paths);
+  uint32_t *q_cur = sc->ws_queue.as<uint32_t>(), *q_nxt = q_cur + n_paths;
+  TraceCounters *ctr = sc->ws_ctr.as<TraceCounters>();
+  TraceCfg C;
+  C.epsilon = p->epsilon; C.max_trace_dist = p->max_trace_dist; C.diffuse_radius = p->diffuse_radius;
+  C.caustic_radius = p->caustic_radius; C.standard_lamp_area = p->standard_lamp_area;
+  C.shadow_bias = p->shadow_bias > 0 ? p->shadow_bias : p->epsilon;
+  C.max_depth = p->max_depth; C.sub_sample = p->sub_sample; C.use_direct_light = p->use_direct_light;
+  C.use_photon_maps = p->use_photon_maps; C.max_bounces = p->max_bounces > 0 ? p->max_bounces : 64;
+  C.seed = p->seed; C.x0 = x0; C.y0 = y0; C.w = w; C.h = h;
+  if (!p->use_photon_maps) { md.n = 0; mc.n = 0; }
+
+  RT_HIP(ctx, hipMemsetAsync(ctr, 0, sizeof(TraceCounters), ctx->stream));
+  RT_LAUNCH(ctx, "raygen", k_raygen<T>, div_up(n_paths, 256), 256, S, P, C, (uint32_t)n_paths, q_cur);
+  uint64_t rays = 0, bounces = 0;
+  uint32_t count = (uint32_t)n_paths;
+  unsigned long long *host_count = (unsigned long long *)ctx->pinned;
+  while (count > 0) {
+    RT_LAUNCH(ctx, "intersect_closest", k_intersect_closest<T>, div_up(count, 256), 256, S, P, q_cur, count, T(p->epsilon));
+    RT_LAUNCH(ctx, "shade", k_shade<T>, div_up(count, 256), 256, S, P, C, md, mc, q_cur, count, q_nxt, ctr, (int)bounces);
+    rays += count; bounces++;
+    RT_HIP(ctx, hipMemcpyAsync(host_count, &ctr->next_count, 8, hipMemcpyDeviceToHost, ctx->stream));
+    RT_HIP(ctx, hipMemsetAsync(&ctr->next_count, 0, 8, ctx->stream));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    count = (uint32_t)*host_count;
+    std::swap(q_cur, q_nxt);
+  }
+  RT_LAUNCH(ctx, "resolve", k_resolve<T>, div_up(n_pixels, 256), 256, P, (int)n_pixels, (int)p->sub_sample, pre, post, rgba8);
+  TraceCounters hc;
+  RT_HIP(ctx, hipMemcpyAsync(&hc, ctr, sizeof(hc), hipMemcpyDeviceToHost, ctx->stream));
+  RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  RT_HIP(ctx, hipGetLastError());
+  if (stats) {
+    stats->rays = rays; stats->bounces = bounces; stats->shadow_rays = hc.shadow_rays; stats->gathers = hc.gathers;
+    stats->stack_overflows = hc.stack_overflows;
+  }
+  return RT_OK;
+}
+
+// ------------------------------------------------------------------ emission
+template <typename T>
+int pl_emit_batch(rt_scene *sc, const rt_params *p, int phase, uint64_t a0, uint32_t count) {
+  rt_ctx *ctx = sc->ctx;
+  DevScene<T> &S = SceneOf<T>::get(sc);
+  RT_HIP(ctx, sc->ws_emit_kind.reserve(count));
+  RT_HIP(ctx, sc->ws_emit_rec.reserve((size_t)count * RT_REC_STRIDE * sizeof(T)));
+  if (!sc->ws_misc.p) { RT_HIP(ctx, sc->ws_misc.alloc(256)); RT_HIP(ctx, hipMemsetAsync(sc->ws_misc.p, 0, 256, ctx->stream)); }
+  EmitCfg C; C.epsilon = p->epsilon; C.max_depth = p->max_depth; C.num_diffuse = p->num_photons_diffuse;
+  C.num_caustic = p->num_photons_caustic; C.seed = p->seed;
+  RT_LAUNCH(ctx, "photon_emit_bounce", k_emit<T>, div_up(count, 256), 256, S, C, phase, (unsigned long long)a0, count,
+            sc->ws_emit_kind.as<uint8_t>(), sc->ws_emit_rec.as<T>(), sc->ws_misc.as<EmitCounters>());
+  RT_HIP(ctx, hipGetLastError());
+  return RT_OK;
+}
+
+template <typename T>
+int pl_emit_compact(rt_scene *sc, uint32_t count, int want, uint64_t a0, uint32_t out_base, uint32_t out_cap,
+                    double *out_rec, int64_t *out_attempt, uint8_t *out_kind, uint32_t *n_match) {
+  rt_ctx *ctx = sc->ctx;
+  const uint32_t blocks = div_up(count, 256);
+  RT_HIP(ctx, sc->ws_emit_blocks.reserve(((size_t)blocks + 1) * 4));
+  uint32_t *bc = sc->ws_emit_blocks.as<uint32_t>();
+  RT_LAUNCH(ctx, "compact_count", k_compact_count, blocks, 256, sc->ws_emit_kind.as<uint8_t>(), count, want, bc);
+  RT_LAUNCH(ctx, "compact_scan", k_scan_blocks, 1, 1024, bc, blocks, bc + blocks);
+  RT_LAUNCH(ctx, "compact_scatter", k_compact_scatter<T>, blocks, 256, sc->ws_emit_kind.as<uint8_t>(), sc->ws_emit_rec.as<T>(), count,
+            want, bc, (unsigned long long)a0, out_base, out_cap, out_rec, (long long *)out_attempt, out_kind);
+  RT_HIP(ctx, hipMemcpyAsync(ctx->pinned, bc + blocks, 4, hipMemcpyDeviceToHost, ctx->stream));
+  RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  RT_HIP(ctx, hipGetLastError());
+  *n_match = ctx->pinned[0];
+  return RT_OK;
+}
+
+#define RT_INSTANTIATE_PIPELINE(T)                                                                                     \
+  template int pl_intersect_pairs<T>(rt_ctx *, const rt_params *, uint32_t, const double *, const double *, int,       \
+                                     const uint8_t *, const double *, double *);                                       \
+  template int pl_intersect_scene<T>(rt_scene *, const rt_params *, int, uint32_t, const double *, const double *,     \
+                                     const double *, double *, int32_t *);                                             \
+  template int pl_trace_tile<T>(rt_scene *, const rt_params *, DevMap, DevMap, int, int, int, int, double *, double *, \
+                                uint8_t *, rt_trace_stats *);                                                          \
+  template int pl_emit_batch<T>(rt_scene *, const rt_params *, int, uint64_t, uint32_t);                               \
+  template int pl_emit_compact<T>(rt_scene *, uint32_t, int, uint64_t, uint32_t, uint32_t, double *, int64_t *,        \
+                                  uint8_t *, uint32_t *);

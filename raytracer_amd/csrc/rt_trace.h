@@ -1,0 +1,270 @@
+// Wavefront path tracer: SoA path state in HBM, one kernel per stage, survivors compacted
+// into the next queue with a wave ballot + prefix count and one atomic per wave.
+//
+//   raygen -> [ intersect_closest -> shade ]* -> resolve
+//
+// Semantics are the reference's traceRay / directLight (rayphoton.js:1626-1880).  Every
+// branch of traceRay makes at most one recursive call and adds its result unscaled, so a
+// path is a loop that accumulates the local terms of its opaque hits and ends with the
+// colour of the event that terminates it.
+#pragma once
+#include "rt_geom.h"
+#include "rt_kdq.h"
+#include "rt_sample.h"
+
+template <typename T> struct PathSoA {
+  T *ox, *oy, *oz, *dx, *dy, *dz;     // current segment
+  T *max_dist, *importance;
+  T *acc_r, *acc_g, *acc_b;           // sum of the local terms of the opaque hits so far
+  T *hit_t; int32_t *hit_idx;         // written by intersect_closest
+  uint32_t *draw;                     // RNG draws consumed by this path's stream
+  int32_t *depth;                     // low 16 bits depth, bit 16: an opaque hit fixed alpha = 1
+  uint64_t *stack;                    // MatStack bits
+  T *out;                             // n x 4: finished paths' colour
+};
+
+struct TraceCfg {
+  double epsilon, max_trace_dist, diffuse_radius, caustic_radius, standard_lamp_area, shadow_bias;
+  int32_t max_depth, sub_sample, use_direct_light, use_photon_maps, max_bounces;
+  uint64_t seed;
+  int32_t x0, y0, w, h;
+};
+
+struct TraceCounters { unsigned long long next_count, shadow_rays, gathers, stack_overflows; };
+
+// Append `value` to the queue for the lanes where `keep` is true: one atomicAdd per wave.
+RT_D void wave_push(bool keep, uint32_t value, uint32_t *queue, unsigned long long *counter) {
+  unsigned long long mask = __ballot(keep);
+  if (mask == 0) return;
+  int lane = threadIdx.x & 63;
+  int leader = __ffsll((long long)mask) - 1;
+  unsigned long long base = 0;
+  if (lane == leader) base = atomicAdd(counter, (unsigned long long)__popcll(mask));
+  base = __shfl(base, leader, 64);
+  if (keep) {
+    unsigned long long below = mask & (((unsigned long long)1 << lane) - 1);
+    queue[base + __popcll(below)] = value;
+  }
+}
+
+// traceOnCanvas ray set-up (rayphoton.js:1589-1609, superSampleScale 0).  One thread per path.
+template <typename T>
+__global__ void __launch_bounds__(256) k_raygen(DevScene<T> S, PathSoA<T> P, TraceCfg C, uint32_t n_paths, uint32_t *queue) {
+  uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n_paths) return;
+  const int SS = C.sub_sample * C.sub_sample;
+  uint32_t pix = p / SS, sub = p % SS;
+  int X = C.x0 + (int)(pix % C.w), Y = C.y0 + (int)(pix / C.w);
+  int sx = sub % C.sub_sample, sy = sub / C.sub_sample;
+  RngStream rng; rng.init(C.seed, RT_DOMAIN_RENDER, (uint32_t)(Y * (int)S.width + X), sub);
+  T u = ((T(X) + (T(sx) + rng.next<T>()) / T(C.sub_sample)) * T(2) / T(S.width)) - T(1);
+  T v = -(((T(Y) + (T(sy) + rng.next<T>()) / T(C.sub_sample)) * T(2) / T(S.height)) - T(1));
+  u *= S.camera[12]; v *= S.camera[13];
+  V3<T> co = ld3(S.camera), cu = ld3(S.camera + 3), cv = ld3(S.camera + 6), cw = ld3(S.camera + 9);
+  V3<T> xyz = ((co + u * cu) + v * cv) + T(-1) * cw;                    // Camera.toXYZ, rayphoton.js:712
+  V3<T> d = normalize<T>(xyz - co, T(C.epsilon));
+  P.ox[p] = co.x; P.oy[p] = co.y; P.oz[p] = co.z; P.dx[p] = d.x; P.dy[p] = d.y; P.dz[p] = d.z;
+  P.max_dist[p] = T(C.max_trace_dist); P.importance[p] = T(1);
+  P.acc_r[p] = T(0); P.acc_g[p] = T(0); P.acc_b[p] = T(0);
+  P.draw[p] = rng.draw; P.depth[p] = 0;
+  MatStack st; st.init(); P.stack[p] = st.bits;
+  queue[p] = p;
+}
+
+// Closest hit of every queued path against the whole scene (rayphoton.js:1642-1650).
+// This is the VALU-bound kernel: the primitive index is wave-uniform, so primitive operands
+// are scalar loads and every lane spends its cycles on the distance arithmetic.
+template <typename T>
+__global__ void __launch_bounds__(256) k_intersect_closest(DevScene<T> S, PathSoA<T> P, const uint32_t *queue, uint32_t count, T eps) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  uint32_t p = queue[i];
+  V3<T> o = mk<T>(P.ox[p], P.oy[p], P.oz[p]), d = mk<T>(P.dx[p], P.dy[p], P.dz[p]);
+  T t;
+  int idx = scan_scene<T, 0>(S, o, d, eps, T(0), t);
+  P.hit_t[p] = t; P.hit_idx[p] = idx;
+}
+
+// directLight (rayphoton.js:1841-1880): per light one createPhoton() of a RANDOM light, scaled by
+// THIS light's area; an unclamped cosine; floor at the end.
+template <typename T>
+RT_D V3<T> direct_light(const DevScene<T> &S, const TraceCfg &C, V3<T> point, V3<T> normal, V3<T> local, RngStream &rng,
+                        unsigned long long &shadow_rays) {
+  const T eps = T(C.epsilon);
+  V3<T> col = mk<T>(0, 0, 0);
+  for (uint32_t l = 0; l < S.n_lights; l++) {
+    PhotonState<T> ph; create_photon<T>(S, eps, rng, ph);
+    T power = ph.power * S.light_data[l][1];
+    V3<T> dir = normalize<T>(ph.o - point, eps);
+    T source_dist = rt_sqrt(sqlen(point - ph.o));
+    T thit;
+    shadow_rays++;
+    if (!scan_scene<T, 2>(S, point, dir, eps, source_dist, thit)) {
+      T dn = dot(dir, normal);
+      T k = T(C.standard_lamp_area);
+      col.x += (ph.r / T(255)) * local.x * dn * power / k;
+      col.y += (ph.g / T(255)) * local.y * dn * power / k;
+      col.z += (ph.b / T(255)) * local.z * dn * power / k;
+    }
+  }
+  return mk<T>(rt_floor(col.x), rt_floor(col.y), rt_floor(col.z));
+}
+
+// Radiance estimate from one photon map (rayphoton.js:1765-1815): sum over the photons within r
+// of colour * power * max(0, dir . normal).  fp64 paths use the fp64 photon records when the map
+// kept them; the fp32 path reads the 24-byte fp32 payload.
+template <typename T>
+RT_D V3<T> gather_map(const DevMap &M, V3<T> x, V3<T> normal, double r) {
+  T sr = T(0), sg = T(0), sb = T(0);
+  const double r2 = r * r;
+  const bool use64 = (sizeof(T) == 8) && (M.rec64 != nullptr);
+  kd_radius_walk(M, (double)x.x, (double)x.y, (double)x.z, r, [&](uint32_t slot, float4 nd) {
+    if (use64) {
+      const double *R = M.rec64 + (size_t)slot * 11;
+      if (sq_dist((double)x.x, (double)x.y, (double)x.z, R[0], R[1], R[2]) < r2) {
+        T w = dot(mk<T>(T(R[3]), T(R[4]), T(R[5])), normal);
+        w = w > T(0) ? w : T(0);
+        sr += T(R[7]) * T(R[6]) * w; sg += T(R[8]) * T(R[6]) * w; sb += T(R[9]) * T(R[6]) * w;
+      }
+    } else if (sq_dist((double)x.x, (double)x.y, (double)x.z, (double)nd.x, (double)nd.y, (double)nd.z) < r2) {
+      const float *pp = M.pay + (size_t)slot * 6;
+      T w = dot(mk<T>(T(pp[0]), T(pp[1]), T(pp[2])), normal);
+      w = w > T(0) ? w : T(0);
+      sr += T(pp[3]) * w; sg += T(pp[4]) * w; sb += T(pp[5]) * w;
+    }
+  });
+  return mk<T>(sr, sg, sb);
+}
+
+template <typename T> RT_D void finish_path(const PathSoA<T> &P, uint32_t p, V3<T> acc, V3<T> term, T term_a, bool alpha_fixed) {
+  T *o = P.out + (size_t)p * 4;
+  o[0] = acc.x + term.x; o[1] = acc.y + term.y; o[2] = acc.z + term.z;
+  o[3] = alpha_fixed ? T(1) : term_a;
+}
+
+// One traceRay body per queued path (rayphoton.js:1651-1838).  A path either finishes (its
+// colour goes to P.out) or leaves a new segment in the path state and enters `next_queue`.
+template <typename T>
+__global__ void __launch_bounds__(256) k_shade(DevScene<T> S, PathSoA<T> P, TraceCfg C, DevMap Md, DevMap Mc,
+                                               const uint32_t *queue, uint32_t count, uint32_t *next_queue,
+                                               TraceCounters *ctr, int bounce) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  bool alive = false; uint32_t p = 0;
+  unsigned long long shadow_rays = 0, gathers = 0, overflows = 0;
+  if (i < count) {
+    p = queue[i];
+    const T eps = T(C.epsilon);
+    const int idx = P.hit_idx[p];
+    V3<T> acc = mk<T>(P.acc_r[p], P.acc_g[p], P.acc_b[p]);
+    const int dword = P.depth[p];
+    const int depth = dword & 0xFFFF; const bool alpha_fixed = dword & 0x10000;
+    const V3<T> ZERO = mk<T>(0, 0, 0);
+    if (idx < 0) {
+      finish_path<T>(P, p, acc, mk<T>(16, 16, 16), T(1), alpha_fixed);                 // COL_VERY_DARK_GREY :1838
+    } else if (S.meta[4 * idx + 2] & RT_FLAG_LIGHT) {                                  // :1654-1656
+      int l = 0;
+      for (uint32_t k = 0; k < S.n_lights; k++) if ((int)S.light_shape[k] == idx) l = (int)k;
+      finish_path<T>(P, p, acc, mk<T>(S.light_data[l][3], S.light_data[l][4], S.light_data[l][5]), S.light_data[l][6], alpha_fixed);
+    } else {
+      const T t = P.hit_t[p];
+      V3<T> o = mk<T>(P.ox[p], P.oy[p], P.oz[p]), d = mk<T>(P.dx[p], P.dy[p], P.dz[p]);
+      const T max_dist = P.max_dist[p];
+      V3<T> hit = o + t * d;
+      V3<T> local = shape_colour<T>(S, idx, hit);
+      V3<T> n = shape_normal<T>(S, idx, hit);
+      if (t < max_dist || depth < C.max_depth) {                                       // :1677 (note: OR)
+        const T cos1 = -dot(d, n);
+        const int mat = S.meta[4 * idx + 1] & 7;
+        const bool has_mat = S.meta[4 * idx + 1] < 8;
+        RngStream rng; rng.init(C.seed, RT_DOMAIN_RENDER, 0, 0, P.draw[p]);
+        {   // the stream key is (pixel, sub-sample); recover it from the path index
+          const int SS = C.sub_sample * C.sub_sample;
+          uint32_t pix = p / SS;
+          int X = C.x0 + (int)(pix % C.w), Y = C.y0 + (int)(pix / C.w);
+          rng.a = (uint32_t)(Y * (int)S.width + X); rng.b = p % SS;
+        }
+        if (has_mat && S.mat[0][mat] == T(1)) {                                        // transparent :1679
+          MatStack st; st.bits = P.stack[p];
+          V3<T> ndir; bool ovf = false;
+          if (!fresnel_bounce<T>(S, mat, d, n, cos1, st, rng, ndir, ovf)) {
+            finish_path<T>(P, p, acc, ZERO, T(0), alpha_fixed);                        // COL_BLACK :1699
+          } else {
+            if (ovf) overflows++;
+            ndir = normalize<T>(ndir, eps);
+            P.ox[p] = hit.x; P.oy[p] = hit.y; P.oz[p] = hit.z; P.dx[p] = ndir.x; P.dy[p] = ndir.y; P.dz[p] = ndir.z;
+            P.max_dist[p] = max_dist - t; P.depth[p] = dword + 1; P.stack[p] = st.bits; P.draw[p] = rng.draw;
+            alive = true;                                                              // importance unchanged, >= 0.01
+          }
+        } else if (cos1 < T(0)) {
+          finish_path<T>(P, p, acc, ZERO, T(1), alpha_fixed);                          // inside an opaque object :1736-1747
+        } else {
+          const T refl = has_mat ? S.mat[2][mat] : Limits<T>::nan();
+          V3<T> direct = ZERO;
+          if (refl < T(1) && C.use_direct_light) {
+            const T bias = T(C.shadow_bias);
+            direct = direct_light<T>(S, C, hit + bias * n, n, local, rng, shadow_rays);          // :1750-1752
+          }
+          bool spec = false;
+          if (rng.next_k() < (has_mat ? S.refl_k[mat] : 0u)) spec = rng.next_k() < S.spec_k[mat];   // :1753, short-circuit
+          V3<T> diff = ZERO, caus = ZERO;
+          if (C.use_photon_maps) {
+            if (Md.n) { diff = gather_map<T>(Md, hit, n, C.diffuse_radius); gathers++; }
+            if (Mc.n) { caus = gather_map<T>(Mc, hit, n, C.caustic_radius); gathers++; }
+          }
+          const T PI_ = T(3.141592653589793);
+          const T dArea = PI_ * T(C.diffuse_radius * C.diffuse_radius), cArea = PI_ * T(C.caustic_radius * C.caustic_radius);
+          V3<T> lc = mk<T>(local.x / T(255), local.y / T(255), local.z / T(255));
+          diff = mk<T>(diff.x * lc.x / dArea, diff.y * lc.y / dArea, diff.z * lc.z / dArea);      // :1808-1815
+          caus = mk<T>(caus.x * lc.x / cArea, caus.y * lc.y / cArea, caus.z * lc.z / cArea);
+          V3<T> term = ((T(1) - refl) * direct + diff) + caus;                                    // :1817-1822 minus the child
+          acc = acc + term;
+          const T imp = P.importance[p] * refl;
+          if (spec && !(imp < T(0.01))) {                                                         // child would return at :1627
+            V3<T> ndir = normalize<T>(d + (T(2) * cos1) * n, eps);
+            P.ox[p] = hit.x; P.oy[p] = hit.y; P.oz[p] = hit.z; P.dx[p] = ndir.x; P.dy[p] = ndir.y; P.dz[p] = ndir.z;
+            P.max_dist[p] = max_dist - t; P.importance[p] = imp; P.depth[p] = (dword + 1) | 0x10000;
+            P.acc_r[p] = acc.x; P.acc_g[p] = acc.y; P.acc_b[p] = acc.z; P.draw[p] = rng.draw;
+            alive = true;
+          } else {
+            finish_path<T>(P, p, acc, ZERO, T(1), true);
+          }
+        }
+      } else {
+        finish_path<T>(P, p, acc, ZERO, T(1), alpha_fixed);                            // :1828-1833
+      }
+    }
+    if (alive && bounce + 1 >= C.max_bounces) {                                        // safety cap; the reference has none
+      finish_path<T>(P, p, mk<T>(P.acc_r[p], P.acc_g[p], P.acc_b[p]), ZERO, T(1), (P.depth[p] & 0x10000) != 0);
+      alive = false;
+    }
+  }
+  wave_push(alive, p, next_queue, &ctr->next_count);
+  if (shadow_rays) atomicAdd(&ctr->shadow_rays, shadow_rays);
+  if (gathers) atomicAdd(&ctr->gathers, gathers);
+  if (overflows) atomicAdd(&ctr->stack_overflows, overflows);
+}
+
+RT_D double clamp01(double x, double lo, double hi) { return (x < lo) ? lo : ((x > hi) ? hi : x); }
+
+// Pixel resolve (rayphoton.js:1610-1623): clamp each sub-sample (`colour()`), sum, floor of the
+// mean.  pre = the last sub-sample's unclamped colour; rgba8 = post as bytes.
+template <typename T>
+__global__ void __launch_bounds__(256) k_resolve(PathSoA<T> P, int n_pixels, int sub_sample, double *pre, double *post, uint8_t *rgba8) {
+  int pix = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pix >= n_pixels) return;
+  const int SS = sub_sample * sub_sample;
+  double tot[4] = { 0, 0, 0, 0 }, last[4] = { 0, 0, 0, 0 };
+  for (int s = 0; s < SS; s++) {
+    const T *o = P.out + ((size_t)pix * SS + s) * 4;
+    for (int c = 0; c < 4; c++) { last[c] = (double)o[c]; tot[c] += clamp01(last[c], 0, c == 3 ? 1 : 255); }
+  }
+  for (int c = 0; c < 4; c++) {
+    double v = floor(tot[c] / SS);
+    if (pre) pre[(size_t)pix * 4 + c] = last[c];
+    if (post) post[(size_t)pix * 4 + c] = v;
+    if (rgba8) {
+      double b = (c == 3) ? v * 255.0 : v;
+      rgba8[(size_t)pix * 4 + c] = (b == b) ? (uint8_t)(b < 0 ? 0 : (b > 255 ? 255 : b)) : 0;
+    }
+  }
+}
