@@ -74,7 +74,9 @@ typedef struct rt_params {
   int32_t use_photon_maps;      /* 0: skip both radius gathers (rayphoton.js:1765, :1788) */
   int32_t precision;            /* RT_PRECISION_F32 (throughput) or RT_PRECISION_F64 (parity) */
   int32_t mode;                 /* RT_MODE_PHOTON or RT_MODE_WHITTED */
-  double shadow_bias;           /* offset along the normal for shadow rays; 0 = epsilon (rayphoton.js:1751) */
+  double shadow_bias;           /* offset along the normal for shadow rays; 0 = the working epsilon (rayphoton.js:1751) */
+  double epsilon_f32;           /* the epsilon the fp32 kernels use instead of `epsilon` (0 = 1e-4): 1e-6 is below
+                                   fp32 resolution at scene scale, so on-surface origins would re-hit their surface */
   int32_t max_bounces;          /* hard cap on path segments (0 = 64); the reference has none */
   int32_t reserved;
 } rt_params;

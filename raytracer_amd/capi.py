@@ -47,7 +47,7 @@ class Params(C.Structure):
                 ("num_photons_caustic", C.c_uint32), ("diffuse_radius", C.c_double),
                 ("caustic_radius", C.c_double), ("standard_lamp_area", C.c_double), ("seed", C.c_uint64),
                 ("use_direct_light", C.c_int32), ("use_photon_maps", C.c_int32), ("precision", C.c_int32),
-                ("mode", C.c_int32), ("shadow_bias", C.c_double), ("max_bounces", C.c_int32),
+                ("mode", C.c_int32), ("shadow_bias", C.c_double), ("epsilon_f32", C.c_double), ("max_bounces", C.c_int32),
                 ("reserved", C.c_int32)]
 
 

@@ -55,7 +55,7 @@ void rt_default_params(rt_params *p) {
   p->num_photons_diffuse = 20000; p->num_photons_caustic = 50000;
   p->diffuse_radius = 0.40; p->caustic_radius = 0.15; p->standard_lamp_area = 100;
   p->seed = 12345; p->use_direct_light = 1; p->use_photon_maps = 1;
-  p->precision = RT_PRECISION_F32; p->mode = RT_MODE_PHOTON; p->shadow_bias = 0; p->max_bounces = 64;
+  p->precision = RT_PRECISION_F32; p->mode = RT_MODE_PHOTON; p->shadow_bias = 0; p->epsilon_f32 = 1e-4; p->max_bounces = 64;
 }
 
 int rt_init(const int *device_ids, int n, rt_ctx **out) {
@@ -379,7 +379,10 @@ int rt_emit_many(rt_scene *sc, const rt_params *p, double *diffuse, int64_t *dif
   if (caustic_attempt) memcpy(caustic_attempt, c_att.data(), c_att.size() * 8);
   if (diffuse) RT_TRY(rt_stage_out_end(ctx, diffuse, (size_t)nd * 88, t1));
   if (caustic) RT_TRY(rt_stage_out_end(ctx, caustic, (size_t)nc * 88, t2));
-  if (err) rc = rt_fail(ctx, RT_ERR_MATERIAL_STACK, "photon exited all materials? check consistency of objects? (%llu attempts)",
+  // The reference throws here (rayphoton.js:1489).  The fp64 build mirrors that; in fp32 the rim gaps between a
+  // cylinder and its caps are epsilon_f32 wide, a photon can slip through one and later meet the inside of the
+  // glass with an empty stack: such attempts are dropped and only counted (stats.errors).
+  if (err && p->precision == RT_PRECISION_F64) rc = rt_fail(ctx, RT_ERR_MATERIAL_STACK, "photon exited all materials? check consistency of objects? (%llu attempts)",
                         (unsigned long long)err);                                  // rayphoton.js:1489
   else if (st.capped) rc = rt_fail(ctx, RT_ERR_ATTEMPT_CAP, "I tried many times but only created %u diffuse / %u caustic photons.", nd, nc);
   return rc;

@@ -5,6 +5,12 @@
 #include "rt_pipeline.h"
 #include "rt_trace.h"
 
+// working epsilon of a precision: the reference's EPSILON for fp64, the coarser epsilon_f32 for fp32
+template <typename T> static double working_eps(const rt_params *p) {
+  if (sizeof(T) == 8) return p->epsilon;
+  return p->epsilon_f32 > 0 ? p->epsilon_f32 : 1e-4;
+}
+
 template <typename T> struct SceneOf;
 template <> struct SceneOf<float> { static DevScene<float> &get(rt_scene *s) { return s->d32; } };
 template <> struct SceneOf<double> { static DevScene<double> &get(rt_scene *s) { return s->d64; } };
@@ -40,7 +46,7 @@ __global__ void __launch_bounds__(256) k_scan_rays(DevScene<T> S, uint32_t n, co
 template <typename T>
 int pl_intersect_pairs(rt_ctx *ctx, const rt_params *p, uint32_t n, const double *o, const double *d, int normalize_dir,
                        const uint8_t *meta, const double *geom, double *t_out) {
-  RT_LAUNCH(ctx, "intersect_pairs", k_intersect_pairs<T>, div_up(n, 256), 256, n, o, d, normalize_dir, meta, geom, T(p->epsilon), t_out);
+  RT_LAUNCH(ctx, "intersect_pairs", k_intersect_pairs<T>, div_up(n, 256), 256, n, o, d, normalize_dir, meta, geom, T(working_eps<T>(p)), t_out);
   RT_HIP(ctx, hipGetLastError());
   return RT_OK;
 }
@@ -51,7 +57,7 @@ int pl_intersect_scene(rt_scene *sc, const rt_params *p, int mode, uint32_t n, c
   rt_ctx *ctx = sc->ctx;
   DevScene<T> &S = SceneOf<T>::get(sc);
   const uint32_t grid = div_up(n, 256);
-  const T eps = T(p->epsilon);
+  const T eps = T(working_eps<T>(p));
   if (mode == RT_SCAN_CLOSEST) RT_LAUNCH(ctx, "scan_closest", (k_scan_rays<T, 0>), grid, 256, S, n, o, d, source_dist, eps, t_out, idx_out);
   else if (mode == RT_SCAN_CLOSEST_NOLIGHT) RT_LAUNCH(ctx, "scan_closest_nolight", (k_scan_rays<T, 1>), grid, 256, S, n, o, d, source_dist, eps, t_out, idx_out);
   else RT_LAUNCH(ctx, "scan_any", (k_scan_rays<T, 2>), grid, 256, S, n, o, d, source_dist, eps, t_out, idx_out);
@@ -60,10 +66,8 @@ int pl_intersect_scene(rt_scene *sc, const rt_params *p, int mode, uint32_t n, c
 }
 
 // ------------------------------------------------------------------ renderer
-template <typename T> static size_t path_bytes(size_t n) { return n * (15 * sizeof(T) + 4 + 4 + 4 + 8) + 64 * 32; }
-
-template <typename T> static PathSoA<T> carve_paths(void *base, size_t n) {
-  // 256-byte aligned sub-arrays out of one allocation
+// 256-byte aligned sub-arrays out of one allocation; with base == nullptr only the total size is computed
+template <typename T> static PathSoA<T> carve_paths(void *base, size_t n, size_t *total = nullptr) {
   char *p = (char *)base;
   auto take = [&](size_t bytes) { char *r = p; p += (bytes + 255) & ~(size_t)255; return (void *)r; };
   PathSoA<T> P;
@@ -74,6 +78,7 @@ template <typename T> static PathSoA<T> carve_paths(void *base, size_t n) {
   P.hit_t = (T *)take(n * sizeof(T)); P.hit_idx = (int32_t *)take(n * 4);
   P.draw = (uint32_t *)take(n * 4); P.depth = (int32_t *)take(n * 4); P.stack = (uint64_t *)take(n * 8);
   P.out = (T *)take(n * 4 * sizeof(T));
+  if (total) *total = (size_t)(p - (char *)base);
   return P;
 }
 
@@ -86,16 +91,18 @@ int pl_trace_tile(rt_scene *sc, const rt_params *p, DevMap md, DevMap mc, int x0
   const size_t n_paths = n_pixels * p->sub_sample * p->sub_sample;
   if (n_paths == 0) return RT_OK;
   if (n_paths > 0x7FFFFFFFull) return rt_fail(ctx, RT_ERR_TOO_LARGE, "tile has too many paths (%zu)", n_paths);
-  RT_HIP(ctx, sc->ws_paths.reserve(path_bytes<T>(n_paths)));
+  size_t path_bytes = 0;
+  carve_paths<T>(nullptr, n_paths, &path_bytes);
+  RT_HIP(ctx, sc->ws_paths.reserve(path_bytes));
   RT_HIP(ctx, sc->ws_queue.reserve(n_paths * 8));
   RT_HIP(ctx, sc->ws_ctr.reserve(sizeof(TraceCounters)));
   PathSoA<T> P = carve_paths<T>(sc->ws_paths.p, n_paths);
   uint32_t *q_cur = sc->ws_queue.as<uint32_t>(), *q_nxt = q_cur + n_paths;
   TraceCounters *ctr = sc->ws_ctr.as<TraceCounters>();
   TraceCfg C;
-  C.epsilon = p->epsilon; C.max_trace_dist = p->max_trace_dist; C.diffuse_radius = p->diffuse_radius;
+  C.epsilon = working_eps<T>(p); C.max_trace_dist = p->max_trace_dist; C.diffuse_radius = p->diffuse_radius;
   C.caustic_radius = p->caustic_radius; C.standard_lamp_area = p->standard_lamp_area;
-  C.shadow_bias = p->shadow_bias > 0 ? p->shadow_bias : p->epsilon;
+  C.shadow_bias = p->shadow_bias > 0 ? p->shadow_bias : C.epsilon;
   C.max_depth = p->max_depth; C.sub_sample = p->sub_sample; C.use_direct_light = p->use_direct_light;
   C.use_photon_maps = p->use_photon_maps; C.max_bounces = p->max_bounces > 0 ? p->max_bounces : 64;
   C.seed = p->seed; C.x0 = x0; C.y0 = y0; C.w = w; C.h = h;
@@ -107,7 +114,7 @@ int pl_trace_tile(rt_scene *sc, const rt_params *p, DevMap md, DevMap mc, int x0
   uint32_t count = (uint32_t)n_paths;
   unsigned long long *host_count = (unsigned long long *)ctx->pinned;
   while (count > 0) {
-    RT_LAUNCH(ctx, "intersect_closest", k_intersect_closest<T>, div_up(count, 256), 256, S, P, q_cur, count, T(p->epsilon));
+    RT_LAUNCH(ctx, "intersect_closest", k_intersect_closest<T>, div_up(count, 256), 256, S, P, q_cur, count, T(C.epsilon));
     RT_LAUNCH(ctx, "shade", k_shade<T>, div_up(count, 256), 256, S, P, C, md, mc, q_cur, count, q_nxt, ctr, (int)bounces);
     rays += count; bounces++;
     RT_HIP(ctx, hipMemcpyAsync(host_count, &ctr->next_count, 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -136,7 +143,7 @@ int pl_emit_batch(rt_scene *sc, const rt_params *p, int phase, uint64_t a0, uint
   RT_HIP(ctx, sc->ws_emit_kind.reserve(count));
   RT_HIP(ctx, sc->ws_emit_rec.reserve((size_t)count * RT_REC_STRIDE * sizeof(T)));
   if (!sc->ws_misc.p) { RT_HIP(ctx, sc->ws_misc.alloc(256)); RT_HIP(ctx, hipMemsetAsync(sc->ws_misc.p, 0, 256, ctx->stream)); }
-  EmitCfg C; C.epsilon = p->epsilon; C.max_depth = p->max_depth; C.num_diffuse = p->num_photons_diffuse;
+  EmitCfg C; C.epsilon = working_eps<T>(p); C.max_depth = p->max_depth; C.num_diffuse = p->num_photons_diffuse;
   C.num_caustic = p->num_photons_caustic; C.seed = p->seed;
   RT_LAUNCH(ctx, "photon_emit_bounce", k_emit<T>, div_up(count, 256), 256, S, C, phase, (unsigned long long)a0, count,
             sc->ws_emit_kind.as<uint8_t>(), sc->ws_emit_rec.as<T>(), sc->ws_misc.as<EmitCounters>());
