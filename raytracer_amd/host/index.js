@@ -1,0 +1,231 @@
+'use strict';
+// Node host of the MI355X ray-tracing / photon-mapping core: the reference's JavaScript-visible
+// surface (Scene, Ray, Photon, KdTree; rayphoton.js:483-488, :647-654, :715-727, kdtree.js:1-8)
+// kept as the API, with every hot path running in HIP behind the N-API shim
+// (napi/rt355_napi.cc -> librt355.so).  Nothing here computes intersections, photon walks,
+// tree builds or gathers in JavaScript; if the addon or a GPU is missing the calls throw.
+
+const path = require('path');
+const S = require('./scene');
+const presets = require('./presets');
+
+let native = null;
+function addon() {
+  if (!native) {
+    try { native = require(path.join(__dirname, 'napi', 'rt355.node')); }
+    catch (e) { throw new Error(`rt355.node is not built (make -C raytracer_amd/host/napi): ${e.message}`); }
+  }
+  return native;
+}
+
+let sharedCtx = null;
+function context(device) {
+  if (!sharedCtx) sharedCtx = addon().init(device || 0);
+  return sharedCtx;
+}
+
+const PRECISION = { F32: 0, F64: 1 };
+
+// the reference's top-of-file constants (rayphoton.js:6-23) as overridable defaults
+const DEFAULTS = {
+  epsilon: 1e-6, maxTraceDist: 20, maxDepth: 5, subSample: 6, numPhotonsDiffuse: 20000, numPhotonsCaustic: 50000,
+  causticRadius: 0.15, diffuseRadius: 0.40, standardLampArea: 100, seed: 12345, precision: PRECISION.F32,
+};
+
+class Ray {
+  constructor(origin, dir) { this.origin = origin; this.dir = require('./vec').normalise(dir); }
+  // distance to one shape, or undefined (rayphoton.js:490-644) -- one-pair launch of the geometry kernel
+  intersectDist(shape, params) {
+    const f = S.flattenShape(shape);
+    const t = addon().intersectPairs(context(), Object.assign({ precision: PRECISION.F64 }, params || {}),
+      Float64Array.from(this.origin), Float64Array.from(this.dir), 0,
+      Uint8Array.from([f.typeId, f.material, f.flags, f.proc]), Float64Array.from(f.g));
+    return Number.isNaN(t[0]) ? undefined : t[0];
+  }
+}
+
+class Photon extends Ray {
+  constructor(origin, dir, power, colour, isCaustic) {
+    super(origin, dir);
+    this.power = power; this.colour = colour || S.COL.WHITE; this.isCaustic = isCaustic;
+  }
+}
+
+// photon list <-> the 11-double records of the C ABI (origin3 dir3 power rgba)
+function photonsToRecords(photons) {
+  const rec = new Float64Array(photons.length * 11);
+  photons.forEach((p, i) => {
+    const c = p.colour || S.COL.WHITE;
+    rec.set([p.origin[0], p.origin[1], p.origin[2], p.dir[0], p.dir[1], p.dir[2], p.power === undefined ? 0 : p.power,
+      c.r, c.g, c.b, c.a === undefined ? NaN : c.a], i * 11);
+  });
+  return rec;
+}
+function recordsToPhotons(rec, isCaustic) {
+  const out = new Array(rec.length / 11);
+  for (let i = 0; i < out.length; i++) {
+    const r = rec.subarray(i * 11, i * 11 + 11);
+    const p = Object.create(Photon.prototype);          // records are already normalised: skip the ctor's renormalisation
+    p.origin = [r[0], r[1], r[2]]; p.dir = [r[3], r[4], r[5]]; p.power = r[6];
+    p.colour = { r: r[7], g: r[8], b: r[9], a: r[10] }; p.isCaustic = isCaustic;
+    out[i] = p;
+  }
+  return out;
+}
+
+class KdTree {
+  // photons: array of {origin, dir, power, colour} (anything with .origin works for pure queries),
+  // or a Float64Array of 11-double records
+  constructor(data) {
+    const n = ArrayBuffer.isView(data) ? data.length / 11 : data.length;
+    console.log(`building a k-d tree with ${n} elements`);                 // kdtree.js:3
+    if (n === 0) throw new Error('tried to build a k-d tree with no data!');   // kdtree.js:6
+    this.photons = ArrayBuffer.isView(data) ? null : data;
+    this.records = ArrayBuffer.isView(data) ? data : photonsToRecords(data);
+    this.map = addon().photonMapBuild(context(), this.records);
+    this._nodes = null;
+  }
+  get length() { return this.records.length / 11; }
+  photonAt(i) {
+    if (!this.photons) this.photons = recordsToPhotons(this.records, undefined);
+    return this.photons[i];
+  }
+  // nodes[pos] = {dim, photon}, 1-based implicit heap (kdtree.js:104), materialised on first use
+  get nodes() {
+    if (!this._nodes) {
+      const { perm, dim } = addon().photonMapNodes(this.map);
+      this._nodes = [undefined];
+      for (let s = 0; s < perm.length; s++) this._nodes.push({ dim: dim[s], photon: this.photonAt(perm[s]) });
+    }
+    return this._nodes;
+  }
+  // all photons within r of x, in the reference's pre-order (kdtree.js:64-80)
+  nearestNeighbours(x, r, pos) {
+    if (pos !== undefined && pos !== 1) throw new Error('nearestNeighbours: sub-tree queries (pos != 1) are not offered by the device tree');
+    return this.nearestNeighboursBatch(Float32Array.from(x), r)[0];
+  }
+  // many queries in one launch: queries = Float32Array(nq*3) -> array of photon lists
+  nearestNeighboursBatch(queries, r, cap) {
+    const nq = queries.length / 3;
+    cap = cap || 64;
+    let res = addon().kdRadius(this.map, queries, r, cap);
+    let most = 0;
+    for (let i = 0; i < nq; i++) most = Math.max(most, res.count[i]);
+    if (most > cap) { cap = most; res = addon().kdRadius(this.map, queries, r, cap); }
+    const out = [];
+    for (let i = 0; i < nq; i++) {
+      const list = [];
+      for (let k = 0; k < res.count[i]; k++) list.push(this.photonAt(res.idx[i * cap + k]));
+      out.push(list);
+    }
+    return out;
+  }
+  // k nearest photons ordered by (squared distance, input index): [{photon, index, distSq}]
+  kNearest(x, k) {
+    const res = addon().kdKnn(this.map, Float32Array.from(x), k);
+    const out = [];
+    for (let i = 0; i < k && res.idx[i] >= 0; i++) out.push({ photon: this.photonAt(res.idx[i]), index: res.idx[i], distSq: res.d2[i] });
+    return out;
+  }
+  // [point, distance] of the nearest photon.  The reference's version (kdtree.js:10-62) never searches
+  // the far side of a split and is therefore approximate (and never called); this one is exact.
+  nearestNeighbourAndDistance(x, pos) {
+    if (pos !== undefined && pos !== 1) throw new Error('nearestNeighbourAndDistance: sub-tree queries are not offered by the device tree');
+    const best = this.kNearest(x, 1)[0];
+    return best ? [best.photon.origin, Math.sqrt(best.distSq)] : [undefined, undefined];
+  }
+  findMedian(n) {
+    if (n === 0) throw new Error(':O');                                      // kdtree.js:110
+    return addon().findMedian(n);
+  }
+}
+
+class Scene {
+  // ctx: anything with width/height and (optionally) fillStyle/fillRect, like the canvas context
+  // the reference draws into (rayphoton.js:716-727, :1917-1918)
+  constructor(ctx, options) {
+    this.ctx = ctx;
+    this.canvasWidth = ctx.width; this.canvasHeight = ctx.height;
+    this.shapes = []; this.lights = [];
+    this.photonListDiffuse = []; this.photonListCaustic = []; this.photonListBad = [];
+    this.photonKdTDiffuse = []; this.photonKdTCaustic = [];
+    this.params = Object.assign({}, DEFAULTS, options || {});
+    this._device = null;
+  }
+
+  loadPreset(def) {
+    const build = presets[String(def)];
+    if (!build) { console.log('No such scene!'); }                           // rayphoton.js:1306
+    else build(this, S);
+    this.initLights();
+    this.emitManyPhotons();
+  }
+
+  initLights() {                                                              // rayphoton.js:1313-1324
+    let total = 0;
+    for (const l of this.lights) { const s = this.shapes[l]; s.intensity = s.wattage * s.area; total += s.intensity; }
+    for (const l of this.lights) { const s = this.shapes[l]; s.prob = s.intensity / total; }
+    this._device = null;
+  }
+
+  flatten() { return S.flatten(this); }
+
+  _scene() {                  // uploads on first use; call initLights()/invalidate() after editing shapes
+    if (!this._device) this._device = addon().sceneUpload(context(), this.flatten());
+    return this._device;
+  }
+  invalidate() { this._device = null; }
+
+  // emitManyPhotons (rayphoton.js:1354-1383): both phases on the GPU, then both kd-trees
+  emitManyPhotons() {
+    if (this.lights.length === 0) { console.log("No lights! Can't emit photons."); return; }
+    const res = addon().emitMany(this._scene(), this.params);
+    this.emitStats = res.stats;
+    if (res.stats.capped) {
+      console.log(`I tried many times but only created ${res.stats.nDiffuse} diffuse / ${res.stats.nCaustic} caustic photons.`);
+      if (res.stats.nDiffuse < this.params.numPhotonsDiffuse) { this._recD = res.diffuse; this._recC = res.caustic; return; }
+    }
+    this._recD = res.diffuse; this._recC = res.caustic;
+    this.photonKdTDiffuse = new KdTree(res.diffuse);
+    if (!res.stats.capped) this.photonKdTCaustic = new KdTree(res.caustic);
+    let listD = null, listC = null;     // photon object lists are materialised only if somebody looks
+    Object.defineProperty(this, 'photonListDiffuse', { configurable: true, get: () => (listD = listD || recordsToPhotons(res.diffuse, false)) });
+    Object.defineProperty(this, 'photonListCaustic', { configurable: true, get: () => (listC = listC || recordsToPhotons(res.caustic, true)) });
+  }
+
+  // pixels [x0,x0+w) x [y0,y0+h): {pre, post: Float64Array(w*h*4), rgba8: Uint8Array, stats}
+  render(x0, y0, w, h, overrides) {
+    const md = this.photonKdTDiffuse instanceof KdTree ? this.photonKdTDiffuse.map : null;
+    const mc = this.photonKdTCaustic instanceof KdTree ? this.photonKdTCaustic.map : null;
+    return addon().traceTile(this._scene(), Object.assign({}, this.params, overrides || {}), md, mc, x0, y0, w, h);
+  }
+
+  // traceTile / traceOnCanvas (rayphoton.js:1573-1624) at superSampleScale 0: one launch per tile,
+  // then the same fillStyle / fillRect calls per pixel that putPixel makes (:1910-1919)
+  traceTile(tile, tileSize, superSampleScale) {
+    if (superSampleScale) throw new Error('traceTile: progressive super-sample levels (scale > 0) are a presentation feature of the browser UI and are not offered');
+    const x0 = tile[0], y0 = tile[1];
+    const w = Math.min(tileSize, this.canvasWidth - x0), h = Math.min(tileSize, this.canvasHeight - y0);
+    if (w <= 0 || h <= 0) return;
+    const out = this.render(x0, y0, w, h);
+    if (this.ctx && typeof this.ctx.fillRect === 'function') {
+      for (let y = 0; y < h; y++) for (let x = 0; x < w; x++) {
+        const o = (y * w + x) * 4, p = out.post;
+        this.ctx.fillStyle = 'rgba(' + p[o] + ',' + p[o + 1] + ',' + p[o + 2] + ',' + p[o + 3] + ')';
+        this.ctx.fillRect(x0 + x, y0 + y, 1, 1);
+      }
+    }
+    return out;
+  }
+  traceOnCanvas(canvasX, canvasY, superSampleScale) { return this.traceTile([canvasX, canvasY], 1, superSampleScale); }
+
+  projectToCanvas(xyz) {                                                      // rayphoton.js:1559-1571
+    const uvw = this.camera.toUVW(xyz);
+    if (uvw[2] >= 0) return undefined;
+    const u = (-uvw[0] / uvw[2]) / this.camera.fovScaleWidth, v = (-uvw[1] / uvw[2]) / this.camera.fovScaleHeight;
+    return { x: (u + 1) * this.canvasWidth / 2 - 1, y: (-v + 1) * this.canvasHeight / 2 - 1 };
+  }
+}
+
+module.exports = Object.assign({}, S, { Scene, Ray, Photon, KdTree, PRECISION, DEFAULTS, context, addon,
+  photonsToRecords, recordsToPhotons });

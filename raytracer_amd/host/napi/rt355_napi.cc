@@ -1,0 +1,338 @@
+// N-API shim: exposes the C ABI of librt355.so (include/rt355.h) to the Node host.
+// Thin by design: argument unpacking, typed-array borrowing for the duration of a call,
+// opaque handles as napi_external with finalisers, and status -> thrown JS Error (the
+// reference's convention: `throw new Error`, kdtree.js:6, rayphoton.js:640, :1489).
+#include <node_api.h>
+#include <stdint.h>
+#include <string.h>
+#include <string>
+#include <vector>
+#include "../../../include/rt355.h"
+
+#define NAPI_OK(call)                                                  \
+  do { if ((call) != napi_ok) { napi_throw_error(env, nullptr, "N-API call failed: " #call); return nullptr; } } while (0)
+
+static napi_value fail(napi_env env, rt_ctx *ctx, int code) {
+  std::string msg = std::string(rt_last_error(ctx)) + " (rt355 status " + std::to_string(code) + ")";
+  napi_throw_error(env, std::to_string(code).c_str(), msg.c_str());
+  return nullptr;
+}
+
+struct Args {
+  napi_env env; size_t argc; napi_value argv[16];
+  Args(napi_env e, napi_callback_info info) : env(e), argc(16) { napi_get_cb_info(e, info, &argc, argv, nullptr, nullptr); }
+  bool has(size_t i) const {
+    if (i >= argc) return false;
+    napi_valuetype t; napi_typeof(env, argv[i], &t);
+    return t != napi_undefined && t != napi_null;
+  }
+  double num(size_t i, double dflt = 0) const { double v = dflt; if (has(i)) napi_get_value_double(env, argv[i], &v); return v; }
+  template <typename T> T *ext(size_t i) const { void *p = nullptr; if (has(i)) napi_get_value_external(env, argv[i], &p); return (T *)p; }
+  // typed array -> pointer + element count (borrowed for this call only)
+  void *typed(size_t i, napi_typedarray_type want, size_t *len = nullptr) const {
+    if (!has(i)) { if (len) *len = 0; return nullptr; }
+    bool is = false; napi_is_typedarray(env, argv[i], &is);
+    if (!is) { napi_throw_type_error(env, nullptr, "typed array expected"); return nullptr; }
+    napi_typedarray_type t; size_t n; void *data; napi_value ab; size_t off;
+    napi_get_typedarray_info(env, argv[i], &t, &n, &data, &ab, &off);
+    if (t != want) { napi_throw_type_error(env, nullptr, "typed array of the wrong element type"); return nullptr; }
+    if (len) *len = n;
+    return data;
+  }
+};
+
+static napi_value get_prop(napi_env env, napi_value obj, const char *name) { napi_value v; napi_get_named_property(env, obj, name, &v); return v; }
+static double prop_num(napi_env env, napi_value obj, const char *name, double dflt) {
+  bool has = false; napi_has_named_property(env, obj, name, &has);
+  if (!has) return dflt;
+  napi_value v = get_prop(env, obj, name); napi_valuetype t; napi_typeof(env, v, &t);
+  if (t != napi_number) return dflt;
+  double d; napi_get_value_double(env, v, &d); return d;
+}
+static void *prop_typed(napi_env env, napi_value obj, const char *name, napi_typedarray_type want, size_t *len) {
+  napi_value v = get_prop(env, obj, name);
+  bool is = false; napi_is_typedarray(env, v, &is);
+  if (!is) { *len = 0; return nullptr; }
+  napi_typedarray_type t; void *data; napi_value ab; size_t off;
+  napi_get_typedarray_info(env, v, &t, len, &data, &ab, &off);
+  return t == want ? data : nullptr;
+}
+
+// params object -> rt_params (missing fields keep the reference's defaults)
+static void read_params(napi_env env, napi_value o, rt_params *p) {
+  rt_default_params(p);
+  napi_valuetype t; napi_typeof(env, o, &t);
+  if (t != napi_object) return;
+  p->epsilon = prop_num(env, o, "epsilon", p->epsilon);
+  p->max_trace_dist = prop_num(env, o, "maxTraceDist", p->max_trace_dist);
+  p->max_depth = (int32_t)prop_num(env, o, "maxDepth", p->max_depth);
+  p->sub_sample = (int32_t)prop_num(env, o, "subSample", p->sub_sample);
+  p->num_photons_diffuse = (uint32_t)prop_num(env, o, "numPhotonsDiffuse", p->num_photons_diffuse);
+  p->num_photons_caustic = (uint32_t)prop_num(env, o, "numPhotonsCaustic", p->num_photons_caustic);
+  p->diffuse_radius = prop_num(env, o, "diffuseRadius", p->diffuse_radius);
+  p->caustic_radius = prop_num(env, o, "causticRadius", p->caustic_radius);
+  p->standard_lamp_area = prop_num(env, o, "standardLampArea", p->standard_lamp_area);
+  p->seed = (uint64_t)prop_num(env, o, "seed", (double)p->seed);
+  p->use_direct_light = (int32_t)prop_num(env, o, "useDirectLight", p->use_direct_light);
+  p->use_photon_maps = (int32_t)prop_num(env, o, "usePhotonMaps", p->use_photon_maps);
+  p->precision = (int32_t)prop_num(env, o, "precision", p->precision);
+  p->mode = (int32_t)prop_num(env, o, "mode", p->mode);
+  p->shadow_bias = prop_num(env, o, "shadowBias", p->shadow_bias);
+  p->epsilon_f32 = prop_num(env, o, "epsilonF32", p->epsilon_f32);
+  p->max_bounces = (int32_t)prop_num(env, o, "maxBounces", p->max_bounces);
+}
+
+static void set_num(napi_env env, napi_value obj, const char *name, double v) { napi_value n; napi_create_double(env, v, &n); napi_set_named_property(env, obj, name, n); }
+
+struct SceneBox { rt_ctx *ctx; rt_scene *scene; };
+struct MapBox { rt_ctx *ctx; rt_photon_map *map; };
+
+// init([deviceId]) -> ctx
+static napi_value Init(napi_env env, napi_callback_info info) {
+  Args a(env, info);
+  int dev = (int)a.num(0, 0);
+  rt_ctx *ctx = nullptr;
+  int rc = rt_init(&dev, 1, &ctx);
+  if (rc != RT_OK) return fail(env, nullptr, rc);
+  napi_value out;
+  // No finaliser: scenes and maps hold a pointer to their context and the GC orders nothing, so a
+  // context lives until shutdown(ctx) or process exit.
+  NAPI_OK(napi_create_external(env, ctx, nullptr, nullptr, &out));
+  return out;
+}
+
+// shutdown(ctx): only after every scene / map made from it has been dropped
+static napi_value Shutdown(napi_env env, napi_callback_info info) {
+  Args a(env, info);
+  rt_shutdown(a.ext<rt_ctx>(0));
+  return nullptr;
+}
+
+// sceneUpload(ctx, flat) -> scene      flat = what host/scene.js flatten() returns
+static napi_value SceneUpload(napi_env env, napi_callback_info info) {
+  Args a(env, info);
+  rt_ctx *ctx = a.ext<rt_ctx>(0);
+  if (!ctx || !a.has(1)) { napi_throw_type_error(env, nullptr, "sceneUpload(ctx, flat)"); return nullptr; }
+  napi_value f = a.argv[1];
+  rt_scene_desc d; memset(&d, 0, sizeof d);
+  size_t n;
+  d.n_shapes = (uint32_t)prop_num(env, f, "nShapes", 0);
+  d.shape_meta = (const uint8_t *)prop_typed(env, f, "shapeMeta", napi_uint8_array, &n);
+  d.shape_geom = (const double *)prop_typed(env, f, "shapeGeom", napi_float64_array, &n);
+  d.shape_colour = (const double *)prop_typed(env, f, "shapeColour", napi_float64_array, &n);
+  d.n_lights = (uint32_t)prop_num(env, f, "nLights", 0);
+  d.light_shape = (const uint32_t *)prop_typed(env, f, "lightShape", napi_uint32_array, &n);
+  d.light_data = (const double *)prop_typed(env, f, "lightData", napi_float64_array, &n);
+  const double *cam = (const double *)prop_typed(env, f, "camera", napi_float64_array, &n);
+  if (!cam || n < 14) { napi_throw_type_error(env, nullptr, "flat.camera must be a Float64Array(16)"); return nullptr; }
+  memcpy(d.camera, cam, sizeof(double) * (n < 16 ? n : 16));
+  d.width = (uint32_t)prop_num(env, f, "width", 0); d.height = (uint32_t)prop_num(env, f, "height", 0);
+  const double *mats = (const double *)prop_typed(env, f, "materials", napi_float64_array, &n);
+  if (!mats || n != 32) { napi_throw_type_error(env, nullptr, "flat.materials must be a Float64Array(32)"); return nullptr; }
+  memcpy(d.materials, mats, sizeof d.materials);
+  rt_scene *sc = nullptr;
+  int rc = rt_scene_upload(ctx, &d, &sc);
+  if (rc != RT_OK) return fail(env, ctx, rc);
+  SceneBox *box = new SceneBox{ ctx, sc };
+  napi_value out;
+  NAPI_OK(napi_create_external(env, box, [](napi_env, void *p, void *) { SceneBox *b = (SceneBox *)p; rt_scene_free(b->scene); delete b; }, nullptr, &out));
+  return out;
+}
+
+// intersectPairs(ctx, params, rayO, rayD, normalizeDir, shapeMeta, shapeGeom) -> Float64Array t (NaN = undefined)
+static napi_value IntersectPairs(napi_env env, napi_callback_info info) {
+  Args a(env, info);
+  rt_ctx *ctx = a.ext<rt_ctx>(0);
+  rt_params p; read_params(env, a.argv[1], &p);
+  size_t no, nd, nm, ng;
+  const double *o = (const double *)a.typed(2, napi_float64_array, &no), *d = (const double *)a.typed(3, napi_float64_array, &nd);
+  const uint8_t *meta = (const uint8_t *)a.typed(5, napi_uint8_array, &nm);
+  const double *geom = (const double *)a.typed(6, napi_float64_array, &ng);
+  if (!ctx || !o || !d || !meta || !geom) { napi_throw_type_error(env, nullptr, "intersectPairs: bad arguments"); return nullptr; }
+  uint32_t n = (uint32_t)(no / 3);
+  if (nd != no || nm != (size_t)n * 4 || ng != (size_t)n * 12) { napi_throw_range_error(env, nullptr, "intersectPairs: array sizes disagree"); return nullptr; }
+  napi_value ab, out; void *data;
+  NAPI_OK(napi_create_arraybuffer(env, (size_t)n * 8, &data, &ab));
+  NAPI_OK(napi_create_typedarray(env, napi_float64_array, n, ab, 0, &out));
+  int rc = rt_intersect_pairs(ctx, &p, n, o, d, (int)a.num(4, 0), meta, geom, (double *)data);
+  if (rc != RT_OK) return fail(env, ctx, rc);
+  return out;
+}
+
+// intersect(scene, params, mode, rayO, rayD[, sourceDist]) -> {t: Float64Array, idx: Int32Array}
+static napi_value Intersect(napi_env env, napi_callback_info info) {
+  Args a(env, info);
+  SceneBox *sb = a.ext<SceneBox>(0);
+  rt_params p; read_params(env, a.argv[1], &p);
+  size_t no, nd, ns = 0;
+  const double *o = (const double *)a.typed(3, napi_float64_array, &no), *d = (const double *)a.typed(4, napi_float64_array, &nd);
+  const double *sd = (const double *)a.typed(5, napi_float64_array, &ns);
+  if (!sb || !o || !d || no != nd) { napi_throw_type_error(env, nullptr, "intersect: bad arguments"); return nullptr; }
+  uint32_t n = (uint32_t)(no / 3);
+  if (sd && ns != n) { napi_throw_range_error(env, nullptr, "intersect: sourceDist size"); return nullptr; }
+  napi_value abt, abi, t, idx, out; void *td, *id;
+  NAPI_OK(napi_create_arraybuffer(env, (size_t)n * 8, &td, &abt)); NAPI_OK(napi_create_typedarray(env, napi_float64_array, n, abt, 0, &t));
+  NAPI_OK(napi_create_arraybuffer(env, (size_t)n * 4, &id, &abi)); NAPI_OK(napi_create_typedarray(env, napi_int32_array, n, abi, 0, &idx));
+  int rc = rt_intersect(sb->scene, &p, (int)a.num(2, 0), n, o, d, sd, (double *)td, (int32_t *)id);
+  if (rc != RT_OK) return fail(env, sb->ctx, rc);
+  NAPI_OK(napi_create_object(env, &out));
+  napi_set_named_property(env, out, "t", t); napi_set_named_property(env, out, "idx", idx);
+  return out;
+}
+
+// emitMany(scene, params) -> {diffuse: Float64Array(n*11), caustic, diffuseAttempt: Float64Array(n*2), causticAttempt, stats}
+static napi_value EmitMany(napi_env env, napi_callback_info info) {
+  Args a(env, info);
+  SceneBox *sb = a.ext<SceneBox>(0);
+  if (!sb) { napi_throw_type_error(env, nullptr, "emitMany(scene, params)"); return nullptr; }
+  rt_params p; read_params(env, a.argv[1], &p);
+  const uint32_t ND = p.num_photons_diffuse, NC = p.num_photons_caustic;
+  std::vector<double> d((size_t)ND * 11), c((size_t)NC * 11);
+  std::vector<int64_t> da((size_t)ND * 2), ca((size_t)NC * 2);
+  rt_emit_stats st;
+  int rc = rt_emit_many(sb->scene, &p, d.data(), da.data(), c.data(), ca.data(), &st);
+  if (rc != RT_OK && rc != RT_ERR_ATTEMPT_CAP) return fail(env, sb->ctx, rc);     // the cap only logs in the reference (rayphoton.js:1366)
+  napi_value out, stats; NAPI_OK(napi_create_object(env, &out)); NAPI_OK(napi_create_object(env, &stats));
+  auto f64 = [&](const char *name, const double *src, size_t n) {
+    napi_value ab, ta; void *data; napi_create_arraybuffer(env, n * 8, &data, &ab); memcpy(data, src, n * 8);
+    napi_create_typedarray(env, napi_float64_array, n, ab, 0, &ta); napi_set_named_property(env, out, name, ta);
+  };
+  f64("diffuse", d.data(), (size_t)st.n_diffuse * 11); f64("caustic", c.data(), (size_t)st.n_caustic * 11);
+  std::vector<double> tmp;
+  tmp.assign(da.begin(), da.begin() + (size_t)st.n_diffuse * 2); f64("diffuseAttempt", tmp.data(), tmp.size());
+  tmp.assign(ca.begin(), ca.begin() + (size_t)st.n_caustic * 2); f64("causticAttempt", tmp.data(), tmp.size());
+  set_num(env, stats, "attemptsPhase1", (double)st.attempts_phase1); set_num(env, stats, "attemptsPhase2", (double)st.attempts_phase2);
+  set_num(env, stats, "segments", (double)st.segments); set_num(env, stats, "nDiffuse", st.n_diffuse); set_num(env, stats, "nCaustic", st.n_caustic);
+  set_num(env, stats, "capped", st.capped); set_num(env, stats, "errors", st.errors);
+  napi_set_named_property(env, out, "stats", stats);
+  return out;
+}
+
+// photonMapBuild(ctx, rec Float64Array(n*11)) -> map
+static napi_value PhotonMapBuild(napi_env env, napi_callback_info info) {
+  Args a(env, info);
+  rt_ctx *ctx = a.ext<rt_ctx>(0);
+  size_t n = 0;
+  const double *rec = (const double *)a.typed(1, napi_float64_array, &n);
+  if (!ctx) { napi_throw_type_error(env, nullptr, "photonMapBuild(ctx, rec)"); return nullptr; }
+  rt_photon_map *m = nullptr;
+  int rc = rt_photon_map_build(ctx, rec, (uint32_t)(n / 11), &m);
+  if (rc != RT_OK) return fail(env, ctx, rc);
+  MapBox *box = new MapBox{ ctx, m };
+  napi_value out;
+  NAPI_OK(napi_create_external(env, box, [](napi_env, void *p, void *) { MapBox *b = (MapBox *)p; rt_photon_map_free(b->map); delete b; }, nullptr, &out));
+  return out;
+}
+
+// photonMapNodes(map) -> {perm: Int32Array, dim: Uint8Array}
+static napi_value PhotonMapNodes(napi_env env, napi_callback_info info) {
+  Args a(env, info);
+  MapBox *mb = a.ext<MapBox>(0);
+  if (!mb) { napi_throw_type_error(env, nullptr, "photonMapNodes(map)"); return nullptr; }
+  uint32_t n = rt_photon_map_size(mb->map);
+  napi_value abp, abd, perm, dim, out; void *pd, *dd;
+  NAPI_OK(napi_create_arraybuffer(env, (size_t)n * 4, &pd, &abp)); NAPI_OK(napi_create_typedarray(env, napi_int32_array, n, abp, 0, &perm));
+  NAPI_OK(napi_create_arraybuffer(env, n, &dd, &abd)); NAPI_OK(napi_create_typedarray(env, napi_uint8_array, n, abd, 0, &dim));
+  int rc = rt_photon_map_nodes(mb->map, (int32_t *)pd, (uint8_t *)dd);
+  if (rc != RT_OK) return fail(env, mb->ctx, rc);
+  NAPI_OK(napi_create_object(env, &out));
+  napi_set_named_property(env, out, "perm", perm); napi_set_named_property(env, out, "dim", dim);
+  return out;
+}
+
+// kdRadius(map, queries Float32Array(nq*3), r, cap) -> {count: Uint32Array, idx: Int32Array(nq*cap)}
+static napi_value KdRadius(napi_env env, napi_callback_info info) {
+  Args a(env, info);
+  MapBox *mb = a.ext<MapBox>(0);
+  size_t nq3 = 0;
+  const float *q = (const float *)a.typed(1, napi_float32_array, &nq3);
+  if (!mb || !q) { napi_throw_type_error(env, nullptr, "kdRadius(map, queries, r, cap)"); return nullptr; }
+  uint32_t nq = (uint32_t)(nq3 / 3), cap = (uint32_t)a.num(3, 64);
+  napi_value abc, abi, cnt, idx, out; void *cd, *id;
+  NAPI_OK(napi_create_arraybuffer(env, (size_t)nq * 4, &cd, &abc)); NAPI_OK(napi_create_typedarray(env, napi_uint32_array, nq, abc, 0, &cnt));
+  NAPI_OK(napi_create_arraybuffer(env, (size_t)nq * cap * 4, &id, &abi)); NAPI_OK(napi_create_typedarray(env, napi_int32_array, (size_t)nq * cap, abi, 0, &idx));
+  int rc = rt_kd_radius(mb->map, q, nq, a.num(2, 0), cap, (uint32_t *)cd, (int32_t *)id);
+  if (rc != RT_OK) return fail(env, mb->ctx, rc);
+  NAPI_OK(napi_create_object(env, &out));
+  napi_set_named_property(env, out, "count", cnt); napi_set_named_property(env, out, "idx", idx);
+  return out;
+}
+
+// kdKnn(map, queries Float32Array(nq*3), k) -> {idx: Int32Array(nq*k), d2: Float64Array(nq*k)}
+static napi_value KdKnn(napi_env env, napi_callback_info info) {
+  Args a(env, info);
+  MapBox *mb = a.ext<MapBox>(0);
+  size_t nq3 = 0;
+  const float *q = (const float *)a.typed(1, napi_float32_array, &nq3);
+  if (!mb || !q) { napi_throw_type_error(env, nullptr, "kdKnn(map, queries, k)"); return nullptr; }
+  uint32_t nq = (uint32_t)(nq3 / 3), k = (uint32_t)a.num(2, 64);
+  napi_value abi, abd, idx, d2, out; void *id, *dd;
+  NAPI_OK(napi_create_arraybuffer(env, (size_t)nq * k * 4, &id, &abi)); NAPI_OK(napi_create_typedarray(env, napi_int32_array, (size_t)nq * k, abi, 0, &idx));
+  NAPI_OK(napi_create_arraybuffer(env, (size_t)nq * k * 8, &dd, &abd)); NAPI_OK(napi_create_typedarray(env, napi_float64_array, (size_t)nq * k, abd, 0, &d2));
+  int rc = rt_kd_knn(mb->map, q, nq, k, (int32_t *)id, (double *)dd);
+  if (rc != RT_OK) return fail(env, mb->ctx, rc);
+  NAPI_OK(napi_create_object(env, &out));
+  napi_set_named_property(env, out, "idx", idx); napi_set_named_property(env, out, "d2", d2);
+  return out;
+}
+
+// gatherRadiance(map, hits Float32Array(nq*9), r, k) -> Float32Array(nq*3)
+static napi_value GatherRadiance(napi_env env, napi_callback_info info) {
+  Args a(env, info);
+  MapBox *mb = a.ext<MapBox>(0);
+  size_t n9 = 0;
+  const float *h = (const float *)a.typed(1, napi_float32_array, &n9);
+  if (!mb || !h) { napi_throw_type_error(env, nullptr, "gatherRadiance(map, hits, r, k)"); return nullptr; }
+  uint32_t nq = (uint32_t)(n9 / 9);
+  napi_value ab, out; void *data;
+  NAPI_OK(napi_create_arraybuffer(env, (size_t)nq * 12, &data, &ab)); NAPI_OK(napi_create_typedarray(env, napi_float32_array, (size_t)nq * 3, ab, 0, &out));
+  int rc = rt_gather_radiance(mb->map, h, nq, a.num(2, 0), (uint32_t)a.num(3, 0), (float *)data);
+  if (rc != RT_OK) return fail(env, mb->ctx, rc);
+  return out;
+}
+
+// traceTile(scene, params, diffuseMap|null, causticMap|null, x0, y0, w, h) -> {pre, post: Float64Array(w*h*4), rgba8: Uint8Array, stats}
+static napi_value TraceTile(napi_env env, napi_callback_info info) {
+  Args a(env, info);
+  SceneBox *sb = a.ext<SceneBox>(0);
+  if (!sb) { napi_throw_type_error(env, nullptr, "traceTile(scene, params, diffuse, caustic, x0, y0, w, h)"); return nullptr; }
+  rt_params p; read_params(env, a.argv[1], &p);
+  MapBox *md = a.ext<MapBox>(2), *mc = a.ext<MapBox>(3);
+  int x0 = (int)a.num(4), y0 = (int)a.num(5), w = (int)a.num(6), h = (int)a.num(7);
+  if (w <= 0 || h <= 0) { napi_throw_range_error(env, nullptr, "traceTile: empty tile"); return nullptr; }
+  size_t npx = (size_t)w * h;
+  napi_value ab1, ab2, ab3, pre, post, r8, out, stats; void *d1, *d2, *d3;
+  NAPI_OK(napi_create_arraybuffer(env, npx * 32, &d1, &ab1)); NAPI_OK(napi_create_typedarray(env, napi_float64_array, npx * 4, ab1, 0, &pre));
+  NAPI_OK(napi_create_arraybuffer(env, npx * 32, &d2, &ab2)); NAPI_OK(napi_create_typedarray(env, napi_float64_array, npx * 4, ab2, 0, &post));
+  NAPI_OK(napi_create_arraybuffer(env, npx * 4, &d3, &ab3)); NAPI_OK(napi_create_typedarray(env, napi_uint8_array, npx * 4, ab3, 0, &r8));
+  rt_trace_stats st;
+  int rc = rt_trace_tile(sb->scene, &p, md ? md->map : nullptr, mc ? mc->map : nullptr, x0, y0, w, h, (double *)d1, (double *)d2, (uint8_t *)d3, &st);
+  if (rc != RT_OK) return fail(env, sb->ctx, rc);
+  NAPI_OK(napi_create_object(env, &out)); NAPI_OK(napi_create_object(env, &stats));
+  napi_set_named_property(env, out, "pre", pre); napi_set_named_property(env, out, "post", post); napi_set_named_property(env, out, "rgba8", r8);
+  set_num(env, stats, "rays", (double)st.rays); set_num(env, stats, "shadowRays", (double)st.shadow_rays);
+  set_num(env, stats, "gathers", (double)st.gathers); set_num(env, stats, "bounces", (double)st.bounces);
+  napi_set_named_property(env, out, "stats", stats);
+  return out;
+}
+
+static napi_value FindMedian(napi_env env, napi_callback_info info) {
+  Args a(env, info);
+  napi_value out; napi_create_uint32(env, rt_find_median((uint32_t)a.num(0, 1)), &out);
+  return out;
+}
+
+static napi_value ModuleInit(napi_env env, napi_value exports) {
+  const struct { const char *name; napi_callback fn; } fns[] = {
+    { "init", Init }, { "shutdown", Shutdown }, { "sceneUpload", SceneUpload }, { "intersectPairs", IntersectPairs }, { "intersect", Intersect },
+    { "emitMany", EmitMany }, { "photonMapBuild", PhotonMapBuild }, { "photonMapNodes", PhotonMapNodes },
+    { "kdRadius", KdRadius }, { "kdKnn", KdKnn }, { "gatherRadiance", GatherRadiance }, { "traceTile", TraceTile },
+    { "findMedian", FindMedian },
+  };
+  for (const auto &f : fns) {
+    napi_value fn; napi_create_function(env, f.name, NAPI_AUTO_LENGTH, f.fn, nullptr, &fn);
+    napi_set_named_property(env, exports, f.name, fn);
+  }
+  return exports;
+}
+NAPI_MODULE(NODE_GYP_MODULE_NAME, ModuleInit)

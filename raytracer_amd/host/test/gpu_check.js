@@ -1,0 +1,95 @@
+'use strict';
+// GPU check of the Node host: the reference's default scene driven through Scene / KdTree / Ray
+// exactly as a caller of the reference would, compared with the fixtures the reference produced
+// (tests/golden).  Prints one line per check; exit code 0 iff all pass.
+const rt = require('..');
+const { loadBundle } = require('./bundle');
+
+let failures = 0;
+function check(name, ok, detail) { console.log(`${ok ? 'PASS' : 'FAIL'} ${name}${detail ? ' -- ' + detail : ''}`); if (!ok) failures++; }
+const same = (a, b) => a === b || (Number.isNaN(a) && Number.isNaN(b));
+
+const W = 320, H = 240;
+const filled = new Float64Array(W * H * 4).fill(NaN);
+const ctx = { width: W, height: H, fillStyle: '', fillRect(x, y) {
+  const m = /rgba\(([^,]+),([^,]+),([^,]+),([^)]+)\)/.exec(this.fillStyle);
+  for (let c = 0; c < 4; c++) filled[(y * W + x) * 4 + c] = Number(m[c + 1]);
+} };
+const log = console.log; console.log = () => {};         // the tree-build line of kdtree.js:3
+const scene = new rt.Scene(ctx, { numPhotonsDiffuse: 10000, numPhotonsCaustic: 10000, subSample: 1, seed: 12345, precision: rt.PRECISION.F64 });
+scene.loadPreset(10);
+console.log = log;
+
+// emission: attempts and stored lists
+const g = loadBundle('photons_c1');
+check('emission attempts', scene.emitStats.attemptsPhase1 === g.meta.stats.attempts1 && scene.emitStats.attemptsPhase2 === g.meta.stats.attempts2,
+  `${scene.emitStats.attemptsPhase1}/${scene.emitStats.attemptsPhase2}`);
+let worst = 0;
+for (let i = 0; i < g.diffuse.length; i++) if (!Number.isNaN(g.diffuse[i])) worst = Math.max(worst, Math.abs(scene._recD[i] - g.diffuse[i]));
+for (let i = 0; i < g.caustic.length; i++) if (!Number.isNaN(g.caustic[i])) worst = Math.max(worst, Math.abs(scene._recC[i] - g.caustic[i]));
+check('photon lists', scene._recD.length === g.diffuse.length && worst < 1e-12, `max abs diff ${worst}`);
+check('photon objects', scene.photonListDiffuse.length === 10000 && scene.photonListCaustic[0].isCaustic === true && scene.photonListDiffuse[0].origin.length === 3);
+
+// kd-tree: nodes and radius query order
+const kd = loadBundle('kd_c1');
+const nodes = scene.photonKdTDiffuse.nodes;
+let nodeOk = nodes.length === 10001;
+for (let pos = 1; pos <= 10000 && nodeOk; pos++) nodeOk = nodes[pos].dim === kd.diffuse_dim[pos - 1] && nodes[pos].photon === scene.photonKdTDiffuse.photonAt(kd.diffuse_perm[pos - 1]);
+check('KdTree.nodes', nodeOk);
+const q = loadBundle('queries_c1');
+let radiusOk = true;
+for (let i = 0; i < 64 && radiusOk; i++) {
+  const x = [q.queries[i * 3], q.queries[i * 3 + 1], q.queries[i * 3 + 2]];
+  const got = scene.photonKdTDiffuse.nearestNeighbours(x, 1.0);
+  const lo = q.diffuse_wide_offsets[i], hi = q.diffuse_wide_offsets[i + 1];
+  radiusOk = got.length === hi - lo;
+  for (let k = 0; k < got.length && radiusOk; k++) radiusOk = got[k] === scene.photonKdTDiffuse.photonAt(q.diffuse_wide_indices[lo + k]);
+}
+check('KdTree.nearestNeighbours order', radiusOk);
+let fmOk = true;
+for (let n = 1; n <= 4096 && fmOk; n++) fmOk = scene.photonKdTDiffuse.findMedian(n) === kd.find_median[n - 1];
+check('KdTree.findMedian', fmOk);
+let threw = false;
+try { new rt.KdTree([]); } catch (e) { threw = /no data/.test(e.message); }
+check('KdTree([]) throws', threw);
+
+// Ray.intersectDist on single pairs
+const ib = loadBundle('intersect');
+const names = ['plane', 'sphere', 'hemisphere', 'cylinder', 'triangle', 'square', 'disc', 'annulus'];
+let isectOk = true;
+for (let i = 0; i < ib.t.length && isectOk; i += 97) {
+  const gg = ib.shape_g.subarray(i * 12, i * 12 + 12), type = names[ib.shape_meta[i * 2]], flags = ib.shape_meta[i * 2 + 1];
+  const shape = { type, convex: !!(flags & 1), _material: 6 };
+  const v = (o) => [gg[o], gg[o + 1], gg[o + 2]];
+  if (type === 'plane') Object.assign(shape, { origin: v(0), normalDir: v(3) });
+  else if (type === 'sphere') Object.assign(shape, { centre: v(0), radius: gg[6] });
+  else if (type === 'hemisphere') Object.assign(shape, { centre: v(0), normalDir: v(3), radius: gg[6], truncateMin: gg[7], truncateMax: (flags & 4) ? gg[8] : undefined });
+  else if (type === 'cylinder') Object.assign(shape, { centre: v(0), axis: v(3), radius: gg[6], halfHeight: (flags & 8) ? gg[7] : undefined });
+  else if (type === 'triangle' || type === 'square') Object.assign(shape, { vtxA: v(0), edgeAB: v(3), edgeAC: v(6), normalDir: v(9) });
+  else if (type === 'disc') Object.assign(shape, { centre: v(0), normalDir: v(3), radius: gg[6] });
+  else Object.assign(shape, { centre: v(0), normalDir: v(3), outerRadius: gg[6], innerRadius: gg[7] });
+  const ray = new rt.Ray([ib.ray_o[i * 3], ib.ray_o[i * 3 + 1], ib.ray_o[i * 3 + 2]], [ib.ray_d_raw[i * 3], ib.ray_d_raw[i * 3 + 1], ib.ray_d_raw[i * 3 + 2]]);
+  const t = ray.intersectDist(shape);
+  isectOk = same(t === undefined ? NaN : t, ib.t[i]);
+}
+check('Ray.intersectDist', isectOk);
+
+// image: whole frame in one launch, then the tile API with fillRect
+const img = loadBundle('image_c1_modeB');
+const out = scene.render(0, 0, W, H);
+let bad = 0;
+for (let p = 0; p < W * H; p++) {
+  for (let c = 0; c < 3; c++) {
+    const a = out.pre[p * 4 + c], b = img.pre_floor[p * 4 + c];
+    if (Math.abs(a - b) / Math.max(1, Math.abs(b)) > 1e-9) { bad++; break; }
+  }
+}
+check('Scene.render radiance', bad <= 8, `${bad} of ${W * H} pixels differ, ${out.stats.rays} rays`);
+scene.traceTile([96, 64], 64, 0);
+scene.traceOnCanvas(5, 7, 0);
+let tileBad = 0;
+for (let y = 64; y < 128; y++) for (let x = 96; x < 160; x++) for (let c = 0; c < 4; c++) if (!same(filled[(y * W + x) * 4 + c], img.post_floor[(y * W + x) * 4 + c])) { tileBad++; break; }
+for (let c = 0; c < 4; c++) if (!same(filled[(7 * W + 5) * 4 + c], img.post_floor[(7 * W + 5) * 4 + c])) tileBad++;
+check('Scene.traceTile / traceOnCanvas -> fillRect', tileBad <= 2, `${tileBad} pixels differ`);
+
+process.exit(failures ? 1 : 0);
