@@ -355,3 +355,14 @@ def test_render_is_tile_and_subsample_invariant(rt):
 
 def same_px(a, b):
     return ((a == b) | (np.isnan(a) & np.isnan(b))).all(axis=-1)
+
+
+def test_sharded_protocol_on_gpu_equals_emit_many(c1_emit):
+    """the multi-GPU emission protocol (attempt sub-ranges + caps on the merged sequence), run through
+    rt_emit_photons on one GPU, reproduces rt_emit_many"""
+    from raytracer_amd import parallel
+    sc, p, whole = c1_emit
+    res = parallel.emit_sharded(parallel.GpuEngine(sc, p), 10000, 10000, batch=5000)
+    assert same(res["diffuse"], whole["diffuse"]) and same(res["caustic"], whole["caustic"])
+    assert np.array_equal(res["diffuse_attempt"], whole["diffuse_attempt"])
+    assert res["attempts1"] == whole["stats"]["attempts_phase1"] and res["attempts2"] == whole["stats"]["attempts_phase2"]
