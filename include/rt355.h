@@ -87,6 +87,7 @@ typedef struct rt_trace_stats {
   uint64_t gathers;             /* photon-map queries (one per map per opaque hit) */
   uint64_t bounces;             /* wavefront iterations */
   uint64_t stack_overflows;     /* paths whose material stack exceeded the fixed capacity */
+  uint64_t tail_rays;           /* of `rays`: segments traced by the per-lane tail kernel instead of a wavefront pass */
 } rt_trace_stats;
 
 typedef struct rt_emit_stats {

@@ -109,12 +109,20 @@ int pl_trace_tile(rt_scene *sc, const rt_params *p, DevMap md, DevMap mc, int x0
   if (!p->use_photon_maps) { md.n = 0; mc.n = 0; }
 
   RT_HIP(ctx, hipMemsetAsync(ctr, 0, sizeof(TraceCounters), ctx->stream));
-  RT_LAUNCH(ctx, "raygen", k_raygen<T>, div_up(n_paths, 256), 256, S, P, C, (uint32_t)n_paths, q_cur);
   uint64_t rays = 0, bounces = 0;
   uint32_t count = (uint32_t)n_paths;
   unsigned long long *host_count = (unsigned long long *)ctx->pinned;
+  // Wide bounces run as wavefront passes (intersect_closest, then shade with compaction); once fewer
+  // than tail_threshold paths are left, one k_tail launch follows each of them to its end.
+  const uint32_t tail_threshold = 1u << 17;
   while (count > 0) {
-    RT_LAUNCH(ctx, "intersect_closest", k_intersect_closest<T>, div_up(count, 256), 256, S, P, q_cur, count, T(C.epsilon));
+    if (bounces > 0 && count <= tail_threshold) {
+      RT_LAUNCH(ctx, "tail", k_tail<T>, div_up(count, 256), 256, S, P, C, md, mc, q_cur, count, ctr, (int)bounces);
+      bounces++;
+      break;
+    }
+    if (bounces == 0) RT_LAUNCH(ctx, "intersect_closest", (k_intersect_closest<T, true>), div_up(count, 256), 256, S, P, C, q_cur, count);
+    else RT_LAUNCH(ctx, "intersect_closest", (k_intersect_closest<T, false>), div_up(count, 256), 256, S, P, C, q_cur, count);
     RT_LAUNCH(ctx, "shade", k_shade<T>, div_up(count, 256), 256, S, P, C, md, mc, q_cur, count, q_nxt, ctr, (int)bounces);
     rays += count; bounces++;
     RT_HIP(ctx, hipMemcpyAsync(host_count, &ctr->next_count, 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -129,8 +137,8 @@ int pl_trace_tile(rt_scene *sc, const rt_params *p, DevMap md, DevMap mc, int x0
   RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
   RT_HIP(ctx, hipGetLastError());
   if (stats) {
-    stats->rays = rays; stats->bounces = bounces; stats->shadow_rays = hc.shadow_rays; stats->gathers = hc.gathers;
-    stats->stack_overflows = hc.stack_overflows;
+    stats->rays = rays + hc.tail_rays; stats->bounces = bounces; stats->shadow_rays = hc.shadow_rays; stats->gathers = hc.gathers;
+    stats->stack_overflows = hc.stack_overflows; stats->tail_rays = hc.tail_rays;
   }
   return RT_OK;
 }

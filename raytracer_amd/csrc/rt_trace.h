@@ -30,7 +30,7 @@ struct TraceCfg {
   int32_t x0, y0, w, h;
 };
 
-struct TraceCounters { unsigned long long next_count, shadow_rays, gathers, stack_overflows; };
+struct TraceCounters { unsigned long long next_count, shadow_rays, gathers, stack_overflows, tail_rays; };
 
 // Append `value` to the queue for the lanes where `keep` is true: one atomicAdd per wave.
 RT_D void wave_push(bool keep, uint32_t value, uint32_t *queue, unsigned long long *counter) {
@@ -47,11 +47,10 @@ RT_D void wave_push(bool keep, uint32_t value, uint32_t *queue, unsigned long lo
   }
 }
 
-// traceOnCanvas ray set-up (rayphoton.js:1589-1609, superSampleScale 0).  One thread per path.
+// traceOnCanvas ray set-up (rayphoton.js:1589-1609, superSampleScale 0) for path p: writes the initial
+// path state and returns the camera ray.
 template <typename T>
-__global__ void __launch_bounds__(256) k_raygen(DevScene<T> S, PathSoA<T> P, TraceCfg C, uint32_t n_paths, uint32_t *queue) {
-  uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= n_paths) return;
+RT_D void raygen_path(const DevScene<T> &S, const PathSoA<T> &P, const TraceCfg &C, uint32_t p, V3<T> &o, V3<T> &d) {
   const int SS = C.sub_sample * C.sub_sample;
   uint32_t pix = p / SS, sub = p % SS;
   int X = C.x0 + (int)(pix % C.w), Y = C.y0 + (int)(pix / C.w);
@@ -62,26 +61,28 @@ __global__ void __launch_bounds__(256) k_raygen(DevScene<T> S, PathSoA<T> P, Tra
   u *= S.camera[12]; v *= S.camera[13];
   V3<T> co = ld3(S.camera), cu = ld3(S.camera + 3), cv = ld3(S.camera + 6), cw = ld3(S.camera + 9);
   V3<T> xyz = ((co + u * cu) + v * cv) + T(-1) * cw;                    // Camera.toXYZ, rayphoton.js:712
-  V3<T> d = normalize<T>(xyz - co, T(C.epsilon));
-  P.ox[p] = co.x; P.oy[p] = co.y; P.oz[p] = co.z; P.dx[p] = d.x; P.dy[p] = d.y; P.dz[p] = d.z;
+  o = co; d = normalize<T>(xyz - co, T(C.epsilon));
+  P.ox[p] = o.x; P.oy[p] = o.y; P.oz[p] = o.z; P.dx[p] = d.x; P.dy[p] = d.y; P.dz[p] = d.z;
   P.max_dist[p] = T(C.max_trace_dist); P.importance[p] = T(1);
   P.acc_r[p] = T(0); P.acc_g[p] = T(0); P.acc_b[p] = T(0);
   P.draw[p] = rng.draw; P.depth[p] = 0;
   MatStack st; st.init(); P.stack[p] = st.bits;
-  queue[p] = p;
 }
 
 // Closest hit of every queued path against the whole scene (rayphoton.js:1642-1650).
 // This is the VALU-bound kernel: the primitive index is wave-uniform, so primitive operands
 // are scalar loads and every lane spends its cycles on the distance arithmetic.
-template <typename T>
-__global__ void __launch_bounds__(256) k_intersect_closest(DevScene<T> S, PathSoA<T> P, const uint32_t *queue, uint32_t count, T eps) {
+// PRIMARY: the queue is the identity and the ray is generated in place (no ray loads); otherwise
+// the segment left by the previous shade pass is read from the path state.
+template <typename T, bool PRIMARY>
+__global__ void __launch_bounds__(256) k_intersect_closest(DevScene<T> S, PathSoA<T> P, TraceCfg C, uint32_t *queue, uint32_t count) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= count) return;
-  uint32_t p = queue[i];
-  V3<T> o = mk<T>(P.ox[p], P.oy[p], P.oz[p]), d = mk<T>(P.dx[p], P.dy[p], P.dz[p]);
+  uint32_t p; V3<T> o, d;
+  if (PRIMARY) { p = i; queue[i] = i; raygen_path<T>(S, P, C, p, o, d); }     // also seeds the identity queue the shade pass reads
+  else { p = queue[i]; o = mk<T>(P.ox[p], P.oy[p], P.oz[p]); d = mk<T>(P.dx[p], P.dy[p], P.dz[p]); }
   T t;
-  int idx = scan_scene<T, 0>(S, o, d, eps, T(0), t);
+  int idx = scan_scene<T, 0>(S, o, d, T(C.epsilon), T(0), t);
   P.hit_t[p] = t; P.hit_idx[p] = idx;
 }
 
@@ -144,17 +145,15 @@ template <typename T> RT_D void finish_path(const PathSoA<T> &P, uint32_t p, V3<
 
 // One traceRay body per queued path (rayphoton.js:1651-1838).  A path either finishes (its
 // colour goes to P.out) or leaves a new segment in the path state and enters `next_queue`.
+struct ShadeTally { unsigned long long shadow_rays = 0, gathers = 0, overflows = 0; };
+
 template <typename T>
-__global__ void __launch_bounds__(256) k_shade(DevScene<T> S, PathSoA<T> P, TraceCfg C, DevMap Md, DevMap Mc,
-                                               const uint32_t *queue, uint32_t count, uint32_t *next_queue,
-                                               TraceCounters *ctr, int bounce) {
-  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  bool alive = false; uint32_t p = 0;
-  unsigned long long shadow_rays = 0, gathers = 0, overflows = 0;
-  if (i < count) {
-    p = queue[i];
+RT_D bool shade_body(const DevScene<T> &S, const PathSoA<T> &P, const TraceCfg &C, const DevMap &Md, const DevMap &Mc,
+                     uint32_t p, T t, int idx, int bounce, ShadeTally &tally) {
+  bool alive = false;
+  unsigned long long &shadow_rays = tally.shadow_rays, &gathers = tally.gathers, &overflows = tally.overflows;
+  {
     const T eps = T(C.epsilon);
-    const int idx = P.hit_idx[p];
     V3<T> acc = mk<T>(P.acc_r[p], P.acc_g[p], P.acc_b[p]);
     const int dword = P.depth[p];
     const int depth = dword & 0xFFFF; const bool alpha_fixed = dword & 0x10000;
@@ -166,7 +165,6 @@ __global__ void __launch_bounds__(256) k_shade(DevScene<T> S, PathSoA<T> P, Trac
       for (uint32_t k = 0; k < S.n_lights; k++) if ((int)S.light_shape[k] == idx) l = (int)k;
       finish_path<T>(P, p, acc, mk<T>(S.light_data[l][3], S.light_data[l][4], S.light_data[l][5]), S.light_data[l][6], alpha_fixed);
     } else {
-      const T t = P.hit_t[p];
       V3<T> o = mk<T>(P.ox[p], P.oy[p], P.oz[p]), d = mk<T>(P.dx[p], P.dy[p], P.dz[p]);
       const T max_dist = P.max_dist[p];
       V3<T> hit = o + t * d;
@@ -238,11 +236,57 @@ __global__ void __launch_bounds__(256) k_shade(DevScene<T> S, PathSoA<T> P, Trac
       alive = false;
     }
   }
-  wave_push(alive, p, next_queue, &ctr->next_count);
-  if (shadow_rays) atomicAdd(&ctr->shadow_rays, shadow_rays);
-  if (gathers) atomicAdd(&ctr->gathers, gathers);
-  if (overflows) atomicAdd(&ctr->stack_overflows, overflows);
+  return alive;
 }
+
+RT_D void flush_tally(const ShadeTally &t, TraceCounters *ctr) {
+  if (t.shadow_rays) atomicAdd(&ctr->shadow_rays, t.shadow_rays);
+  if (t.gathers) atomicAdd(&ctr->gathers, t.gathers);
+  if (t.overflows) atomicAdd(&ctr->stack_overflows, t.overflows);
+}
+
+// Wavefront shade pass: one traceRay body per queued path; survivors are compacted into next_queue.
+template <typename T>
+__global__ void __launch_bounds__(256) k_shade(DevScene<T> S, PathSoA<T> P, TraceCfg C, DevMap Md, DevMap Mc,
+                                               const uint32_t *queue, uint32_t count, uint32_t *next_queue,
+                                               TraceCounters *ctr, int bounce) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  bool alive = false; uint32_t p = 0;
+  ShadeTally tally;
+  if (i < count) {
+    p = queue[i];
+    alive = shade_body<T>(S, P, C, Md, Mc, p, P.hit_t[p], P.hit_idx[p], bounce, tally);
+  }
+  wave_push(alive, p, next_queue, &ctr->next_count);
+  flush_tally(tally, ctr);
+}
+
+// Tail of a frame: once few paths are left, a wavefront pass per bounce is all launch and
+// synchronisation overhead, so each remaining path is followed to its end by one lane
+// (scan + traceRay body in a loop; the loop is bounded by max_bounces).  Segments traced here are
+// counted in ctr->tail_rays.
+template <typename T>
+__global__ void __launch_bounds__(256) k_tail(DevScene<T> S, PathSoA<T> P, TraceCfg C, DevMap Md, DevMap Mc,
+                                              const uint32_t *queue, uint32_t count, TraceCounters *ctr, int bounce0) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  ShadeTally tally;
+  unsigned long long rays = 0;
+  if (i < count) {
+    const uint32_t p = queue[i];
+    bool alive = true;
+    for (int b = bounce0; alive && b < C.max_bounces; b++) {
+      V3<T> o = mk<T>(P.ox[p], P.oy[p], P.oz[p]), d = mk<T>(P.dx[p], P.dy[p], P.dz[p]);
+      T t;
+      int idx = scan_scene<T, 0>(S, o, d, T(C.epsilon), T(0), t);
+      rays++;
+      alive = shade_body<T>(S, P, C, Md, Mc, p, t, idx, b, tally);
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) rays += __shfl_down(rays, off, 64);
+  if ((threadIdx.x & 63) == 0 && rays) atomicAdd(&ctr->tail_rays, rays);
+  flush_tally(tally, ctr);
+}
+
 
 RT_D double clamp01(double x, double lo, double hi) { return (x < lo) ? lo : ((x > hi) ? hi : x); }
 
