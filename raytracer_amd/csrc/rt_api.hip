@@ -133,7 +133,7 @@ template <typename T> static int upload_typed(rt_ctx *ctx, const rt_scene_desc *
   memset(&S, 0, sizeof S);
   S.n_shapes = n; S.n_lights = d->n_lights;
   S.meta = sc->meta.as<uint8_t>(); S.geom = geom.as<T>(); S.colour = colour.as<T>(); S.sgeom = sgeom.as<T>();
-  S.sorig = sc->sorig.as<uint32_t>(); S.sflags = sc->sflags.as<uint8_t>();
+  S.sorig = sc->sorig.as<uint32_t>(); S.sflags32 = sc->sflags.as<uint32_t>();
   for (uint32_t l = 0; l < d->n_lights; l++) {
     S.light_shape[l] = d->light_shape[l];
     for (int k = 0; k < 8; k++) S.light_data[l][k] = (T)d->light_data[(size_t)l * 8 + k];
@@ -168,7 +168,7 @@ int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *d, rt_scene **out) {
   std::vector<uint32_t> order(n);
   for (uint32_t i = 0; i < n; i++) order[i] = i;
   std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return d->shape_meta[4 * a] < d->shape_meta[4 * b]; });
-  std::vector<uint8_t> sflags(n);
+  std::vector<uint32_t> sflags(n);
   uint32_t seg[RT_NUM_TYPES + 1] = { 0 };
   for (uint32_t s = 0; s < n; s++) { sflags[s] = d->shape_meta[4 * order[s] + 2]; seg[d->shape_meta[4 * order[s]] + 1]++; }
   for (int t = 0; t < RT_NUM_TYPES; t++) seg[t + 1] += seg[t];
@@ -177,7 +177,7 @@ int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *d, rt_scene **out) {
     RT_HIP(ctx, m.alloc(bytes)); RT_HIP(ctx, hipMemcpy(m.p, src, bytes, hipMemcpyHostToDevice)); return RT_OK;
   };
   if ((rc = up(sc->meta, d->shape_meta, (size_t)n * 4)) || (rc = up(sc->sorig, order.data(), (size_t)n * 4)) ||
-      (rc = up(sc->sflags, sflags.data(), n)) ||
+      (rc = up(sc->sflags, sflags.data(), (size_t)n * 4)) ||
       (rc = upload_typed<float>(ctx, d, order, sc->geom32, sc->colour32, sc->sgeom32, sc->d32, sc)) ||
       (rc = upload_typed<double>(ctx, d, order, sc->geom64, sc->colour64, sc->sgeom64, sc->d64, sc))) {
     delete sc; return rc;

@@ -1,0 +1,49 @@
+// Ordered stream compaction building blocks: per-workgroup counts -> exclusive scan of the counts by
+// one workgroup -> scatter.  Order-preserving and free of contended atomics (a single returning
+// atomic counter serialises at roughly ten nanoseconds per wave, which dominated the first
+// wavefront passes of a frame).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+// exclusive scan of n block counts by one workgroup of 1024; total goes to *total
+static __global__ void __launch_bounds__(1024) k_scan_blocks(uint32_t *block_count, uint32_t n, uint32_t *total) {
+  __shared__ uint32_t part[1024];
+  const uint32_t per = (n + 1023) / 1024;
+  const uint32_t b = threadIdx.x * per, e = (b + per < n) ? b + per : n;
+  uint32_t s = 0;
+  for (uint32_t i = b; i < e; i++) s += block_count[i];
+  part[threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t run = 0;
+    for (int i = 0; i < 1024; i++) { uint32_t v = part[i]; part[i] = run; run += v; }
+    *total = run;
+  }
+  __syncthreads();
+  uint32_t run = part[threadIdx.x];
+  for (uint32_t i = b; i < e; i++) { uint32_t v = block_count[i]; block_count[i] = run; run += v; }
+}
+
+// Inside a 256-thread workgroup: publish this wave's keep-mask and the workgroup's keep-count.
+__device__ __forceinline__ void block_publish_masks(bool keep, unsigned long long *wave_mask, uint32_t *block_count) {
+  __shared__ uint32_t cnt[4];
+  unsigned long long mask = __ballot(keep);
+  const int wv = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { wave_mask[(size_t)blockIdx.x * 4 + wv] = mask; cnt[wv] = (uint32_t)__popcll(mask); }
+  __syncthreads();
+  if (threadIdx.x == 0) block_count[blockIdx.x] = cnt[0] + cnt[1] + cnt[2] + cnt[3];
+}
+
+// next_queue[rank] = queue[i] for every kept i, rank = position among the kept items in queue order
+static __global__ void __launch_bounds__(256) k_queue_scatter(const uint32_t *queue, uint32_t count, const unsigned long long *wave_mask,
+                                                              const uint32_t *block_offset, uint32_t *next_queue) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const unsigned long long *m = wave_mask + (size_t)blockIdx.x * 4;
+  const unsigned long long mine = m[wv];
+  if (i >= count || !((mine >> lane) & 1ull)) return;
+  uint32_t rank = block_offset[blockIdx.x] + (uint32_t)__popcll(mine & (((unsigned long long)1 << lane) - 1));
+  for (int w = 0; w < wv; w++) rank += (uint32_t)__popcll(m[w]);
+  next_queue[rank] = queue[i];
+}

@@ -5,6 +5,7 @@
 // then compacted in attempt order (ballot + prefix count), which is what lets the host apply
 // the reference's list caps exactly.
 #pragma once
+#include "rt_compact.h"
 #include "rt_sample.h"
 
 struct EmitCfg {
@@ -17,9 +18,11 @@ struct EmitCounters { unsigned long long segments, errors, overflows; };
 
 #define RT_REC_STRIDE 11
 
-template <typename T>
+template <typename T, bool LDS>
 __global__ void __launch_bounds__(256) k_emit(DevScene<T> S, EmitCfg C, int phase, unsigned long long a0, uint32_t count,
                                               uint8_t *kind, T *rec, EmitCounters *ctr) {
+  extern __shared__ __align__(16) unsigned char rt_lds[];
+  const ScanSrc<T> G = LDS ? stage_scene_lds<T>(S, rt_lds) : global_scan_src<T>(S);
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   unsigned long long segments = 0, errors = 0, overflows = 0;
   if (i < count) {
@@ -33,7 +36,7 @@ __global__ void __launch_bounds__(256) k_emit(DevScene<T> S, EmitCfg C, int phas
     int depth = 0, stored = 0;
     for (;;) {
       T t; segments++;
-      int idx = scan_scene<T, 1>(S, ph.o, ph.d, eps, T(0), t);
+      int idx = scan_scene<T, 1>(S, G, ph.o, ph.d, eps, T(0), t);
       if (idx < 0) break;                                                      // left the scene
       V3<T> hit = ph.o + t * ph.d;
       V3<T> local = shape_colour<T>(S, idx, hit);
@@ -106,25 +109,6 @@ static __global__ void __launch_bounds__(256) k_compact_count(const uint8_t *kin
   if ((threadIdx.x & 63) == 0) wave_cnt[threadIdx.x >> 6] = (uint32_t)__popcll(mask);
   __syncthreads();
   if (threadIdx.x == 0) block_count[blockIdx.x] = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
-}
-
-// exclusive scan of n block counts by one workgroup; total goes to *total
-static __global__ void __launch_bounds__(1024) k_scan_blocks(uint32_t *block_count, uint32_t n, uint32_t *total) {
-  __shared__ uint32_t part[1024];
-  const uint32_t per = (n + 1023) / 1024;
-  const uint32_t b = threadIdx.x * per, e = (b + per < n) ? b + per : n;
-  uint32_t s = 0;
-  for (uint32_t i = b; i < e; i++) s += block_count[i];
-  part[threadIdx.x] = s;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    uint32_t run = 0;
-    for (int i = 0; i < 1024; i++) { uint32_t v = part[i]; part[i] = run; run += v; }
-    *total = run;
-  }
-  __syncthreads();
-  uint32_t run = part[threadIdx.x];
-  for (uint32_t i = b; i < e; i++) { uint32_t v = block_count[i]; block_count[i] = run; run += v; }
 }
 
 template <typename T>

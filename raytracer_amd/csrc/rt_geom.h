@@ -20,7 +20,7 @@ template <typename T> struct DevScene {
   const T *colour;            // n x 4, original order
   const T *sgeom;             // n x 12, type-sorted
   const uint32_t *sorig;      // sorted slot -> original index
-  const uint8_t *sflags;      // sorted slot -> flags
+  const uint32_t *sflags32;   // sorted slot -> flags
   uint32_t seg[RT_NUM_TYPES + 1];   // type t occupies sorted slots [seg[t], seg[t+1])
   uint32_t light_shape[RT_MAX_LIGHTS];
   T light_data[RT_MAX_LIGHTS][8];   // wattage area prob r g b a reserved
@@ -44,6 +44,15 @@ template <typename T> RT_D bool q_roots(T a, T halfB, T c, T &t0, T &t1) {
   return true;
 }
 
+// a == 1 (sphere, hemisphere): the divisions by a are exact and dropped
+template <typename T> RT_D bool q_roots_unit(T halfB, T c, T &t0, T &t1) {
+  T disc = halfB * halfB - c;
+  if (disc < T(0)) return false;
+  disc = rt_sqrt(disc);
+  t0 = -halfB - disc; t1 = -halfB + disc;
+  return true;
+}
+
 template <typename T> RT_D T isect_plane(V3<T> o, V3<T> d, const T *g, T eps) {           // :492-501
   V3<T> a = ld3(g), n = ld3(g + 3);
   T dn = dot(d, n);
@@ -55,7 +64,7 @@ template <typename T> RT_D T isect_sphere(V3<T> o, V3<T> d, const T *g, T eps) {
   V3<T> oc = o - ld3(g); T r = g[6], t0, t1;
   T halfB = dot(d, oc);
   T c = sqlen(oc) - r * r;
-  if (!q_roots<T>(T(1), halfB, c, t0, t1)) return miss<T>();
+  if (!q_roots_unit<T>(halfB, c, t0, t1)) return miss<T>();
   if (t0 > eps) return t0;
   if (t1 > eps) return t1;
   return miss<T>();
@@ -65,7 +74,7 @@ template <typename T> RT_D T isect_hemisphere(V3<T> o, V3<T> d, const T *g, int 
   V3<T> oc = o - c;
   T halfB = dot(d, oc);
   T cc = sqlen(oc) - r * r;
-  if (!q_roots<T>(T(1), halfB, cc, t0, t1)) return miss<T>();
+  if (!q_roots_unit<T>(halfB, cc, t0, t1)) return miss<T>();
   bool has_max = flags & RT_FLAG_TRUNC_MAX;
   if (t0 > eps) {
     T proj = dot((o + t0 * d) - c, n);
@@ -138,24 +147,45 @@ template <typename T> RT_D T isect_any_type(V3<T> o, V3<T> d, int type, int flag
   return miss<T>();
 }
 
-struct Hit { int idx; };
+// Where a scan reads the type-sorted primitives from: the scene's global arrays (the primitive index
+// is wave-uniform, so these become scalar loads) or a copy the workgroup staged in LDS.
+template <typename T> struct ScanSrc { const T *geom; const uint32_t *orig; const uint32_t *flags; };
+
+// LDS bytes needed to stage n primitives
+template <typename T> constexpr size_t scan_lds_bytes(uint32_t n) { return (size_t)n * (RT_GEOM_STRIDE * sizeof(T) + 8); }
+
+// Cooperative, coalesced copy of the type-sorted scene into LDS (all threads of the block must call it).
+template <typename T> RT_D ScanSrc<T> stage_scene_lds(const DevScene<T> &S, void *lds) {
+  T *lg = (T *)lds;
+  uint32_t *lo = (uint32_t *)(lg + (size_t)S.n_shapes * RT_GEOM_STRIDE), *lf = lo + S.n_shapes;
+  for (uint32_t i = threadIdx.x; i < S.n_shapes * RT_GEOM_STRIDE; i += blockDim.x) lg[i] = S.sgeom[i];
+  for (uint32_t i = threadIdx.x; i < S.n_shapes; i += blockDim.x) { lo[i] = S.sorig[i]; lf[i] = S.sflags32[i]; }
+  __syncthreads();
+  ScanSrc<T> G; G.geom = lg; G.orig = lo; G.flags = lf;
+  return G;
+}
+template <typename T> RT_D ScanSrc<T> global_scan_src(const DevScene<T> &S) {
+  ScanSrc<T> G; G.geom = S.sgeom; G.orig = S.sorig; G.flags = S.sflags32;
+  return G;
+}
 
 // Scan all primitives in type-sorted order.  MODE 0: closest incl. lights (rayphoton.js:1642-1650),
 // MODE 1: closest excluding lights (:1467-1475), MODE 2: any occluder closer than limit - eps
 // (:1853-1857).  The reference scans in index order and keeps the first of equal distances
 // (strict `<`), so ties go to the lowest original index here too.
-template <typename T, int MODE> RT_D int scan_scene(const DevScene<T> &S, V3<T> o, V3<T> d, T eps, T limit, T &t_out) {
+template <typename T, int MODE> RT_D int scan_scene(const DevScene<T> &S, const ScanSrc<T> &G, V3<T> o, V3<T> d, T eps, T limit, T &t_out) {
   T best = Limits<T>::inf(); int best_idx = -1;
   const T lim = (MODE == 2) ? limit - eps : T(0);
 #define RT_SCAN_LOOP(TYPE, EXPR)                                                        \
+  _Pragma("unroll 2")                                                                   \
   for (uint32_t s = S.seg[TYPE]; s < S.seg[TYPE + 1]; s++) {                            \
-    const T *g = S.sgeom + (size_t)s * RT_GEOM_STRIDE;                                  \
-    const int flags = S.sflags[s]; (void)flags;                                         \
+    const T *g = G.geom + (size_t)s * RT_GEOM_STRIDE;                                   \
+    const int flags = (int)G.flags[s]; (void)flags;                                     \
     T t = EXPR;                                                                         \
     if (MODE != 0 && (flags & RT_FLAG_LIGHT)) continue;                                 \
     if (MODE == 2) { if (t > eps && t < lim) { t_out = t; return 1; } }                 \
     else {                                                                              \
-      int orig = (int)S.sorig[s];                                                       \
+      int orig = (int)G.orig[s];                                                        \
       if (t > eps && (t < best || (t == best && orig < best_idx))) { best = t; best_idx = orig; } \
     }                                                                                   \
   }

@@ -72,6 +72,12 @@ struct KernelTimer {
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, (ctx)->stream, __VA_ARGS__);        \
   } while (0)
 
+#define RT_LAUNCH_SMEM(ctx, name, kernel, grid, block, smem, ...)                              \
+  do {                                                                                         \
+    KernelTimer timer_((ctx), (name));                                                         \
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), (smem), (ctx)->stream, __VA_ARGS__);   \
+  } while (0)
+
 static inline uint32_t div_up(uint64_t a, uint32_t b) { return (uint32_t)((a + b - 1) / b); }
 
 // ---- scene ----
@@ -80,7 +86,7 @@ struct rt_scene {
   DevMem meta, geom32, geom64, colour32, colour64, sgeom32, sgeom64, sorig, sflags;
   DevScene<float> d32; DevScene<double> d64;
   // per-scene workspaces (grow-only) so that steady-state calls do not allocate
-  DevMem ws_paths, ws_queue, ws_ctr, ws_emit_kind, ws_emit_rec, ws_emit_blocks, ws_misc;
+  DevMem ws_paths, ws_queue, ws_ctr, ws_masks, ws_blocks, ws_emit_kind, ws_emit_rec, ws_emit_blocks, ws_misc;
 };
 
 // ---- photon map ----

@@ -11,6 +11,10 @@ template <typename T> static double working_eps(const rt_params *p) {
   return p->epsilon_f32 > 0 ? p->epsilon_f32 : 1e-4;
 }
 
+// Scenes of up to this many primitives are staged whole in LDS by every workgroup (<= 56 KB); larger
+// scenes read the primitives through wave-uniform (scalar) loads from global memory.
+template <typename T> static bool scene_fits_lds(uint32_t n) { return scan_lds_bytes<T>(n) <= 56 * 1024; }
+
 template <typename T> struct SceneOf;
 template <> struct SceneOf<float> { static DevScene<float> &get(rt_scene *s) { return s->d32; } };
 template <> struct SceneOf<double> { static DevScene<double> &get(rt_scene *s) { return s->d64; } };
@@ -38,7 +42,7 @@ __global__ void __launch_bounds__(256) k_scan_rays(DevScene<T> S, uint32_t n, co
   V3<T> ro = mk<T>(T(o[3 * i]), T(o[3 * i + 1]), T(o[3 * i + 2]));
   V3<T> rd = mk<T>(T(d[3 * i]), T(d[3 * i + 1]), T(d[3 * i + 2]));
   T t = Limits<T>::inf();
-  int idx = scan_scene<T, MODE>(S, ro, rd, eps, MODE == 2 ? T(source_dist[i]) : T(0), t);
+  int idx = scan_scene<T, MODE>(S, global_scan_src<T>(S), ro, rd, eps, MODE == 2 ? T(source_dist[i]) : T(0), t);
   idx_out[i] = idx;
   if (t_out) t_out[i] = (MODE == 2) ? 0.0 : (double)t;
 }
@@ -111,24 +115,41 @@ int pl_trace_tile(rt_scene *sc, const rt_params *p, DevMap md, DevMap mc, int x0
   RT_HIP(ctx, hipMemsetAsync(ctr, 0, sizeof(TraceCounters), ctx->stream));
   uint64_t rays = 0, bounces = 0;
   uint32_t count = (uint32_t)n_paths;
-  unsigned long long *host_count = (unsigned long long *)ctx->pinned;
-  // Wide bounces run as wavefront passes (intersect_closest, then shade with compaction); once fewer
-  // than tail_threshold paths are left, one k_tail launch follows each of them to its end.
+  const uint32_t max_blocks = div_up(n_paths, 256);
+  RT_HIP(ctx, sc->ws_masks.reserve((size_t)max_blocks * 4 * 8));
+  RT_HIP(ctx, sc->ws_blocks.reserve(((size_t)max_blocks + 1) * 4));
+  unsigned long long *wave_mask = sc->ws_masks.as<unsigned long long>();
+  uint32_t *block_count = sc->ws_blocks.as<uint32_t>();
+  const bool lds = scene_fits_lds<T>(S.n_shapes);
+  const size_t smem = lds ? scan_lds_bytes<T>(S.n_shapes) : 0;
+  // Wide bounces run as wavefront passes (intersect_closest, shade, ordered compaction of the survivors);
+  // once fewer than tail_threshold paths are left, one k_tail launch follows each of them to its end.
   const uint32_t tail_threshold = 1u << 17;
   while (count > 0) {
+    const uint32_t blocks = div_up(count, 256);
     if (bounces > 0 && count <= tail_threshold) {
-      RT_LAUNCH(ctx, "tail", k_tail<T>, div_up(count, 256), 256, S, P, C, md, mc, q_cur, count, ctr, (int)bounces);
+      if (lds) RT_LAUNCH_SMEM(ctx, "tail", (k_tail<T, true>), blocks, 256, smem, S, P, C, md, mc, q_cur, count, ctr, (int)bounces);
+      else RT_LAUNCH_SMEM(ctx, "tail", (k_tail<T, false>), blocks, 256, 0, S, P, C, md, mc, q_cur, count, ctr, (int)bounces);
       bounces++;
       break;
     }
-    if (bounces == 0) RT_LAUNCH(ctx, "intersect_closest", (k_intersect_closest<T, true>), div_up(count, 256), 256, S, P, C, q_cur, count);
-    else RT_LAUNCH(ctx, "intersect_closest", (k_intersect_closest<T, false>), div_up(count, 256), 256, S, P, C, q_cur, count);
-    RT_LAUNCH(ctx, "shade", k_shade<T>, div_up(count, 256), 256, S, P, C, md, mc, q_cur, count, q_nxt, ctr, (int)bounces);
+    if (bounces == 0) {
+      if (lds) RT_LAUNCH_SMEM(ctx, "intersect_closest", (k_intersect_closest<T, true, true>), blocks, 256, smem, S, P, C, q_cur, count);
+      else RT_LAUNCH_SMEM(ctx, "intersect_closest", (k_intersect_closest<T, true, false>), blocks, 256, 0, S, P, C, q_cur, count);
+    } else {
+      if (lds) RT_LAUNCH_SMEM(ctx, "intersect_closest", (k_intersect_closest<T, false, true>), blocks, 256, smem, S, P, C, q_cur, count);
+      else RT_LAUNCH_SMEM(ctx, "intersect_closest", (k_intersect_closest<T, false, false>), blocks, 256, 0, S, P, C, q_cur, count);
+    }
+    if (lds && C.use_direct_light)      // only the shadow-ray scans of directLight read primitives in this pass
+      RT_LAUNCH_SMEM(ctx, "shade", (k_shade<T, true>), blocks, 256, smem, S, P, C, md, mc, q_cur, count, wave_mask, block_count, ctr, (int)bounces);
+    else
+      RT_LAUNCH_SMEM(ctx, "shade", (k_shade<T, false>), blocks, 256, 0, S, P, C, md, mc, q_cur, count, wave_mask, block_count, ctr, (int)bounces);
+    RT_LAUNCH(ctx, "queue_scan", k_scan_blocks, 1, 1024, block_count, blocks, block_count + blocks);
+    RT_LAUNCH(ctx, "queue_scatter", k_queue_scatter, blocks, 256, q_cur, count, wave_mask, block_count, q_nxt);
     rays += count; bounces++;
-    RT_HIP(ctx, hipMemcpyAsync(host_count, &ctr->next_count, 8, hipMemcpyDeviceToHost, ctx->stream));
-    RT_HIP(ctx, hipMemsetAsync(&ctr->next_count, 0, 8, ctx->stream));
+    RT_HIP(ctx, hipMemcpyAsync(ctx->pinned, block_count + blocks, 4, hipMemcpyDeviceToHost, ctx->stream));
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    count = (uint32_t)*host_count;
+    count = ctx->pinned[0];
     std::swap(q_cur, q_nxt);
   }
   RT_LAUNCH(ctx, "resolve", k_resolve<T>, div_up(n_pixels, 256), 256, P, (int)n_pixels, (int)p->sub_sample, pre, post, rgba8);
@@ -153,8 +174,12 @@ int pl_emit_batch(rt_scene *sc, const rt_params *p, int phase, uint64_t a0, uint
   if (!sc->ws_misc.p) { RT_HIP(ctx, sc->ws_misc.alloc(256)); RT_HIP(ctx, hipMemsetAsync(sc->ws_misc.p, 0, 256, ctx->stream)); }
   EmitCfg C; C.epsilon = working_eps<T>(p); C.max_depth = p->max_depth; C.num_diffuse = p->num_photons_diffuse;
   C.num_caustic = p->num_photons_caustic; C.seed = p->seed;
-  RT_LAUNCH(ctx, "photon_emit_bounce", k_emit<T>, div_up(count, 256), 256, S, C, phase, (unsigned long long)a0, count,
-            sc->ws_emit_kind.as<uint8_t>(), sc->ws_emit_rec.as<T>(), sc->ws_misc.as<EmitCounters>());
+  if (scene_fits_lds<T>(S.n_shapes))
+    RT_LAUNCH_SMEM(ctx, "photon_emit_bounce", (k_emit<T, true>), div_up(count, 256), 256, scan_lds_bytes<T>(S.n_shapes), S, C, phase,
+                   (unsigned long long)a0, count, sc->ws_emit_kind.as<uint8_t>(), sc->ws_emit_rec.as<T>(), sc->ws_misc.as<EmitCounters>());
+  else
+    RT_LAUNCH_SMEM(ctx, "photon_emit_bounce", (k_emit<T, false>), div_up(count, 256), 256, 0, S, C, phase,
+                   (unsigned long long)a0, count, sc->ws_emit_kind.as<uint8_t>(), sc->ws_emit_rec.as<T>(), sc->ws_misc.as<EmitCounters>());
   RT_HIP(ctx, hipGetLastError());
   return RT_OK;
 }

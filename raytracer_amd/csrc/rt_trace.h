@@ -8,6 +8,7 @@
 // path is a loop that accumulates the local terms of its opaque hits and ends with the
 // colour of the event that terminates it.
 #pragma once
+#include "rt_compact.h"
 #include "rt_geom.h"
 #include "rt_kdq.h"
 #include "rt_sample.h"
@@ -31,21 +32,6 @@ struct TraceCfg {
 };
 
 struct TraceCounters { unsigned long long next_count, shadow_rays, gathers, stack_overflows, tail_rays; };
-
-// Append `value` to the queue for the lanes where `keep` is true: one atomicAdd per wave.
-RT_D void wave_push(bool keep, uint32_t value, uint32_t *queue, unsigned long long *counter) {
-  unsigned long long mask = __ballot(keep);
-  if (mask == 0) return;
-  int lane = threadIdx.x & 63;
-  int leader = __ffsll((long long)mask) - 1;
-  unsigned long long base = 0;
-  if (lane == leader) base = atomicAdd(counter, (unsigned long long)__popcll(mask));
-  base = __shfl(base, leader, 64);
-  if (keep) {
-    unsigned long long below = mask & (((unsigned long long)1 << lane) - 1);
-    queue[base + __popcll(below)] = value;
-  }
-}
 
 // traceOnCanvas ray set-up (rayphoton.js:1589-1609, superSampleScale 0) for path p: writes the initial
 // path state and returns the camera ray.
@@ -74,22 +60,24 @@ RT_D void raygen_path(const DevScene<T> &S, const PathSoA<T> &P, const TraceCfg 
 // are scalar loads and every lane spends its cycles on the distance arithmetic.
 // PRIMARY: the queue is the identity and the ray is generated in place (no ray loads); otherwise
 // the segment left by the previous shade pass is read from the path state.
-template <typename T, bool PRIMARY>
+template <typename T, bool PRIMARY, bool LDS>
 __global__ void __launch_bounds__(256) k_intersect_closest(DevScene<T> S, PathSoA<T> P, TraceCfg C, uint32_t *queue, uint32_t count) {
+  extern __shared__ __align__(16) unsigned char rt_lds[];
+  const ScanSrc<T> G = LDS ? stage_scene_lds<T>(S, rt_lds) : global_scan_src<T>(S);
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= count) return;
   uint32_t p; V3<T> o, d;
   if (PRIMARY) { p = i; queue[i] = i; raygen_path<T>(S, P, C, p, o, d); }     // also seeds the identity queue the shade pass reads
   else { p = queue[i]; o = mk<T>(P.ox[p], P.oy[p], P.oz[p]); d = mk<T>(P.dx[p], P.dy[p], P.dz[p]); }
   T t;
-  int idx = scan_scene<T, 0>(S, o, d, T(C.epsilon), T(0), t);
+  int idx = scan_scene<T, 0>(S, G, o, d, T(C.epsilon), T(0), t);
   P.hit_t[p] = t; P.hit_idx[p] = idx;
 }
 
 // directLight (rayphoton.js:1841-1880): per light one createPhoton() of a RANDOM light, scaled by
 // THIS light's area; an unclamped cosine; floor at the end.
 template <typename T>
-RT_D V3<T> direct_light(const DevScene<T> &S, const TraceCfg &C, V3<T> point, V3<T> normal, V3<T> local, RngStream &rng,
+RT_D V3<T> direct_light(const DevScene<T> &S, const ScanSrc<T> &G, const TraceCfg &C, V3<T> point, V3<T> normal, V3<T> local, RngStream &rng,
                         unsigned long long &shadow_rays) {
   const T eps = T(C.epsilon);
   V3<T> col = mk<T>(0, 0, 0);
@@ -100,7 +88,7 @@ RT_D V3<T> direct_light(const DevScene<T> &S, const TraceCfg &C, V3<T> point, V3
     T source_dist = rt_sqrt(sqlen(point - ph.o));
     T thit;
     shadow_rays++;
-    if (!scan_scene<T, 2>(S, point, dir, eps, source_dist, thit)) {
+    if (!scan_scene<T, 2>(S, G, point, dir, eps, source_dist, thit)) {
       T dn = dot(dir, normal);
       T k = T(C.standard_lamp_area);
       col.x += (ph.r / T(255)) * local.x * dn * power / k;
@@ -148,7 +136,7 @@ template <typename T> RT_D void finish_path(const PathSoA<T> &P, uint32_t p, V3<
 struct ShadeTally { unsigned long long shadow_rays = 0, gathers = 0, overflows = 0; };
 
 template <typename T>
-RT_D bool shade_body(const DevScene<T> &S, const PathSoA<T> &P, const TraceCfg &C, const DevMap &Md, const DevMap &Mc,
+RT_D bool shade_body(const DevScene<T> &S, const ScanSrc<T> &G, const PathSoA<T> &P, const TraceCfg &C, const DevMap &Md, const DevMap &Mc,
                      uint32_t p, T t, int idx, int bounce, ShadeTally &tally) {
   bool alive = false;
   unsigned long long &shadow_rays = tally.shadow_rays, &gathers = tally.gathers, &overflows = tally.overflows;
@@ -200,7 +188,7 @@ RT_D bool shade_body(const DevScene<T> &S, const PathSoA<T> &P, const TraceCfg &
           V3<T> direct = ZERO;
           if (refl < T(1) && C.use_direct_light) {
             const T bias = T(C.shadow_bias);
-            direct = direct_light<T>(S, C, hit + bias * n, n, local, rng, shadow_rays);          // :1750-1752
+            direct = direct_light<T>(S, G, C, hit + bias * n, n, local, rng, shadow_rays);          // :1750-1752
           }
           bool spec = false;
           if (rng.next_k() < (has_mat ? S.refl_k[mat] : 0u)) spec = rng.next_k() < S.spec_k[mat];   // :1753, short-circuit
@@ -245,19 +233,22 @@ RT_D void flush_tally(const ShadeTally &t, TraceCounters *ctr) {
   if (t.overflows) atomicAdd(&ctr->stack_overflows, t.overflows);
 }
 
-// Wavefront shade pass: one traceRay body per queued path; survivors are compacted into next_queue.
-template <typename T>
+// Wavefront shade pass: one traceRay body per queued path.  Survivors are recorded as one keep-mask per
+// wave plus one count per workgroup; k_scan_blocks and k_queue_scatter then build the next queue in order.
+template <typename T, bool LDS>
 __global__ void __launch_bounds__(256) k_shade(DevScene<T> S, PathSoA<T> P, TraceCfg C, DevMap Md, DevMap Mc,
-                                               const uint32_t *queue, uint32_t count, uint32_t *next_queue,
-                                               TraceCounters *ctr, int bounce) {
+                                               const uint32_t *queue, uint32_t count, unsigned long long *wave_mask,
+                                               uint32_t *block_count, TraceCounters *ctr, int bounce) {
+  extern __shared__ __align__(16) unsigned char rt_lds[];
+  const ScanSrc<T> G = LDS ? stage_scene_lds<T>(S, rt_lds) : global_scan_src<T>(S);
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  bool alive = false; uint32_t p = 0;
+  bool alive = false;
   ShadeTally tally;
   if (i < count) {
-    p = queue[i];
-    alive = shade_body<T>(S, P, C, Md, Mc, p, P.hit_t[p], P.hit_idx[p], bounce, tally);
+    const uint32_t p = queue[i];
+    alive = shade_body<T>(S, G, P, C, Md, Mc, p, P.hit_t[p], P.hit_idx[p], bounce, tally);
   }
-  wave_push(alive, p, next_queue, &ctr->next_count);
+  block_publish_masks(alive, wave_mask, block_count);
   flush_tally(tally, ctr);
 }
 
@@ -265,9 +256,11 @@ __global__ void __launch_bounds__(256) k_shade(DevScene<T> S, PathSoA<T> P, Trac
 // synchronisation overhead, so each remaining path is followed to its end by one lane
 // (scan + traceRay body in a loop; the loop is bounded by max_bounces).  Segments traced here are
 // counted in ctr->tail_rays.
-template <typename T>
+template <typename T, bool LDS>
 __global__ void __launch_bounds__(256) k_tail(DevScene<T> S, PathSoA<T> P, TraceCfg C, DevMap Md, DevMap Mc,
                                               const uint32_t *queue, uint32_t count, TraceCounters *ctr, int bounce0) {
+  extern __shared__ __align__(16) unsigned char rt_lds[];
+  const ScanSrc<T> G = LDS ? stage_scene_lds<T>(S, rt_lds) : global_scan_src<T>(S);
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   ShadeTally tally;
   unsigned long long rays = 0;
@@ -277,9 +270,9 @@ __global__ void __launch_bounds__(256) k_tail(DevScene<T> S, PathSoA<T> P, Trace
     for (int b = bounce0; alive && b < C.max_bounces; b++) {
       V3<T> o = mk<T>(P.ox[p], P.oy[p], P.oz[p]), d = mk<T>(P.dx[p], P.dy[p], P.dz[p]);
       T t;
-      int idx = scan_scene<T, 0>(S, o, d, T(C.epsilon), T(0), t);
+      int idx = scan_scene<T, 0>(S, G, o, d, T(C.epsilon), T(0), t);
       rays++;
-      alive = shade_body<T>(S, P, C, Md, Mc, p, t, idx, b, tally);
+      alive = shade_body<T>(S, G, P, C, Md, Mc, p, t, idx, b, tally);
     }
   }
   for (int off = 32; off > 0; off >>= 1) rays += __shfl_down(rays, off, 64);
