@@ -92,7 +92,8 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    ctx.profile_enable(True)
+    ctx.profile_enable(os.environ.get("RT355_BENCH_NO_EVENTS") is None)
+    ctx.profile_select(None if os.environ.get("RT355_BENCH_ALL_EVENTS") else "intersect_closest")   # time the roofline kernel only
     ctx.profile_reset()
     barrier()
     t0 = time.perf_counter()
@@ -137,6 +138,7 @@ def main():
         build_s = time.perf_counter() - tb
         pm.gather(hits, k=args.knn, out=rgb)                               # warm-up
         ctx.profile_enable(True)
+        ctx.profile_select("gather_knn")
         ctx.profile_reset()
         gsteps = max(2, min(args.steps, 5))
         barrier()
@@ -161,7 +163,7 @@ def main():
 
     if rank == 0:
         fl = flop_per_ray_pass(flat)
-        achieved = (wave_rays / args.steps) * fl / ((k_ms / args.steps) * 1e-3) / 1e12     # TFLOP/s while the kernel runs
+        achieved = (wave_rays / args.steps) * fl / ((max(k_ms, 1e-9) / args.steps) * 1e-3) / 1e12     # TFLOP/s while the kernel runs
         line = {
             "metric": "Mrays/s (primary+secondary)", "value": rays_total / t_total / 1e6, "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": t_total / args.steps * 1e3,

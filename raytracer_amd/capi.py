@@ -21,7 +21,7 @@ SCAN_CLOSEST, SCAN_CLOSEST_NOLIGHT, SCAN_ANY = 0, 1, 2
 
 EXPORTS = [
     "rt_default_params", "rt_init", "rt_shutdown", "rt_last_error", "rt_stream", "rt_synchronize",
-    "rt_profile_enable", "rt_profile_reset", "rt_profile_get", "rt_scene_upload", "rt_scene_free",
+    "rt_profile_enable", "rt_profile_select", "rt_profile_reset", "rt_profile_get", "rt_scene_upload", "rt_scene_free",
     "rt_intersect_pairs", "rt_intersect", "rt_emit_photons", "rt_emit_many", "rt_photon_map_build",
     "rt_photon_map_free", "rt_photon_map_size", "rt_photon_map_nodes", "rt_kd_build", "rt_find_median",
     "rt_kd_radius", "rt_kd_knn", "rt_gather_radiance", "rt_trace_tile",
@@ -145,6 +145,9 @@ class Context:
     # -- profiling
     def profile_enable(self, on=True):
         self.check(self.lib.rt_profile_enable(self.h, int(on)))
+
+    def profile_select(self, kernel=None):
+        self.check(self.lib.rt_profile_select(self.h, kernel.encode() if kernel else None))
 
     def profile_reset(self):
         self.check(self.lib.rt_profile_reset(self.h))

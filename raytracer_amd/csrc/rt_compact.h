@@ -6,22 +6,26 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-// exclusive scan of n block counts by one workgroup of 1024; total goes to *total
-static __global__ void __launch_bounds__(1024) k_scan_blocks(uint32_t *block_count, uint32_t n, uint32_t *total) {
-  __shared__ uint32_t part[1024];
+// exclusive scan of n block counts by one workgroup of 1024; total goes to *total.
+// item_count (may be null): device-side number of items; when given, n = ceil(*item_count / 256).
+// Each thread owns a contiguous run of counts; run sums are scanned with wave shuffles.
+static __global__ void __launch_bounds__(1024) k_scan_blocks(uint32_t *block_count, uint32_t n, uint32_t *total,
+                                                             const uint32_t *item_count = nullptr) {
+  __shared__ uint32_t wave_sum[16];
+  if (item_count) n = (*item_count + 255u) / 256u;
   const uint32_t per = (n + 1023) / 1024;
   const uint32_t b = threadIdx.x * per, e = (b + per < n) ? b + per : n;
   uint32_t s = 0;
   for (uint32_t i = b; i < e; i++) s += block_count[i];
-  part[threadIdx.x] = s;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  uint32_t incl = s;                                      // inclusive scan inside the wave
+  for (int off = 1; off < 64; off <<= 1) { uint32_t v = __shfl_up(incl, off, 64); if (lane >= off) incl += v; }
+  if (lane == 63) wave_sum[wv] = incl;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    uint32_t run = 0;
-    for (int i = 0; i < 1024; i++) { uint32_t v = part[i]; part[i] = run; run += v; }
-    *total = run;
-  }
-  __syncthreads();
-  uint32_t run = part[threadIdx.x];
+  uint32_t base = 0;
+  for (int w = 0; w < wv; w++) base += wave_sum[w];
+  if (threadIdx.x == 1023) *total = base + incl;
+  uint32_t run = base + incl - s;
   for (uint32_t i = b; i < e; i++) { uint32_t v = block_count[i]; block_count[i] = run; run += v; }
 }
 
@@ -36,8 +40,10 @@ __device__ __forceinline__ void block_publish_masks(bool keep, unsigned long lon
 }
 
 // next_queue[rank] = queue[i] for every kept i, rank = position among the kept items in queue order
-static __global__ void __launch_bounds__(256) k_queue_scatter(const uint32_t *queue, uint32_t count, const unsigned long long *wave_mask,
+static __global__ void __launch_bounds__(256) k_queue_scatter(const uint32_t *queue, const uint32_t *count_ptr, const unsigned long long *wave_mask,
                                                               const uint32_t *block_offset, uint32_t *next_queue) {
+  const uint32_t count = *count_ptr;
+  if (blockIdx.x * blockDim.x >= count) return;
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const unsigned long long *m = wave_mask + (size_t)blockIdx.x * 4;
@@ -45,5 +51,5 @@ static __global__ void __launch_bounds__(256) k_queue_scatter(const uint32_t *qu
   if (i >= count || !((mine >> lane) & 1ull)) return;
   uint32_t rank = block_offset[blockIdx.x] + (uint32_t)__popcll(mine & (((unsigned long long)1 << lane) - 1));
   for (int w = 0; w < wv; w++) rank += (uint32_t)__popcll(m[w]);
-  next_queue[rank] = queue[i];
+  if (rank < count) next_queue[rank] = queue[i];          // (always true: the kept items are a subset of the queue)
 }

@@ -4,6 +4,7 @@
 #include "rt_emit.h"
 #include "rt_pipeline.h"
 #include "rt_trace.h"
+#include <stdlib.h>
 
 // working epsilon of a precision: the reference's EPSILON for fp64, the coarser epsilon_f32 for fp32
 template <typename T> static double working_eps(const rt_params *p) {
@@ -109,56 +110,72 @@ int pl_trace_tile(rt_scene *sc, const rt_params *p, DevMap md, DevMap mc, int x0
   C.shadow_bias = p->shadow_bias > 0 ? p->shadow_bias : C.epsilon;
   C.max_depth = p->max_depth; C.sub_sample = p->sub_sample; C.use_direct_light = p->use_direct_light;
   C.use_photon_maps = p->use_photon_maps; C.max_bounces = p->max_bounces > 0 ? p->max_bounces : 64;
-  C.seed = p->seed; C.x0 = x0; C.y0 = y0; C.w = w; C.h = h;
+  C.seed = p->seed; C.x0 = x0; C.y0 = y0; C.w = w; C.h = h; C.n_paths = (uint32_t)n_paths;
   if (!p->use_photon_maps) { md.n = 0; mc.n = 0; }
 
   RT_HIP(ctx, hipMemsetAsync(ctr, 0, sizeof(TraceCounters), ctx->stream));
-  uint64_t rays = 0, bounces = 0;
-  uint32_t count = (uint32_t)n_paths;
   const uint32_t max_blocks = div_up(n_paths, 256);
   RT_HIP(ctx, sc->ws_masks.reserve((size_t)max_blocks * 4 * 8));
   RT_HIP(ctx, sc->ws_blocks.reserve(((size_t)max_blocks + 1) * 4));
   unsigned long long *wave_mask = sc->ws_masks.as<unsigned long long>();
   uint32_t *block_count = sc->ws_blocks.as<uint32_t>();
+  uint32_t *counts = ctr->counts;                           // counts[b] = queue length of wavefront pass b (device side)
   const bool lds = scene_fits_lds<T>(S.n_shapes);
   const size_t smem = lds ? scan_lds_bytes<T>(S.n_shapes) : 0;
   // Wide bounces run as wavefront passes (intersect_closest, shade, ordered compaction of the survivors);
-  // once fewer than tail_threshold paths are left, one k_tail launch follows each of them to its end.
-  const uint32_t tail_threshold = 1u << 17;
-  while (count > 0) {
-    const uint32_t blocks = div_up(count, 256);
-    if (bounces > 0 && count <= tail_threshold) {
-      if (lds) RT_LAUNCH_SMEM(ctx, "tail", (k_tail<T, true>), blocks, 256, smem, S, P, C, md, mc, q_cur, count, ctr, (int)bounces);
-      else RT_LAUNCH_SMEM(ctx, "tail", (k_tail<T, false>), blocks, 256, 0, S, P, C, md, mc, q_cur, count, ctr, (int)bounces);
-      bounces++;
+  // once at most tail_threshold paths are left, one k_tail launch follows each of them to its end.
+  // Queue lengths live on the device; a launch's grid is only an upper bound, so the host reads a
+  // length back only when it needs one to choose the next step (never for tiles <= tail_threshold).
+  uint32_t tail_threshold = 1u << 17;
+  if (const char *e = getenv("RT355_TAIL_THRESHOLD")) tail_threshold = (uint32_t)strtoul(e, nullptr, 10);
+  uint32_t ub = (uint32_t)n_paths;                          // upper bound of the current queue length
+  bool ub_exact = true;
+  uint32_t wave_bounces = 0;
+  for (;;) {
+    const uint32_t blocks = div_up(ub, 256);
+    uint32_t *cnt = counts + wave_bounces;
+    if ((wave_bounces > 0 && ub <= tail_threshold) || wave_bounces >= RT_MAX_WAVE_BOUNCES) {
+      const uint32_t tblocks = div_up(ub, RT_TAIL_THREADS);
+      if (lds) RT_LAUNCH_SMEM(ctx, "tail", (k_tail<T, true>), tblocks, RT_TAIL_THREADS, smem, S, P, C, md, mc, q_cur, cnt, ctr, (int)wave_bounces);
+      else RT_LAUNCH_SMEM(ctx, "tail", (k_tail<T, false>), tblocks, RT_TAIL_THREADS, 0, S, P, C, md, mc, q_cur, cnt, ctr, (int)wave_bounces);
       break;
     }
-    if (bounces == 0) {
-      if (lds) RT_LAUNCH_SMEM(ctx, "intersect_closest", (k_intersect_closest<T, true, true>), blocks, 256, smem, S, P, C, q_cur, count);
-      else RT_LAUNCH_SMEM(ctx, "intersect_closest", (k_intersect_closest<T, true, false>), blocks, 256, 0, S, P, C, q_cur, count);
+    if (wave_bounces == 0) {
+      if (lds) RT_LAUNCH_SMEM(ctx, "intersect_closest", (k_intersect_closest<T, true, true>), blocks, 256, smem, S, P, C, q_cur, cnt);
+      else RT_LAUNCH_SMEM(ctx, "intersect_closest", (k_intersect_closest<T, true, false>), blocks, 256, 0, S, P, C, q_cur, cnt);
     } else {
-      if (lds) RT_LAUNCH_SMEM(ctx, "intersect_closest", (k_intersect_closest<T, false, true>), blocks, 256, smem, S, P, C, q_cur, count);
-      else RT_LAUNCH_SMEM(ctx, "intersect_closest", (k_intersect_closest<T, false, false>), blocks, 256, 0, S, P, C, q_cur, count);
+      if (lds) RT_LAUNCH_SMEM(ctx, "intersect_closest", (k_intersect_closest<T, false, true>), blocks, 256, smem, S, P, C, q_cur, cnt);
+      else RT_LAUNCH_SMEM(ctx, "intersect_closest", (k_intersect_closest<T, false, false>), blocks, 256, 0, S, P, C, q_cur, cnt);
     }
     if (lds && C.use_direct_light)      // only the shadow-ray scans of directLight read primitives in this pass
-      RT_LAUNCH_SMEM(ctx, "shade", (k_shade<T, true>), blocks, 256, smem, S, P, C, md, mc, q_cur, count, wave_mask, block_count, ctr, (int)bounces);
+      RT_LAUNCH_SMEM(ctx, "shade", (k_shade<T, true>), blocks, 256, smem, S, P, C, md, mc, q_cur, cnt, wave_mask, block_count, ctr, (int)wave_bounces);
     else
-      RT_LAUNCH_SMEM(ctx, "shade", (k_shade<T, false>), blocks, 256, 0, S, P, C, md, mc, q_cur, count, wave_mask, block_count, ctr, (int)bounces);
-    RT_LAUNCH(ctx, "queue_scan", k_scan_blocks, 1, 1024, block_count, blocks, block_count + blocks);
-    RT_LAUNCH(ctx, "queue_scatter", k_queue_scatter, blocks, 256, q_cur, count, wave_mask, block_count, q_nxt);
-    rays += count; bounces++;
-    RT_HIP(ctx, hipMemcpyAsync(ctx->pinned, block_count + blocks, 4, hipMemcpyDeviceToHost, ctx->stream));
-    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    count = ctx->pinned[0];
+      RT_LAUNCH_SMEM(ctx, "shade", (k_shade<T, false>), blocks, 256, 0, S, P, C, md, mc, q_cur, cnt, wave_mask, block_count, ctr, (int)wave_bounces);
+    RT_LAUNCH(ctx, "queue_scan", k_scan_blocks, 1, 1024, block_count, blocks, counts + wave_bounces + 1, cnt);
+    RT_LAUNCH(ctx, "queue_scatter", k_queue_scatter, blocks, 256, q_cur, cnt, wave_mask, block_count, q_nxt);
+    wave_bounces++;
     std::swap(q_cur, q_nxt);
+    ub_exact = false;
+    // the first two passes of a large frame are launched blind; after that a length is worth a round trip
+    if (ub > tail_threshold && wave_bounces >= 2) {
+      RT_HIP(ctx, hipMemcpyAsync(ctx->pinned, counts + wave_bounces, 4, hipMemcpyDeviceToHost, ctx->stream));
+      RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      ub = ctx->pinned[0]; ub_exact = true;
+      if (ub == 0) break;
+    }
   }
+  (void)ub_exact;
   RT_LAUNCH(ctx, "resolve", k_resolve<T>, div_up(n_pixels, 256), 256, P, (int)n_pixels, (int)p->sub_sample, pre, post, rgba8);
   TraceCounters hc;
+  const uint32_t *hcounts = hc.counts;
   RT_HIP(ctx, hipMemcpyAsync(&hc, ctr, sizeof(hc), hipMemcpyDeviceToHost, ctx->stream));
   RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
   RT_HIP(ctx, hipGetLastError());
   if (stats) {
-    stats->rays = rays + hc.tail_rays; stats->bounces = bounces; stats->shadow_rays = hc.shadow_rays; stats->gathers = hc.gathers;
+    uint64_t rays = 0;
+    for (uint32_t b = 0; b < wave_bounces; b++) rays += hcounts[b];
+    stats->rays = rays + hc.tail_rays; stats->bounces = wave_bounces + (hc.tail_rays ? 1 : 0);
+    stats->shadow_rays = hc.shadow_rays; stats->gathers = hc.gathers;
     stats->stack_overflows = hc.stack_overflows; stats->tail_rays = hc.tail_rays;
   }
   return RT_OK;

@@ -29,9 +29,12 @@ struct TraceCfg {
   int32_t max_depth, sub_sample, use_direct_light, use_photon_maps, max_bounces;
   uint64_t seed;
   int32_t x0, y0, w, h;
+  uint32_t n_paths;                   // w * h * sub_sample^2
 };
 
-struct TraceCounters { unsigned long long next_count, shadow_rays, gathers, stack_overflows, tail_rays; };
+#define RT_MAX_WAVE_BOUNCES 62
+// device-side bookkeeping of one rt_trace_tile call; counts[b] = queue length of wavefront pass b
+struct TraceCounters { unsigned long long shadow_rays, gathers, stack_overflows, tail_rays; uint32_t counts[RT_MAX_WAVE_BOUNCES + 2]; };
 
 // traceOnCanvas ray set-up (rayphoton.js:1589-1609, superSampleScale 0) for path p: writes the initial
 // path state and returns the camera ray.
@@ -61,14 +64,22 @@ RT_D void raygen_path(const DevScene<T> &S, const PathSoA<T> &P, const TraceCfg 
 // PRIMARY: the queue is the identity and the ray is generated in place (no ray loads); otherwise
 // the segment left by the previous shade pass is read from the path state.
 template <typename T, bool PRIMARY, bool LDS>
-__global__ void __launch_bounds__(256) k_intersect_closest(DevScene<T> S, PathSoA<T> P, TraceCfg C, uint32_t *queue, uint32_t count) {
+__global__ void __launch_bounds__(256) k_intersect_closest(DevScene<T> S, PathSoA<T> P, TraceCfg C, uint32_t *queue, uint32_t *count_ptr) {
   extern __shared__ __align__(16) unsigned char rt_lds[];
+  // device-side queue length (the grid is only an upper bound); the primary pass knows it and publishes it
+  const uint32_t count = PRIMARY ? C.n_paths : min(*count_ptr, C.n_paths);
+  if (PRIMARY && blockIdx.x == 0 && threadIdx.x == 0) *count_ptr = count;
+  if (blockIdx.x * blockDim.x >= count) return;
   const ScanSrc<T> G = LDS ? stage_scene_lds<T>(S, rt_lds) : global_scan_src<T>(S);
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= count) return;
   uint32_t p; V3<T> o, d;
   if (PRIMARY) { p = i; queue[i] = i; raygen_path<T>(S, P, C, p, o, d); }     // also seeds the identity queue the shade pass reads
-  else { p = queue[i]; o = mk<T>(P.ox[p], P.oy[p], P.oz[p]); d = mk<T>(P.dx[p], P.dy[p], P.dz[p]); }
+  else {
+    p = queue[i];
+    if (p >= C.n_paths) return;                             // (never true; guards the indexed accesses below)
+    o = mk<T>(P.ox[p], P.oy[p], P.oz[p]); d = mk<T>(P.dx[p], P.dy[p], P.dz[p]);
+  }
   T t;
   int idx = scan_scene<T, 0>(S, G, o, d, T(C.epsilon), T(0), t);
   P.hit_t[p] = t; P.hit_idx[p] = idx;
@@ -237,49 +248,79 @@ RT_D void flush_tally(const ShadeTally &t, TraceCounters *ctr) {
 // wave plus one count per workgroup; k_scan_blocks and k_queue_scatter then build the next queue in order.
 template <typename T, bool LDS>
 __global__ void __launch_bounds__(256) k_shade(DevScene<T> S, PathSoA<T> P, TraceCfg C, DevMap Md, DevMap Mc,
-                                               const uint32_t *queue, uint32_t count, unsigned long long *wave_mask,
+                                               const uint32_t *queue, const uint32_t *count_ptr, unsigned long long *wave_mask,
                                                uint32_t *block_count, TraceCounters *ctr, int bounce) {
   extern __shared__ __align__(16) unsigned char rt_lds[];
+  const uint32_t count = min(*count_ptr, C.n_paths);
+  if (blockIdx.x * blockDim.x >= count) return;
   const ScanSrc<T> G = LDS ? stage_scene_lds<T>(S, rt_lds) : global_scan_src<T>(S);
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   bool alive = false;
   ShadeTally tally;
   if (i < count) {
     const uint32_t p = queue[i];
-    alive = shade_body<T>(S, G, P, C, Md, Mc, p, P.hit_t[p], P.hit_idx[p], bounce, tally);
+    if (p < C.n_paths) alive = shade_body<T>(S, G, P, C, Md, Mc, p, P.hit_t[p], P.hit_idx[p], bounce, tally);
+    else tally.overflows++;                                 // (never taken; guards the indexed accesses)
   }
   block_publish_masks(alive, wave_mask, block_count);
   flush_tally(tally, ctr);
 }
 
 // Tail of a frame: once few paths are left, a wavefront pass per bounce is all launch and
-// synchronisation overhead, so each remaining path is followed to its end by one lane
-// (scan + traceRay body in a loop; the loop is bounded by max_bounces).  Segments traced here are
-// counted in ctr->tail_rays.
+// synchronisation overhead, so one launch follows every remaining path to its end.  A workgroup of
+// RT_TAIL_THREADS lanes takes that many queued paths; after every bounce the survivors' path indices
+// are compacted to the front of an LDS queue (the path state itself lives in the SoA arrays, so only
+// the index moves), and waves that are left without a path retire.  The loop is bounded by max_bounces.
+// Segments traced here are counted in ctr->tail_rays.
+#define RT_TAIL_THREADS 512
 template <typename T, bool LDS>
-__global__ void __launch_bounds__(256) k_tail(DevScene<T> S, PathSoA<T> P, TraceCfg C, DevMap Md, DevMap Mc,
-                                              const uint32_t *queue, uint32_t count, TraceCounters *ctr, int bounce0) {
+__global__ void __launch_bounds__(RT_TAIL_THREADS) k_tail(DevScene<T> S, PathSoA<T> P, TraceCfg C, DevMap Md, DevMap Mc,
+                                                          const uint32_t *queue, const uint32_t *count_ptr, TraceCounters *ctr, int bounce0) {
   extern __shared__ __align__(16) unsigned char rt_lds[];
+  __shared__ uint32_t live[2][RT_TAIL_THREADS];
+  __shared__ uint32_t wave_cnt[RT_TAIL_THREADS / 64];
+  const uint32_t count = min(*count_ptr, C.n_paths);
+  if (blockIdx.x * RT_TAIL_THREADS >= count) return;
   const ScanSrc<T> G = LDS ? stage_scene_lds<T>(S, rt_lds) : global_scan_src<T>(S);
-  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  uint32_t n_live = min((uint32_t)RT_TAIL_THREADS, count - blockIdx.x * RT_TAIL_THREADS);
+  if (threadIdx.x < n_live) live[0][threadIdx.x] = queue[blockIdx.x * RT_TAIL_THREADS + threadIdx.x];
+  __syncthreads();
   ShadeTally tally;
   unsigned long long rays = 0;
-  if (i < count) {
-    const uint32_t p = queue[i];
-    bool alive = true;
-    for (int b = bounce0; alive && b < C.max_bounces; b++) {
-      V3<T> o = mk<T>(P.ox[p], P.oy[p], P.oz[p]), d = mk<T>(P.dx[p], P.dy[p], P.dz[p]);
-      T t;
-      int idx = scan_scene<T, 0>(S, G, o, d, T(C.epsilon), T(0), t);
-      rays++;
-      alive = shade_body<T>(S, G, P, C, Md, Mc, p, t, idx, b, tally);
+  int cur = 0;
+  for (int b = bounce0; n_live > 0 && b < C.max_bounces; b++) {
+    // waves 0 .. nw-1 are still running this iteration; the others have retired and their wave_cnt slots are stale
+    const int nw = (int)((n_live + 63u) / 64u);
+    bool alive = false; uint32_t p = 0;
+    if (threadIdx.x < n_live) {
+      p = live[cur][threadIdx.x];
+      if (p < C.n_paths) {                                  // (always true; guards the indexed accesses below)
+        V3<T> o = mk<T>(P.ox[p], P.oy[p], P.oz[p]), d = mk<T>(P.dx[p], P.dy[p], P.dz[p]);
+        T t;
+        int idx = scan_scene<T, 0>(S, G, o, d, T(C.epsilon), T(0), t);
+        rays++;
+        alive = shade_body<T>(S, G, P, C, Md, Mc, p, t, idx, b, tally);
+      } else {
+        tally.overflows++;
+      }
     }
+    // ordered compaction of the survivors into the other LDS queue
+    unsigned long long mask = __ballot(alive);
+    if (lane == 0) wave_cnt[wv] = (uint32_t)__popcll(mask);
+    __syncthreads();
+    uint32_t base = 0, total = 0;
+    for (int w = 0; w < nw; w++) { uint32_t c = wave_cnt[w]; if (w < wv) base += c; total += c; }
+    const uint32_t slot = base + (uint32_t)__popcll(mask & (((unsigned long long)1 << lane) - 1));
+    if (alive && slot < RT_TAIL_THREADS) live[cur ^ 1][slot] = p;
+    __syncthreads();
+    cur ^= 1; n_live = min(total, (uint32_t)RT_TAIL_THREADS);
+    if ((uint32_t)(wv * 64) >= n_live) break;              // this wave has no path left (retired waves do not hold up barriers)
   }
   for (int off = 32; off > 0; off >>= 1) rays += __shfl_down(rays, off, 64);
-  if ((threadIdx.x & 63) == 0 && rays) atomicAdd(&ctr->tail_rays, rays);
+  if (lane == 0 && rays) atomicAdd(&ctr->tail_rays, rays);
   flush_tally(tally, ctr);
 }
-
 
 RT_D double clamp01(double x, double lo, double hi) { return (x < lo) ? lo : ((x > hi) ? hi : x); }
 
