@@ -126,7 +126,7 @@ int pl_trace_tile(rt_scene *sc, const rt_params *p, DevMap md, DevMap mc, int x0
   // once at most tail_threshold paths are left, one k_tail launch follows each of them to its end.
   // Queue lengths live on the device; a launch's grid is only an upper bound, so the host reads a
   // length back only when it needs one to choose the next step (never for tiles <= tail_threshold).
-  uint32_t tail_threshold = 1u << 17;
+  uint32_t tail_threshold = 1u << 19;
   if (const char *e = getenv("RT355_TAIL_THRESHOLD")) tail_threshold = (uint32_t)strtoul(e, nullptr, 10);
   uint32_t ub = (uint32_t)n_paths;                          // upper bound of the current queue length
   bool ub_exact = true;
