@@ -30,9 +30,11 @@ enum { RT_OK = 0, RT_ERR_INVALID = -1, RT_ERR_HIP = -2, RT_ERR_NO_DEVICE = -3, R
 
 /* primitive types: the `type` strings of rayphoton.js:353-481 */
 enum { RT_PLANE = 0, RT_SPHERE, RT_HEMISPHERE, RT_CYLINDER, RT_TRIANGLE, RT_SQUARE, RT_DISC, RT_ANNULUS, RT_NUM_TYPES };
-enum { RT_FLAG_CONVEX = 1, RT_FLAG_LIGHT = 2, RT_FLAG_TRUNC_MAX = 4, RT_FLAG_HALF_HEIGHT = 8 };
+enum { RT_FLAG_CONVEX = 1, RT_FLAG_LIGHT = 2, RT_FLAG_TRUNC_MAX = 4, RT_FLAG_HALF_HEIGHT = 8,
+       RT_FLAG_FIRST_ROOT = 16 /* ray.js cylinder: infinite, first root only (ray.js:443-461) */ };
 /* procedural albedo closures of the presets (rayphoton.js:746-755, :756-768, :784-792, :871-874) */
-enum { RT_PROC_NONE = 0, RT_PROC_STRIPE_CHECKER = 1, RT_PROC_EIGHT_BALL = 2, RT_PROC_TILE_GRID = 3, RT_PROC_ROTATED_CHECKER = 4 };
+enum { RT_PROC_NONE = 0, RT_PROC_STRIPE_CHECKER = 1, RT_PROC_EIGHT_BALL = 2, RT_PROC_TILE_GRID = 3, RT_PROC_ROTATED_CHECKER = 4,
+       RT_PROC_STRIPE_CHECKER3 = 5 /* ray.js:650-659 */ };
 enum { RT_PRECISION_F32 = 0, RT_PRECISION_F64 = 1 };
 enum { RT_MODE_PHOTON = 0 /* rayphoton.js traceRay */, RT_MODE_WHITTED = 1 /* ray.js traceRay */ };
 enum { RT_SCAN_CLOSEST = 0, RT_SCAN_CLOSEST_NOLIGHT = 1, RT_SCAN_ANY = 2 };
@@ -56,6 +58,8 @@ typedef struct rt_scene_desc {
   double camera[16];            /* origin3 ONBu3 ONBv3 ONBw3 fovScaleWidth fovScaleHeight, 2 reserved */
   uint32_t width, height;       /* canvas size */
   double materials[4][8];       /* rows: transparent(0/1), refrIndex, reflectance, specular; NaN = undefined */
+  const double *shape_surface;  /* n_shapes x 2: per-shape reflectance, specular -- the ray.js shape model
+                                   (ray.js:244-385), read by RT_MODE_WHITTED only; may be NULL otherwise */
 } rt_scene_desc;
 
 /* The reference's top-of-file constants (rayphoton.js:6-23) plus run controls. */

@@ -17,7 +17,7 @@ class OraScene(C.Structure):
     _fields_ = [("n_shapes", C.c_uint32), ("shape_meta", C.c_void_p), ("shape_geom", C.c_void_p),
                 ("shape_colour", C.c_void_p), ("n_lights", C.c_uint32), ("light_shape", C.c_void_p),
                 ("light_data", C.c_void_p), ("camera", C.c_double * 16), ("width", C.c_uint32),
-                ("height", C.c_uint32), ("materials", (C.c_double * 8) * 4)]
+                ("height", C.c_uint32), ("materials", (C.c_double * 8) * 4), ("shape_surface", C.c_void_p)]
 
 
 class OraParams(C.Structure):
@@ -72,6 +72,9 @@ class Scene:
         for r in range(4):
             for k in range(8):
                 s.materials[r][k] = float(flat.materials[r, k])
+        if flat.shape_surface is not None:
+            self._keep.append(_c(flat.shape_surface, np.float64))
+            s.shape_surface = _p(self._keep[-1])
         self.c = s
 
 
@@ -201,6 +204,15 @@ class Maps:
         if getattr(self, "h", None):
             lib().ora_maps_destroy(C.c_void_p(self.h))
             self.h = None
+
+
+def render_whitted(scene: Scene, p: OraParams, x0, y0, w, h):
+    """mode A (ray.js): raw traceRay colours and the putPixel values"""
+    raw = np.zeros((h, w, 4), np.float64)
+    post = np.zeros((h, w, 4), np.float64)
+    rays = C.c_uint64()
+    lib().ora_render_whitted(C.byref(scene.c), C.byref(p), C.c_int(x0), C.c_int(y0), C.c_int(w), C.c_int(h), _p(raw), _p(post), C.byref(rays))
+    return raw, post, rays.value
 
 
 def render(scene: Scene, p: OraParams, maps: Maps | None, x0, y0, w, h):

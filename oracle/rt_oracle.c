@@ -160,6 +160,7 @@ double ora_intersect(const double o_[3], const double d_[3], int type, int flags
       double halfB = vd - va * da;
       double cc = sqlen(v) - va * va - r * r;
       if (!q_roots(a, halfB, cc, t)) return NAN;
+      if (flags & ORA_FLAG_FIRST_ROOT) return (t[0] <= 0) ? NAN : t[0];   /* ray.js:443-461: infinite, first root only */
       for (int i = 0; i < 2; i++) {
         if (t[i] > EPS) {
           if (!(flags & ORA_FLAG_HALF_HEIGHT)) return t[i];
@@ -314,6 +315,15 @@ static void shape_colour(const ora_scene *s, int i, v3 p, double out[3]) {
     case 4: {                                                  /* rayphoton.js:871-874, :889-892 */
       int idx = to_int32(floor((0.6 * p.x + 0.8 * p.y + 0.7) / 3.2) + floor((0.8 * p.x - 0.6 * p.y + 0.2) / 3.2)) & 1;
       c = idx ? BLACK : WHITE;
+      break;
+    }
+    case 5: {                                                  /* ray.js:650-659 */
+      double f = ORA_SIN(p.x) + p.y;
+      if (f > 0 && f < 1) c = PINK;
+      else {
+        int idx = 1 + (to_int32(floor(p.x * 2)) & 1) + (to_int32(floor(p.y * 2)) & 1);
+        c = (idx == 1) ? GREY : (idx == 2) ? BLACK : BLUE;
+      }
       break;
     }
     default: break;
@@ -769,4 +779,115 @@ void ora_render(const ora_scene *s, const ora_params *P, const ora_maps *m,
     }
   if (n_rays) *n_rays = c.rays;
   if (n_tests) *n_tests = g_tests;
+}
+
+/* ------------------------------------------------------------------ mode A: ray.js */
+/* vecPerturb of ray.js:75-100: basis NOT normalised; lower bound cos(pi/2)^2 */
+static v3 vec_perturb_a(v3 v, double eps, rng_t *g) {
+  v3 m = V(1, 0, 0);
+  if (is_zero(cross(v, m), eps)) m = V(0, 1, 0);
+  v3 n = cross(v, m);
+  m = cross(n, v);
+  double cl = ORA_COS(PI / 2);
+  double lower = cl * cl;
+  double x = (1 - lower) * rng_next(g) + lower;
+  double cosT = sqrt(x);
+  double sinT = sqrt(1 - cosT * cosT);
+  double phi = 2 * PI * rng_next(g);
+  return plus(plus(scal(cosT, v), scal(sinT * ORA_COS(phi), m)), scal(sinT * ORA_SIN(phi), n));
+}
+
+typedef struct { int ok; double r, g, b, a; } cola_t;      /* ok = 0: undefined */
+
+/* ray.js:844-993.  Scan is in DESCENDING index order, so equal distances go to the highest index. */
+static cola_t trace_ray_a(rctx *c, v3 o, v3 d, double max_dist, int depth, double importance, mstack *st) {
+  const ora_scene *s = c->s; const double EPS = c->P->epsilon;
+  cola_t out = { 1, 0, 0, 0, 1 };
+  if (importance < 0.01) { out.r = out.g = out.b = 255; return out; }          /* COL_WHITE :845-847 */
+  c->rays++;
+  double min = INFINITY; int minS = -1;
+  double oo[3] = { o.x, o.y, o.z }, dd[3] = { d.x, d.y, d.z };
+  for (int i = (int)s->n_shapes; i--;) {
+    double t = ora_intersect(oo, dd, shape_type(s, i), shape_flags(s, i), shape_g(s, i), EPS);
+    if (t > EPS && t < min) { min = t; minS = i; }
+  }
+  if (minS < 0) { out.r = out.g = out.b = 16; return out; }                     /* :992 */
+  v3 hit = plus(o, scal(min, d));
+  double sc[3]; shape_colour(s, minS, hit, sc);
+  v3 n = shape_normal(s, minS, hit);
+  const double refl = s->shape_surface ? s->shape_surface[2 * minS] : NAN;
+  const double spec = s->shape_surface ? s->shape_surface[2 * minS + 1] : NAN;
+  double T[3] = { sc[0], sc[1], sc[2] };                                        /* transmittedColour = shapeCol :891 */
+  if (min < max_dist && depth > 0) {                                            /* :893 */
+    double cos1 = -dot(d, n);
+    int mat = shape_mat(s, minS);
+    cola_t child;
+    if (!mat_transparent(s, mat)) {                                             /* MAT_OPAQUE :895 */
+      if (cos1 < 0) { if (min < 1e5) { out.ok = 0; return out; } out.r = out.g = out.b = 0; out.a = 0; return out; }   /* :905 */
+      v3 rdir = plus(d, scal(2 * cos1, n));
+      v3 pdir = rdir;
+      if (rng_next(c->g) > spec) {                                              /* :910-923 */
+        for (int attempt = 0; attempt < 100; attempt++) {
+          pdir = vec_perturb_a(rdir, EPS, c->g);
+          if (dot(pdir, n) > EPS) break;
+          if (attempt == 99) pdir = rdir;
+        }
+      }
+      child = trace_ray_a(c, hit, normalize(pdir, EPS), max_dist - min, depth - 1, importance * refl, st);
+    } else {
+      double eta1 = mat_refr(s, st->len >= 1 ? st->m[st->len - 1] : -1);
+      double eta2 = (dot(d, n) < 0) ? mat_refr(s, mat) : (st->len >= 2 ? mat_refr(s, st->m[st->len - 2]) : NAN);
+      double ratio = eta1 / eta2;                                               /* eta2 undefined: NaN flows on (:929-931) */
+      double c2sq = 1 - ratio * ratio * (1 - cos1 * cos1);
+      if (c2sq < 0) {
+        v3 rdir = plus(d, scal(2 * cos1, n));
+        child = trace_ray_a(c, hit, normalize(rdir, EPS), max_dist - min, depth - 1, importance * refl, st);
+      } else {
+        double pm = (cos1 < 0) ? -1 : 1;
+        v3 fdir = plus(scal(ratio, d), scal(ratio * cos1 - pm * sqrt(c2sq), n));
+        if (cos1 < 0) { if (st->len > 0) st->len--; } else if (st->len < STACK_MAX) { st->m[st->len++] = (uint8_t)mat; }
+        child = trace_ray_a(c, hit, normalize(fdir, EPS), max_dist - min, depth - 1, (1 - 0.0) * importance * refl, st);
+      }
+    }
+    if (!child.ok) { out.ok = 0; return out; }                                  /* the caller dereferences undefined and throws */
+    T[0] = child.r; T[1] = child.g; T[2] = child.b;
+  }
+  double res[3];
+  for (int k = 0; k < 3; k++) {                                                 /* :979-986, Math.round = floor(x + 0.5) */
+    double v = floor(((1 - refl) * sc[k] + refl * T[k]) + 0.5);
+    res[k] = v < 0 ? 0 : (v > 255 ? 255 : v);
+  }
+  out.r = res[0]; out.g = res[1]; out.b = res[2];
+  return out;
+}
+
+void ora_render_whitted(const ora_scene *s, const ora_params *P, int x0, int y0, int w, int h, double *rgba,
+                        double *post, uint64_t *n_rays) {
+  rng_t g; g.total = 0;
+  rctx c = { s, P, NULL, &g, 0 };
+  const double *cam = s->camera;
+  v3 co = ld(cam), cu = ld(cam + 3), cv = ld(cam + 6), cw = ld(cam + 9);
+  const int S = P->sub_sample;
+  for (int yy = 0; yy < h; yy++)
+    for (int xx = 0; xx < w; xx++) {
+      int X = x0 + xx, Y = y0 + yy;
+      uint32_t pixel = (uint32_t)(Y * (int)s->width + X);
+      double tot[4] = { 0, 0, 0, 0 }; cola_t last = { 1, 0, 0, 0, 0 }; int bad = 0;
+      for (int sy = 0; sy < S; sy++)
+        for (int sx = 0; sx < S; sx++) {                                       /* ray.js:814-835 */
+          rng_set(&g, P->seed, ORA_DOMAIN_RENDER, pixel, (uint32_t)(sy * S + sx));
+          double u = ((X + (sx + rng_next(&g)) / S) * 2 / s->width) - 1;
+          double v = -(((Y + (sy + rng_next(&g)) / S) * 2 / s->height) - 1);
+          u *= cam[12]; v *= cam[13];
+          v3 xyz = plus(plus(plus(co, scal(u, cu)), scal(v, cv)), scal(-1, cw));
+          mstack st; st.len = 1; st.m[0] = 0;
+          last = trace_ray_a(&c, co, normalize(minus(xyz, co), P->epsilon), P->max_trace_dist, P->max_depth, 1, &st);
+          if (!last.ok) bad = 1;
+          tot[0] += last.r; tot[1] += last.g; tot[2] += last.b; tot[3] += last.a;   /* colour() does not clamp in ray.js:102 */
+        }
+      size_t o4 = 4 * ((size_t)yy * w + xx);
+      if (rgba) { rgba[o4] = bad ? NAN : last.r; rgba[o4 + 1] = bad ? NAN : last.g; rgba[o4 + 2] = bad ? NAN : last.b; rgba[o4 + 3] = bad ? NAN : last.a; }
+      if (post) for (int k = 0; k < 4; k++) post[o4 + k] = bad ? NAN : floor(tot[k] / (S * S));   /* :837-840 */
+    }
+  if (n_rays) *n_rays = c.rays;
 }

@@ -18,7 +18,7 @@ extern "C" {
 #endif
 
 enum { ORA_PLANE = 0, ORA_SPHERE, ORA_HEMISPHERE, ORA_CYLINDER, ORA_TRIANGLE, ORA_SQUARE, ORA_DISC, ORA_ANNULUS };
-enum { ORA_FLAG_CONVEX = 1, ORA_FLAG_LIGHT = 2, ORA_FLAG_TRUNC_MAX = 4, ORA_FLAG_HALF_HEIGHT = 8 };
+enum { ORA_FLAG_CONVEX = 1, ORA_FLAG_LIGHT = 2, ORA_FLAG_TRUNC_MAX = 4, ORA_FLAG_HALF_HEIGHT = 8, ORA_FLAG_FIRST_ROOT = 16 };
 enum { ORA_DOMAIN_RENDER = 0, ORA_DOMAIN_EMIT1 = 1, ORA_DOMAIN_EMIT2 = 2, ORA_DOMAIN_AUX = 3 };
 
 /* Scene description: the same flat arrays the product C ABI takes (include/rt355.h). */
@@ -33,6 +33,7 @@ typedef struct ora_scene {
   double camera[16];           /* origin3 u3 v3 w3 fovScaleWidth fovScaleHeight */
   uint32_t width, height;
   double materials[4][8];      /* transparent, refrIndex, reflectance, specular; NaN = undefined */
+  const double *shape_surface; /* n x 2 per-shape reflectance, specular (ray.js shapes), or NULL */
 } ora_scene;
 
 typedef struct ora_params {
@@ -104,6 +105,11 @@ void ora_maps_destroy(ora_maps *m);
 void ora_render(const ora_scene *s, const ora_params *p, const ora_maps *m,
                 int x0, int y0, int w, int h, double *pre_rgba, double *post_rgba,
                 uint64_t *n_rays, uint64_t *n_tests);
+
+/* the older tracer, ray.js:801-993 ("mode A"): raw traceRay colour per pixel (sub_sample 1: one path per
+ * pixel); rgba = NaN where the reference's traceRay returns undefined (ray.js:905) */
+void ora_render_whitted(const ora_scene *s, const ora_params *p, int x0, int y0, int w, int h, double *rgba,
+                        double *post_rgba, uint64_t *n_rays);
 
 #ifdef __cplusplus
 }

@@ -38,7 +38,7 @@ class SceneDesc(C.Structure):
     _fields_ = [("n_shapes", C.c_uint32), ("shape_meta", C.c_void_p), ("shape_geom", C.c_void_p),
                 ("shape_colour", C.c_void_p), ("n_lights", C.c_uint32), ("light_shape", C.c_void_p),
                 ("light_data", C.c_void_p), ("camera", C.c_double * 16), ("width", C.c_uint32),
-                ("height", C.c_uint32), ("materials", (C.c_double * 8) * 4)]
+                ("height", C.c_uint32), ("materials", (C.c_double * 8) * 4), ("shape_surface", C.c_void_p)]
 
 
 class Params(C.Structure):
@@ -202,6 +202,9 @@ class Scene:
         for r in range(4):
             for k in range(8):
                 d.materials[r][k] = float(flat.materials[r, k])
+        if flat.shape_surface is not None:
+            keep.append(_c(flat.shape_surface, np.float64))
+            d.shape_surface = keep[-1].ctypes.data
         h = C.c_void_p()
         ctx.check(ctx.lib.rt_scene_upload(ctx.h, C.byref(d), C.byref(h)))
         self.h = h

@@ -121,7 +121,7 @@ int rt_profile_get(rt_ctx *ctx, const char *kernel, double *total_ms, uint64_t *
 
 // ------------------------------------------------------------------ scene
 template <typename T> static int upload_typed(rt_ctx *ctx, const rt_scene_desc *d, const std::vector<uint32_t> &order, DevMem &geom,
-                                              DevMem &colour, DevMem &sgeom, DevScene<T> &S, rt_scene *sc) {
+                                              DevMem &colour, DevMem &sgeom, DevMem &surface, DevScene<T> &S, rt_scene *sc) {
   const uint32_t n = d->n_shapes;
   std::vector<T> g((size_t)n * 12), c((size_t)n * 4), sg((size_t)n * 12);
   for (size_t i = 0; i < (size_t)n * 12; i++) g[i] = (T)d->shape_geom[i];
@@ -143,6 +143,14 @@ template <typename T> static int upload_typed(rt_ctx *ctx, const rt_scene_desc *
   S.width = d->width; S.height = d->height;
   for (int r = 0; r < 4; r++) for (int k = 0; k < 8; k++) S.mat[r][k] = (T)d->materials[r][k];
   for (int k = 0; k < 8; k++) { S.refl_k[k] = rt_threshold_u24(d->materials[2][k]); S.spec_k[k] = rt_threshold_u24(d->materials[3][k]); }
+  S.surface = nullptr; S.spec_gt_k = sc->spec_gt.as<uint32_t>();
+  if (d->shape_surface) {
+    std::vector<T> sf((size_t)n * 2);
+    for (size_t i = 0; i < (size_t)n * 2; i++) sf[i] = (T)d->shape_surface[i];
+    RT_HIP(ctx, surface.alloc(sf.size() * sizeof(T)));
+    RT_HIP(ctx, hipMemcpy(surface.p, sf.data(), sf.size() * sizeof(T), hipMemcpyHostToDevice));
+    S.surface = surface.as<T>();
+  }
   return RT_OK;
 }
 
@@ -173,14 +181,22 @@ int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *d, rt_scene **out) {
   uint32_t seg[RT_NUM_TYPES + 1] = { 0 };
   for (uint32_t s = 0; s < n; s++) { sflags[s] = d->shape_meta[4 * order[s] + 2]; seg[d->shape_meta[4 * order[s]] + 1]++; }
   for (int t = 0; t < RT_NUM_TYPES; t++) seg[t + 1] += seg[t];
+  // `U > specular` (ray.js:910) on the integer draw: k * 2^-24 > s  <=>  k >= floor(s * 2^24) + 1; NaN never
+  std::vector<uint32_t> spec_gt(n, (1u << 24) + 1);
+  if (d->shape_surface)
+    for (uint32_t i = 0; i < n; i++) {
+      double sp = d->shape_surface[2 * (size_t)i + 1];
+      if (sp == sp) spec_gt[i] = sp < 0 ? 0u : (sp >= 1 ? (1u << 24) + 1 : (uint32_t)floor(sp * 16777216.0) + 1);
+    }
   int rc = RT_OK;
   auto up = [&](DevMem &m, const void *src, size_t bytes) -> int {
     RT_HIP(ctx, m.alloc(bytes)); RT_HIP(ctx, hipMemcpy(m.p, src, bytes, hipMemcpyHostToDevice)); return RT_OK;
   };
   if ((rc = up(sc->meta, d->shape_meta, (size_t)n * 4)) || (rc = up(sc->sorig, order.data(), (size_t)n * 4)) ||
       (rc = up(sc->sflags, sflags.data(), (size_t)n * 4)) ||
-      (rc = upload_typed<float>(ctx, d, order, sc->geom32, sc->colour32, sc->sgeom32, sc->d32, sc)) ||
-      (rc = upload_typed<double>(ctx, d, order, sc->geom64, sc->colour64, sc->sgeom64, sc->d64, sc))) {
+      (rc = up(sc->spec_gt, spec_gt.data(), (size_t)n * 4)) ||
+      (rc = upload_typed<float>(ctx, d, order, sc->geom32, sc->colour32, sc->sgeom32, sc->surface32, sc->d32, sc)) ||
+      (rc = upload_typed<double>(ctx, d, order, sc->geom64, sc->colour64, sc->sgeom64, sc->surface64, sc->d64, sc))) {
     delete sc; return rc;
   }
   memcpy(sc->d32.seg, seg, sizeof seg); memcpy(sc->d64.seg, seg, sizeof seg);
@@ -234,7 +250,7 @@ int rt_trace_tile(rt_scene *sc, const rt_params *p, rt_photon_map *diffuse, rt_p
   if (w <= 0 || h <= 0 || x0 < 0 || y0 < 0 || (uint32_t)(x0 + w) > sc->d32.width || (uint32_t)(y0 + h) > sc->d32.height)
     return rt_fail(ctx, RT_ERR_INVALID, "tile [%d,%d)+[%d,%d) outside the %ux%u canvas", x0, y0, w, h, sc->d32.width, sc->d32.height);
   if (p->sub_sample < 1 || p->sub_sample > 64) return rt_fail(ctx, RT_ERR_INVALID, "sub_sample must be in 1..64");
-  if (p->mode != RT_MODE_PHOTON) return rt_fail(ctx, RT_ERR_INVALID, "mode %d not available", p->mode);
+  if (p->mode != RT_MODE_PHOTON && p->mode != RT_MODE_WHITTED) return rt_fail(ctx, RT_ERR_INVALID, "unknown mode %d", p->mode);
   if ((diffuse && diffuse->ctx != ctx) || (caustic && caustic->ctx != ctx)) return rt_fail(ctx, RT_ERR_INVALID, "photon map belongs to another context");
   RT_HIP(ctx, hipSetDevice(ctx->device));
   const size_t npx = (size_t)w * h;

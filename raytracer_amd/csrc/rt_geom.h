@@ -28,6 +28,8 @@ template <typename T> struct DevScene {
   uint32_t width, height;
   T mat[4][8];                // transparent, refrIndex, reflectance, specular (NaN = undefined)
   uint32_t refl_k[8], spec_k[8];    // integer thresholds of `U < reflectance`, `U < specular`
+  const T *surface;           // n x 2 per-shape reflectance, specular (ray.js shape model) or nullptr
+  const uint32_t *spec_gt_k;  // per shape: smallest 24-bit draw k with k * 2^-24 > specular
 };
 
 // A miss is reported as -1 (every accepted distance is > epsilon > 0).
@@ -94,6 +96,7 @@ template <typename T> RT_D T isect_cylinder(V3<T> o, V3<T> d, const T *g, int fl
   T halfB = vd - va * da;
   T cc = sqlen(v) - va * va - r * r;
   if (!q_roots<T>(a, halfB, cc, t0, t1)) return miss<T>();
+  if (flags & RT_FLAG_FIRST_ROOT) return (t0 <= T(0)) ? miss<T>() : t0;       // ray.js:458-461
   bool finite = flags & RT_FLAG_HALF_HEIGHT;
   if (t0 > eps) {
     if (!finite) return t0;
@@ -172,7 +175,8 @@ template <typename T> RT_D ScanSrc<T> global_scan_src(const DevScene<T> &S) {
 // Scan all primitives in type-sorted order.  MODE 0: closest incl. lights (rayphoton.js:1642-1650),
 // MODE 1: closest excluding lights (:1467-1475), MODE 2: any occluder closer than limit - eps
 // (:1853-1857).  The reference scans in index order and keeps the first of equal distances
-// (strict `<`), so ties go to the lowest original index here too.
+// (strict `<`), so ties go to the lowest original index here too.  MODE 3: closest incl. lights with ties going
+// to the HIGHEST index, for ray.js, which scans in descending index order (ray.js:863).
 template <typename T, int MODE> RT_D int scan_scene(const DevScene<T> &S, const ScanSrc<T> &G, V3<T> o, V3<T> d, T eps, T limit, T &t_out) {
   T best = Limits<T>::inf(); int best_idx = -1;
   const T lim = (MODE == 2) ? limit - eps : T(0);
@@ -182,11 +186,11 @@ template <typename T, int MODE> RT_D int scan_scene(const DevScene<T> &S, const 
     const T *g = G.geom + (size_t)s * RT_GEOM_STRIDE;                                   \
     const int flags = (int)G.flags[s]; (void)flags;                                     \
     T t = EXPR;                                                                         \
-    if (MODE != 0 && (flags & RT_FLAG_LIGHT)) continue;                                 \
+    if ((MODE == 1 || MODE == 2) && (flags & RT_FLAG_LIGHT)) continue;                  \
     if (MODE == 2) { if (t > eps && t < lim) { t_out = t; return 1; } }                 \
     else {                                                                              \
       int orig = (int)G.orig[s];                                                        \
-      if (t > eps && (t < best || (t == best && orig < best_idx))) { best = t; best_idx = orig; } \
+      if (t > eps && (t < best || (t == best && (MODE == 3 ? (best_idx >= 0 && orig > best_idx) : orig < best_idx)))) { best = t; best_idx = orig; } \
     }                                                                                   \
   }
   RT_SCAN_LOOP(RT_PLANE, isect_plane<T>(o, d, g, eps))
@@ -253,6 +257,12 @@ template <typename T> RT_D V3<T> shape_colour(const DevScene<T> &S, int i, V3<T>
       int idx = js_parity<T>(rt_floor((T(0.6) * p.x + T(0.8) * p.y + T(0.7)) / T(3.2)) +
                              rt_floor((T(0.8) * p.x - T(0.6) * p.y + T(0.2)) / T(3.2)));
       return idx ? BLACK : WHITE;
+    }
+    case RT_PROC_STRIPE_CHECKER3: {                                       // ray.js:650-659
+      T f = rt_sin(p.x) + p.y;
+      if (f > T(0) && f < T(1)) return mk<T>(255, 32, 144);
+      int idx = 1 + js_parity<T>(rt_floor(p.x * T(2))) + js_parity<T>(rt_floor(p.y * T(2)));
+      return idx == 1 ? mk<T>(128, 128, 128) : idx == 2 ? BLACK : mk<T>(8, 8, 64);
     }
   }
   return mk<T>(c[0], c[1], c[2]);

@@ -87,9 +87,9 @@ template <typename T> static PathSoA<T> carve_paths(void *base, size_t n, size_t
   return P;
 }
 
-template <typename T>
-int pl_trace_tile(rt_scene *sc, const rt_params *p, DevMap md, DevMap mc, int x0, int y0, int w, int h,
-                  double *pre, double *post, uint8_t *rgba8, rt_trace_stats *stats) {
+template <typename T, bool WHITTED>
+static int trace_tile_mode(rt_scene *sc, const rt_params *p, DevMap md, DevMap mc, int x0, int y0, int w, int h,
+                           double *pre, double *post, uint8_t *rgba8, rt_trace_stats *stats) {
   rt_ctx *ctx = sc->ctx;
   DevScene<T> &S = SceneOf<T>::get(sc);
   const size_t n_pixels = (size_t)w * h;
@@ -112,6 +112,14 @@ int pl_trace_tile(rt_scene *sc, const rt_params *p, DevMap md, DevMap mc, int x0
   C.use_photon_maps = p->use_photon_maps; C.max_bounces = p->max_bounces > 0 ? p->max_bounces : 64;
   C.seed = p->seed; C.x0 = x0; C.y0 = y0; C.w = w; C.h = h; C.n_paths = (uint32_t)n_paths;
   if (!p->use_photon_maps) { md.n = 0; mc.n = 0; }
+  T *levels = nullptr;
+  if (WHITTED) {      // one record of 4 values per path and recursion level (levels 0 .. max_depth)
+    if (p->max_depth < 0 || p->max_depth > 255) return rt_fail(ctx, RT_ERR_INVALID, "max_depth %d outside [0, 255]", p->max_depth);
+    RT_HIP(ctx, sc->ws_levels.reserve((size_t)(p->max_depth + 1) * n_paths * 4 * sizeof(T)));
+    levels = sc->ws_levels.as<T>();
+    C.max_bounces = p->max_depth + 2;                       // every path ends within max_depth + 1 levels
+    md.n = 0; mc.n = 0;
+  }
 
   RT_HIP(ctx, hipMemsetAsync(ctr, 0, sizeof(TraceCounters), ctx->stream));
   const uint32_t max_blocks = div_up(n_paths, 256);
@@ -136,21 +144,21 @@ int pl_trace_tile(rt_scene *sc, const rt_params *p, DevMap md, DevMap mc, int x0
     uint32_t *cnt = counts + wave_bounces;
     if ((wave_bounces > 0 && ub <= tail_threshold) || wave_bounces >= RT_MAX_WAVE_BOUNCES) {
       const uint32_t tblocks = div_up(ub, RT_TAIL_THREADS);
-      if (lds) RT_LAUNCH_SMEM(ctx, "tail", (k_tail<T, true>), tblocks, RT_TAIL_THREADS, smem, S, P, C, md, mc, q_cur, cnt, ctr, (int)wave_bounces);
-      else RT_LAUNCH_SMEM(ctx, "tail", (k_tail<T, false>), tblocks, RT_TAIL_THREADS, 0, S, P, C, md, mc, q_cur, cnt, ctr, (int)wave_bounces);
+      if (lds) RT_LAUNCH_SMEM(ctx, "tail", (k_tail<T, true, WHITTED>), tblocks, RT_TAIL_THREADS, smem, S, P, C, md, mc, levels, q_cur, cnt, ctr, (int)wave_bounces);
+      else RT_LAUNCH_SMEM(ctx, "tail", (k_tail<T, false, WHITTED>), tblocks, RT_TAIL_THREADS, 0, S, P, C, md, mc, levels, q_cur, cnt, ctr, (int)wave_bounces);
       break;
     }
     if (wave_bounces == 0) {
-      if (lds) RT_LAUNCH_SMEM(ctx, "intersect_closest", (k_intersect_closest<T, true, true>), blocks, 256, smem, S, P, C, q_cur, cnt);
-      else RT_LAUNCH_SMEM(ctx, "intersect_closest", (k_intersect_closest<T, true, false>), blocks, 256, 0, S, P, C, q_cur, cnt);
+      if (lds) RT_LAUNCH_SMEM(ctx, "intersect_closest", (k_intersect_closest<T, true, true, WHITTED>), blocks, 256, smem, S, P, C, q_cur, cnt);
+      else RT_LAUNCH_SMEM(ctx, "intersect_closest", (k_intersect_closest<T, true, false, WHITTED>), blocks, 256, 0, S, P, C, q_cur, cnt);
     } else {
-      if (lds) RT_LAUNCH_SMEM(ctx, "intersect_closest", (k_intersect_closest<T, false, true>), blocks, 256, smem, S, P, C, q_cur, cnt);
-      else RT_LAUNCH_SMEM(ctx, "intersect_closest", (k_intersect_closest<T, false, false>), blocks, 256, 0, S, P, C, q_cur, cnt);
+      if (lds) RT_LAUNCH_SMEM(ctx, "intersect_closest", (k_intersect_closest<T, false, true, WHITTED>), blocks, 256, smem, S, P, C, q_cur, cnt);
+      else RT_LAUNCH_SMEM(ctx, "intersect_closest", (k_intersect_closest<T, false, false, WHITTED>), blocks, 256, 0, S, P, C, q_cur, cnt);
     }
-    if (lds && C.use_direct_light)      // only the shadow-ray scans of directLight read primitives in this pass
-      RT_LAUNCH_SMEM(ctx, "shade", (k_shade<T, true>), blocks, 256, smem, S, P, C, md, mc, q_cur, cnt, wave_mask, block_count, ctr, (int)wave_bounces);
+    if (lds && C.use_direct_light && !WHITTED)      // only the shadow-ray scans of directLight read primitives in this pass
+      RT_LAUNCH_SMEM(ctx, "shade", (k_shade<T, true, WHITTED>), blocks, 256, smem, S, P, C, md, mc, levels, q_cur, cnt, wave_mask, block_count, ctr, (int)wave_bounces);
     else
-      RT_LAUNCH_SMEM(ctx, "shade", (k_shade<T, false>), blocks, 256, 0, S, P, C, md, mc, q_cur, cnt, wave_mask, block_count, ctr, (int)wave_bounces);
+      RT_LAUNCH_SMEM(ctx, "shade", (k_shade<T, false, WHITTED>), blocks, 256, 0, S, P, C, md, mc, levels, q_cur, cnt, wave_mask, block_count, ctr, (int)wave_bounces);
     RT_LAUNCH(ctx, "queue_scan", k_scan_blocks, 1, 1024, block_count, blocks, counts + wave_bounces + 1, cnt);
     RT_LAUNCH(ctx, "queue_scatter", k_queue_scatter, blocks, 256, q_cur, cnt, wave_mask, block_count, q_nxt);
     wave_bounces++;
@@ -165,7 +173,11 @@ int pl_trace_tile(rt_scene *sc, const rt_params *p, DevMap md, DevMap mc, int x0
     }
   }
   (void)ub_exact;
-  RT_LAUNCH(ctx, "resolve", k_resolve<T>, div_up(n_pixels, 256), 256, P, (int)n_pixels, (int)p->sub_sample, pre, post, rgba8);
+  if (WHITTED)
+    RT_LAUNCH(ctx, "resolve", k_resolve_a<T>, div_up(n_pixels, 256), 256, P, levels, (uint32_t)n_paths, (int)p->max_depth, (int)n_pixels,
+              (int)p->sub_sample, pre, post, rgba8);
+  else
+    RT_LAUNCH(ctx, "resolve", k_resolve<T>, div_up(n_pixels, 256), 256, P, (int)n_pixels, (int)p->sub_sample, pre, post, rgba8);
   TraceCounters hc;
   const uint32_t *hcounts = hc.counts;
   RT_HIP(ctx, hipMemcpyAsync(&hc, ctr, sizeof(hc), hipMemcpyDeviceToHost, ctx->stream));
@@ -179,6 +191,17 @@ int pl_trace_tile(rt_scene *sc, const rt_params *p, DevMap md, DevMap mc, int x0
     stats->stack_overflows = hc.stack_overflows; stats->tail_rays = hc.tail_rays;
   }
   return RT_OK;
+}
+
+template <typename T>
+int pl_trace_tile(rt_scene *sc, const rt_params *p, DevMap md, DevMap mc, int x0, int y0, int w, int h,
+                  double *pre, double *post, uint8_t *rgba8, rt_trace_stats *stats) {
+  if (p->mode == RT_MODE_WHITTED) {
+    if (!SceneOf<T>::get(sc).surface)
+      return rt_fail(sc->ctx, RT_ERR_INVALID, "RT_MODE_WHITTED needs rt_scene_desc.shape_surface (per-shape reflectance, specular)");
+    return trace_tile_mode<T, true>(sc, p, md, mc, x0, y0, w, h, pre, post, rgba8, stats);
+  }
+  return trace_tile_mode<T, false>(sc, p, md, mc, x0, y0, w, h, pre, post, rgba8, stats);
 }
 
 // ------------------------------------------------------------------ emission

@@ -63,7 +63,8 @@ RT_D void raygen_path(const DevScene<T> &S, const PathSoA<T> &P, const TraceCfg 
 // are scalar loads and every lane spends its cycles on the distance arithmetic.
 // PRIMARY: the queue is the identity and the ray is generated in place (no ray loads); otherwise
 // the segment left by the previous shade pass is read from the path state.
-template <typename T, bool PRIMARY, bool LDS>
+// WHITTED: ray.js's scan order (equal distances go to the highest index) instead of rayphoton.js's.
+template <typename T, bool PRIMARY, bool LDS, bool WHITTED>
 __global__ void __launch_bounds__(256) k_intersect_closest(DevScene<T> S, PathSoA<T> P, TraceCfg C, uint32_t *queue, uint32_t *count_ptr) {
   extern __shared__ __align__(16) unsigned char rt_lds[];
   // device-side queue length (the grid is only an upper bound); the primary pass knows it and publishes it
@@ -81,7 +82,7 @@ __global__ void __launch_bounds__(256) k_intersect_closest(DevScene<T> S, PathSo
     o = mk<T>(P.ox[p], P.oy[p], P.oz[p]); d = mk<T>(P.dx[p], P.dy[p], P.dz[p]);
   }
   T t;
-  int idx = scan_scene<T, 0>(S, G, o, d, T(C.epsilon), T(0), t);
+  int idx = scan_scene<T, WHITTED ? 3 : 0>(S, G, o, d, T(C.epsilon), T(0), t);
   P.hit_t[p] = t; P.hit_idx[p] = idx;
 }
 
@@ -238,6 +239,111 @@ RT_D bool shade_body(const DevScene<T> &S, const ScanSrc<T> &G, const PathSoA<T>
   return alive;
 }
 
+
+// ------------------------------------------------------------------ the older tracer (ray.js:801-993)
+// stream of path p continued at draw `draw`: the key is (pixel, sub-sample)
+RT_D RngStream path_rng(uint32_t width, const TraceCfg &C, uint32_t p, uint32_t draw) {
+  const int SS = C.sub_sample * C.sub_sample;
+  const uint32_t pix = p / SS;
+  const int X = C.x0 + (int)(pix % C.w), Y = C.y0 + (int)(pix / C.w);
+  RngStream rng; rng.init(C.seed, RT_DOMAIN_RENDER, (uint32_t)(Y * (int)width + X), p % SS, draw);
+  return rng;
+}
+
+// vecPerturb of ray.js:75-100: the frame is not normalised and the lower bound is cos(pi/2)^2. 2 draws.
+template <typename T> RT_D V3<T> vec_perturb_a(V3<T> v, T eps, RngStream &rng) {
+  V3<T> m = mk<T>(1, 0, 0);
+  if (sqlen(cross(v, m)) < eps) m = mk<T>(0, 1, 0);
+  V3<T> n = cross(v, m);
+  m = cross(n, v);
+  const T cl = rt_cos(T(3.141592653589793) / T(2));
+  const T lower = cl * cl;
+  T x = (T(1) - lower) * rng.next<T>() + lower;
+  T cosT = rt_sqrt(x);
+  T sinT = rt_sqrt(T(1) - cosT * cosT);
+  T phi = two_pi<T>() * rng.next<T>();
+  return (cosT * v + (sinT * rt_cos(phi)) * m) + (sinT * rt_sin(phi)) * n;
+}
+
+// ray.js's traceRay blends at every level: colour = clamp(round((1 - refl) * shapeCol + refl * child)).
+// A path therefore leaves one record per level -- (1 - refl) * shapeCol (rgb) and refl -- in
+// levels[(level * n_paths + p) * 4 ..], ends with a terminal colour in P.out and its level count in
+// P.depth; k_resolve_a substitutes the terminal colour back up through the records.
+// Returns true when the path goes on with a new segment.
+template <typename T>
+RT_D bool shade_body_a(const DevScene<T> &S, const PathSoA<T> &P, const TraceCfg &C, T *levels, uint32_t p, T t, int idx, ShadeTally &tally) {
+  const T eps = T(C.epsilon);
+  const int level = P.depth[p];
+  T *out = P.out + (size_t)p * 4;
+  if (idx < 0 || idx >= (int)S.n_shapes) {                                       // ray.js:992 (the second test is never true)
+    out[0] = T(16); out[1] = T(16); out[2] = T(16); out[3] = T(1);
+    return false;
+  }
+  if (level < 0 || level > C.max_depth) {                                        // (never true; guards the record store)
+    out[0] = T(0); out[1] = T(0); out[2] = T(0); out[3] = T(1); tally.overflows++;
+    return false;
+  }
+  const V3<T> o = mk<T>(P.ox[p], P.oy[p], P.oz[p]), d = mk<T>(P.dx[p], P.dy[p], P.dz[p]);
+  const T max_dist = P.max_dist[p];
+  const V3<T> hit = o + t * d;
+  const V3<T> sc = shape_colour<T>(S, idx, hit);
+  const V3<T> n = shape_normal<T>(S, idx, hit);
+  const T refl = S.surface ? S.surface[2 * (size_t)idx] : Limits<T>::nan();
+  T *rec = levels + ((size_t)level * C.n_paths + p) * 4;
+  if (t < max_dist && level < C.max_depth) {                                     // ray.js:893, depth = max_depth - level
+    const T cos1 = -dot(d, n);
+    const int mat = S.meta[4 * idx + 1] & 7;
+    const bool has_mat = S.meta[4 * idx + 1] < 8;
+    RngStream rng = path_rng(S.width, C, p, P.draw[p]);
+    V3<T> ndir;
+    if (!(has_mat && S.mat[0][mat] == T(1))) {                                   // MAT_OPAQUE ray.js:895
+      if (cos1 < T(0)) {                                                         // ray.js:897-907: undefined, or black far away
+        const T v = (t < T(1e5)) ? Limits<T>::nan() : T(0);
+        out[0] = v; out[1] = v; out[2] = v; out[3] = v;
+        return false;
+      }
+      const V3<T> rdir = d + (T(2) * cos1) * n;
+      ndir = rdir;
+      if (rng.next_k() >= S.spec_gt_k[idx]) {                                    // Math.random() > specular, ray.js:910-923
+        for (int attempt = 0; attempt < 100; attempt++) {
+          ndir = vec_perturb_a<T>(rdir, eps, rng);
+          if (dot(ndir, n) > eps) break;
+          if (attempt == 99) ndir = rdir;
+        }
+      }
+    } else {                                                                     // ray.js:925-977, no Fresnel term
+      MatStack st; st.bits = P.stack[p];
+      const T eta1 = st.len() >= 1 ? S.mat[1][st.top()] : Limits<T>::nan();
+      const T eta2 = (dot(d, n) < T(0)) ? S.mat[1][mat] : (st.len() >= 2 ? S.mat[1][st.at(st.len() - 2)] : Limits<T>::nan());
+      const T ratio = eta1 / eta2;                                               // an undefined index flows on as NaN
+      const T c2sq = T(1) - ratio * ratio * (T(1) - cos1 * cos1);
+      if (c2sq < T(0)) ndir = d + (T(2) * cos1) * n;
+      else {
+        const T pm = (cos1 < T(0)) ? T(-1) : T(1);
+        ndir = ratio * d + (ratio * cos1 - pm * rt_sqrt(c2sq)) * n;
+        if (cos1 < T(0)) { if (st.len() > 0) st.pop(); }
+        else if (!st.push(mat)) tally.overflows++;
+        P.stack[p] = st.bits;
+      }
+    }
+    rec[0] = (T(1) - refl) * sc.x; rec[1] = (T(1) - refl) * sc.y; rec[2] = (T(1) - refl) * sc.z; rec[3] = refl;
+    P.depth[p] = level + 1;
+    const T imp = P.importance[p] * refl;
+    if (imp < T(0.01)) {                                                         // the child returns COL_WHITE, ray.js:845-847
+      out[0] = T(255); out[1] = T(255); out[2] = T(255); out[3] = T(1);
+      return false;
+    }
+    ndir = normalize<T>(ndir, eps);
+    P.ox[p] = hit.x; P.oy[p] = hit.y; P.oz[p] = hit.z; P.dx[p] = ndir.x; P.dy[p] = ndir.y; P.dz[p] = ndir.z;
+    P.max_dist[p] = max_dist - t; P.importance[p] = imp; P.draw[p] = rng.draw;
+    return true;
+  }
+  rec[0] = (T(1) - refl) * sc.x; rec[1] = (T(1) - refl) * sc.y; rec[2] = (T(1) - refl) * sc.z; rec[3] = refl;
+  P.depth[p] = level + 1;
+  out[0] = sc.x; out[1] = sc.y; out[2] = sc.z; out[3] = T(1);                    // transmittedColour = shapeCol, ray.js:891
+  return false;
+}
+
 RT_D void flush_tally(const ShadeTally &t, TraceCounters *ctr) {
   if (t.shadow_rays) atomicAdd(&ctr->shadow_rays, t.shadow_rays);
   if (t.gathers) atomicAdd(&ctr->gathers, t.gathers);
@@ -246,8 +352,8 @@ RT_D void flush_tally(const ShadeTally &t, TraceCounters *ctr) {
 
 // Wavefront shade pass: one traceRay body per queued path.  Survivors are recorded as one keep-mask per
 // wave plus one count per workgroup; k_scan_blocks and k_queue_scatter then build the next queue in order.
-template <typename T, bool LDS>
-__global__ void __launch_bounds__(256) k_shade(DevScene<T> S, PathSoA<T> P, TraceCfg C, DevMap Md, DevMap Mc,
+template <typename T, bool LDS, bool WHITTED>
+__global__ void __launch_bounds__(256) k_shade(DevScene<T> S, PathSoA<T> P, TraceCfg C, DevMap Md, DevMap Mc, T *levels,
                                                const uint32_t *queue, const uint32_t *count_ptr, unsigned long long *wave_mask,
                                                uint32_t *block_count, TraceCounters *ctr, int bounce) {
   extern __shared__ __align__(16) unsigned char rt_lds[];
@@ -259,8 +365,10 @@ __global__ void __launch_bounds__(256) k_shade(DevScene<T> S, PathSoA<T> P, Trac
   ShadeTally tally;
   if (i < count) {
     const uint32_t p = queue[i];
-    if (p < C.n_paths) alive = shade_body<T>(S, G, P, C, Md, Mc, p, P.hit_t[p], P.hit_idx[p], bounce, tally);
-    else tally.overflows++;                                 // (never taken; guards the indexed accesses)
+    if (p >= C.n_paths) tally.overflows++;                  // (never taken; guards the indexed accesses)
+    else if (WHITTED) alive = shade_body_a<T>(S, P, C, levels, p, P.hit_t[p], P.hit_idx[p], tally);
+    else alive = shade_body<T>(S, G, P, C, Md, Mc, p, P.hit_t[p], P.hit_idx[p], bounce, tally);
+    //                                 // (never taken; guards the indexed accesses)
   }
   block_publish_masks(alive, wave_mask, block_count);
   flush_tally(tally, ctr);
@@ -273,8 +381,8 @@ __global__ void __launch_bounds__(256) k_shade(DevScene<T> S, PathSoA<T> P, Trac
 // the index moves), and waves that are left without a path retire.  The loop is bounded by max_bounces.
 // Segments traced here are counted in ctr->tail_rays.
 #define RT_TAIL_THREADS 512
-template <typename T, bool LDS>
-__global__ void __launch_bounds__(RT_TAIL_THREADS) k_tail(DevScene<T> S, PathSoA<T> P, TraceCfg C, DevMap Md, DevMap Mc,
+template <typename T, bool LDS, bool WHITTED>
+__global__ void __launch_bounds__(RT_TAIL_THREADS) k_tail(DevScene<T> S, PathSoA<T> P, TraceCfg C, DevMap Md, DevMap Mc, T *levels,
                                                           const uint32_t *queue, const uint32_t *count_ptr, TraceCounters *ctr, int bounce0) {
   extern __shared__ __align__(16) unsigned char rt_lds[];
   __shared__ uint32_t live[2][RT_TAIL_THREADS];
@@ -298,9 +406,10 @@ __global__ void __launch_bounds__(RT_TAIL_THREADS) k_tail(DevScene<T> S, PathSoA
       if (p < C.n_paths) {                                  // (always true; guards the indexed accesses below)
         V3<T> o = mk<T>(P.ox[p], P.oy[p], P.oz[p]), d = mk<T>(P.dx[p], P.dy[p], P.dz[p]);
         T t;
-        int idx = scan_scene<T, 0>(S, G, o, d, T(C.epsilon), T(0), t);
+        int idx = scan_scene<T, WHITTED ? 3 : 0>(S, G, o, d, T(C.epsilon), T(0), t);
         rays++;
-        alive = shade_body<T>(S, G, P, C, Md, Mc, p, t, idx, b, tally);
+        if (WHITTED) alive = shade_body_a<T>(S, P, C, levels, p, t, idx, tally);
+        else alive = shade_body<T>(S, G, P, C, Md, Mc, p, t, idx, b, tally);
       } else {
         tally.overflows++;
       }
@@ -339,6 +448,48 @@ __global__ void __launch_bounds__(256) k_resolve(PathSoA<T> P, int n_pixels, int
   for (int c = 0; c < 4; c++) {
     double v = floor(tot[c] / SS);
     if (pre) pre[(size_t)pix * 4 + c] = last[c];
+    if (post) post[(size_t)pix * 4 + c] = v;
+    if (rgba8) {
+      double b = (c == 3) ? v * 255.0 : v;
+      rgba8[(size_t)pix * 4 + c] = (b == b) ? (uint8_t)(b < 0 ? 0 : (b > 255 ? 255 : b)) : 0;
+    }
+  }
+}
+
+// Pixel resolve of the older tracer (ray.js:836-841 and the blend of :979-986): substitute the terminal
+// colour back up through the path's level records, then average the sub-samples (colour() does not clamp
+// there).  A sub-sample whose trace the reference leaves undefined (ray.js:905) makes the pixel NaN.
+template <typename T>
+__global__ void __launch_bounds__(256) k_resolve_a(PathSoA<T> P, const T *levels, uint32_t n_paths, int max_depth, int n_pixels,
+                                                   int sub_sample, double *pre, double *post, uint8_t *rgba8) {
+  int pix = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pix >= n_pixels) return;
+  const int SS = sub_sample * sub_sample;
+  double tot[4] = { 0, 0, 0, 0 }, last[4] = { 0, 0, 0, 0 };
+  bool bad = false;
+  for (int s = 0; s < SS; s++) {
+    const size_t p = (size_t)pix * SS + s;
+    if (p >= n_paths) break;                                // (never true)
+    const T *o = P.out + p * 4;
+    T c[3] = { o[0], o[1], o[2] }; T a = o[3];
+    int nlev = P.depth[p];
+    nlev = nlev < 0 ? 0 : (nlev > max_depth + 1 ? max_depth + 1 : nlev);
+    for (int j = nlev - 1; j >= 0; j--) {
+      const T *rec = levels + ((size_t)j * n_paths + p) * 4;
+      for (int k = 0; k < 3; k++) {
+        T v = rt_floor((rec[k] + rec[3] * c[k]) + T(0.5));                       // Math.round
+        c[k] = v < T(0) ? T(0) : (v > T(255) ? T(255) : v);
+      }
+    }
+    if (nlev > 0) a = T(1);
+    if (!(c[0] == c[0]) || !(c[1] == c[1]) || !(c[2] == c[2])) bad = true;
+    last[0] = (double)c[0]; last[1] = (double)c[1]; last[2] = (double)c[2]; last[3] = (double)a;
+    for (int k = 0; k < 4; k++) tot[k] += last[k];
+  }
+  const double qnan = __builtin_nan("");
+  for (int c = 0; c < 4; c++) {
+    double v = bad ? qnan : floor(tot[c] / SS);
+    if (pre) pre[(size_t)pix * 4 + c] = bad ? qnan : last[c];
     if (post) post[(size_t)pix * 4 + c] = v;
     if (rgba8) {
       double b = (c == 3) ? v * 255.0 : v;

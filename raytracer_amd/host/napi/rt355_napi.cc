@@ -130,6 +130,7 @@ static napi_value SceneUpload(napi_env env, napi_callback_info info) {
   const double *mats = (const double *)prop_typed(env, f, "materials", napi_float64_array, &n);
   if (!mats || n != 32) { napi_throw_type_error(env, nullptr, "flat.materials must be a Float64Array(32)"); return nullptr; }
   memcpy(d.materials, mats, sizeof d.materials);
+  d.shape_surface = (const double *)prop_typed(env, f, "shapeSurface", napi_float64_array, &n);   // ray.js shape model, optional
   rt_scene *sc = nullptr;
   int rc = rt_scene_upload(ctx, &d, &sc);
   if (rc != RT_OK) return fail(env, ctx, rc);

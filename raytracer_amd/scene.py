@@ -22,7 +22,7 @@ import numpy as np
 
 PLANE, SPHERE, HEMISPHERE, CYLINDER, TRIANGLE, SQUARE, DISC, ANNULUS = range(8)
 TYPE_NAMES = ["plane", "sphere", "hemisphere", "cylinder", "triangle", "square", "disc", "annulus"]
-FLAG_CONVEX, FLAG_LIGHT, FLAG_TRUNC_MAX, FLAG_HALF_HEIGHT = 1, 2, 4, 8
+FLAG_CONVEX, FLAG_LIGHT, FLAG_TRUNC_MAX, FLAG_HALF_HEIGHT, FLAG_FIRST_ROOT = 1, 2, 4, 8, 16
 MAT_AIR, MAT_GLASS, MAT_WATER, MAT_MIRROR, MAT_COPPER, MAT_LINOLEUM, MAT_PLASTER, MAT_SPECTRALON = range(8)
 MAT_NONE = 255
 
@@ -51,6 +51,7 @@ class FlatScene:
     width: int
     height: int
     materials: np.ndarray = field(default_factory=lambda: DEFAULT_MATERIALS.copy())
+    shape_surface: np.ndarray | None = None   # (n, 2) per-shape reflectance, specular (ray.js scenes) or None
 
     @property
     def n_shapes(self) -> int:
@@ -67,6 +68,7 @@ class FlatScene:
         assert self.shape_colour.dtype == np.float64 and self.shape_colour.shape == (n, 4)
         assert self.light_shape.dtype == np.uint32
         assert self.light_data.shape == (self.n_lights, 8)
+        assert self.shape_surface is None or self.shape_surface.shape == (n, 2)
         assert self.camera.shape == (16,) and self.materials.shape == (4, 8)
         assert (self.shape_meta[:, 0] < 8).all(), "unknown primitive type"
         for l in self.light_shape:
@@ -77,7 +79,7 @@ class FlatScene:
         cam = self.camera.copy()
         cam[13] = cam[12] * height / width
         return FlatScene(self.shape_meta, self.shape_geom, self.shape_colour, self.light_shape,
-                         self.light_data, cam, width, height, self.materials)
+                         self.light_data, cam, width, height, self.materials, self.shape_surface)
 
     @classmethod
     def from_flat(cls, d: dict) -> "FlatScene":
@@ -106,7 +108,10 @@ class FlatScene:
         else:
             materials = np.array([[_nan(x) for x in m[k]] for k in
                                   ("transparent", "refrIndex", "reflectance", "specular")], np.float64)
-        sc = cls(meta, geom, colour, light_shape, light_data, camera, int(d["width"]), int(d["height"]), materials)
+        surface = None
+        if shapes and "reflectance" in shapes[0]:
+            surface = np.array([[_nan(s_.get("reflectance")), _nan(s_.get("specular"))] for s_ in shapes], np.float64)
+        sc = cls(meta, geom, colour, light_shape, light_data, camera, int(d["width"]), int(d["height"]), materials, surface)
         sc.validate()
         return sc
 

@@ -31,3 +31,12 @@ def load_scene(preset, width=None, height=None):
     if width is not None:
         sc = sc.with_size(width, height)
     return sc
+
+
+def load_rayjs_scene(preset):
+    """flattened ray.js preset (mode A): carries per-shape reflectance/specular"""
+    from raytracer_amd.scene import FlatScene
+    return FlatScene.from_json(os.path.join(GOLDEN, f"scene_rayjs{preset}_flat.json"))
+
+
+RAYJS_PARAMS = dict(max_trace_dist=100.0, max_depth=20, sub_sample=1)      # ray.js:8-12

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_struct_layouts():
-    assert C.sizeof(capi.SceneDesc) == 8 + 3 * 8 + 8 + 2 * 8 + 16 * 8 + 8 + 32 * 8
+    assert C.sizeof(capi.SceneDesc) == 8 + 3 * 8 + 8 + 2 * 8 + 16 * 8 + 8 + 32 * 8 + 8
     assert C.sizeof(capi.Params) == 104
     assert C.sizeof(capi.TraceStats) == 48 and C.sizeof(capi.EmitStats) == 40
     p = capi.default_params()

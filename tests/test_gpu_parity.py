@@ -7,7 +7,7 @@ boundaries."""
 import numpy as np
 import pytest
 
-from golden_io import load_bundle, load_scene
+from golden_io import RAYJS_PARAMS, load_bundle, load_rayjs_scene, load_scene
 from oracle import oracle as ora
 
 pytestmark = pytest.mark.gpu
@@ -366,3 +366,46 @@ def test_sharded_protocol_on_gpu_equals_emit_many(c1_emit):
     assert same(res["diffuse"], whole["diffuse"]) and same(res["caustic"], whole["caustic"])
     assert np.array_equal(res["diffuse_attempt"], whole["diffuse_attempt"])
     assert res["attempts1"] == whole["stats"]["attempts_phase1"] and res["attempts2"] == whole["stats"]["attempts_phase2"]
+
+
+# ------------------------------------------------------------------ mode A: the older tracer (ray.js)
+@pytest.mark.parametrize("preset,rays", [(2, 52993), (3, 59233), (0, 58604)])
+def test_image_mode_a_f64_matches_reference(rt, preset, rays, monkeypatch):
+    capi, ctx = rt
+    g = load_bundle(f"image_rayjs{preset}")
+    sc = ctx.upload(load_rayjs_scene(preset))
+    p = capi.default_params(precision=capi.PRECISION_F64, mode=capi.MODE_WHITTED, seed=g.meta["seed"], **RAYJS_PARAMS)
+    out = sc.trace_tile(p)
+    assert same(out["pre"], g["rgba"]) and same(out["post"], g["rgba"])
+    assert out["stats"]["rays"] == rays and out["stats"]["stack_overflows"] == 0
+    # the same frame with every bounce as a wavefront pass (no tail kernel), and as two tiles
+    monkeypatch.setenv("RT355_TAIL_THRESHOLD", "0")
+    wave = sc.trace_tile(p)
+    assert same(wave["pre"], g["rgba"]) and wave["stats"]["tail_rays"] == 0 and wave["stats"]["rays"] == rays
+    monkeypatch.delenv("RT355_TAIL_THRESHOLD")
+    H = g.meta["H"]
+    top, bot = sc.trace_tile(p, h=50), sc.trace_tile(p, y0=50, h=H - 50)
+    assert same(np.concatenate([top["pre"], bot["pre"]]), g["rgba"])
+
+
+def test_image_mode_a_f32_and_subsamples(rt):
+    capi, ctx = rt
+    g = load_bundle("image_rayjs2")
+    flat = load_rayjs_scene(2)
+    sc = ctx.upload(flat)
+    p = capi.default_params(precision=capi.PRECISION_F32, mode=capi.MODE_WHITTED, seed=g.meta["seed"], **RAYJS_PARAMS)
+    out = sc.trace_tile(p, want=("pre", "rgba8"))
+    # stated tolerance: within 1e-3*255 (+ the unit step of Math.round) on >= 99 % of pixels; diffuse bounces
+    # that take another discrete branch in fp32 make up the rest
+    err = np.abs(out["pre"][..., :3] - g["rgba"][..., :3]).max(axis=-1)
+    assert (err <= 1.0 + 1e-3 * 255).mean() >= 0.99, (err <= 1.26).mean()
+    assert np.array_equal(out["rgba8"][..., :3], np.nan_to_num(out["pre"][..., :3]).astype(np.uint8))
+    # 2x2 sub-samples against the oracle
+    p2 = capi.default_params(precision=capi.PRECISION_F64, mode=capi.MODE_WHITTED, seed=5, **{**RAYJS_PARAMS, "sub_sample": 2})
+    got = sc.trace_tile(p2, x0=40, y0=30, w=64, h=48)
+    op = ora.params(seed=5, **{**RAYJS_PARAMS, "sub_sample": 2})
+    _, post, rays = ora.render_whitted(ora.Scene(flat), op, 40, 30, 64, 48)
+    assert same(got["post"], post) and got["stats"]["rays"] == rays
+    # a scene without the per-shape surface table cannot be traced in this mode
+    with pytest.raises(capi.RtError):
+        ctx.upload(load_scene(10, 64, 48)).trace_tile(p)

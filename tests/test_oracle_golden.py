@@ -3,7 +3,7 @@ itself (oracle/harness/gen_golden.js -> tests/golden/).  CPU only."""
 import numpy as np
 import pytest
 
-from golden_io import load_bundle, load_scene
+from golden_io import RAYJS_PARAMS, load_bundle, load_rayjs_scene, load_scene
 from oracle import oracle as ora
 
 SEED = 12345
@@ -141,3 +141,14 @@ def test_image_c1_mode_b(c1_emission):
     assert same(pre, want_pre)          # every pixel, bit for bit (fp64, same operation order)
     assert same(post, want_post)
     assert rays > W * H
+
+
+@pytest.mark.parametrize("preset,rays", [(2, 52993), (3, 59233), (0, 58604)])
+def test_image_mode_a_whitted(preset, rays):
+    """the older tracer (ray.js:801-993): every pixel of three presets, bit for bit"""
+    g = load_bundle(f"image_rayjs{preset}")
+    osc = ora.Scene(load_rayjs_scene(preset))
+    op = ora.params(seed=g.meta["seed"], **RAYJS_PARAMS)
+    raw, post, n = ora.render_whitted(osc, op, 0, 0, g.meta["W"], g.meta["H"])
+    assert same(raw, g["rgba"]) and n == rays
+    assert same(post, g["rgba"])                 # one sub-sample: putPixel gets floor(colour / 1)
