@@ -120,13 +120,52 @@ int rt_profile_get(rt_ctx *ctx, const char *kernel, double *total_ms, uint64_t *
 }
 
 // ------------------------------------------------------------------ scene
+// fp32 scan record of one primitive (layout: rt_geom.h), computed in fp64 from the boundary's geometry slots
+static void rt_fast_record(int type, int flags, const double *g, float *f) {
+  const double INF = __builtin_huge_val();
+  auto dot = [](const double *a, const double *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; };
+  auto cross = [](const double *a, const double *b, double *r) {
+    r[0] = a[1] * b[2] - a[2] * b[1]; r[1] = a[2] * b[0] - a[0] * b[2]; r[2] = a[0] * b[1] - a[1] * b[0];
+  };
+  double r[12] = { 0 };
+  switch (type) {
+    case RT_PLANE: r[0] = g[3]; r[1] = g[4]; r[2] = g[5]; r[3] = dot(g, g + 3); break;
+    case RT_SPHERE: r[0] = g[0]; r[1] = g[1]; r[2] = g[2]; r[3] = g[6] * g[6]; break;
+    case RT_HEMISPHERE:
+      r[0] = g[0]; r[1] = g[1]; r[2] = g[2]; r[3] = g[6] * g[6]; r[4] = g[3]; r[5] = g[4]; r[6] = g[5];
+      r[7] = g[7]; r[8] = (flags & RT_FLAG_TRUNC_MAX) ? g[8] : INF; break;
+    case RT_CYLINDER:
+      r[0] = g[0]; r[1] = g[1]; r[2] = g[2]; r[3] = g[6] * g[6]; r[4] = g[3]; r[5] = g[4]; r[6] = g[5];
+      r[7] = (flags & RT_FLAG_HALF_HEIGHT) ? g[7] : INF; break;
+    case RT_TRIANGLE: case RT_SQUARE: {
+      const double *A = g, *AB = g + 3, *AC = g + 6;
+      double N[3], n2[3], u[3], v[3];
+      cross(AC, AB, N); cross(AB, AC, n2);
+      cross(AC, n2, u); cross(n2, AB, v);
+      const double su = dot(AB, u), sv = dot(AC, v);
+      for (int k = 0; k < 3; k++) { r[k] = N[k]; r[4 + k] = u[k] / su; r[8 + k] = v[k] / sv; }
+      r[3] = dot(A, N); r[7] = dot(A, r + 4); r[11] = dot(A, r + 8); break;
+    }
+    default:                                                  // disc, annulus
+      r[0] = g[3]; r[1] = g[4]; r[2] = g[5]; r[3] = dot(g, g + 3); r[4] = g[0]; r[5] = g[1]; r[6] = g[2];
+      r[7] = g[6] * g[6]; r[8] = (type == RT_ANNULUS) ? g[7] * g[7] : 0.0; break;
+  }
+  for (int k = 0; k < 12; k++) f[k] = (float)r[k];
+}
+
 template <typename T> static int upload_typed(rt_ctx *ctx, const rt_scene_desc *d, const std::vector<uint32_t> &order, DevMem &geom,
                                               DevMem &colour, DevMem &sgeom, DevMem &surface, DevScene<T> &S, rt_scene *sc) {
   const uint32_t n = d->n_shapes;
   std::vector<T> g((size_t)n * 12), c((size_t)n * 4), sg((size_t)n * 12);
   for (size_t i = 0; i < (size_t)n * 12; i++) g[i] = (T)d->shape_geom[i];
   for (size_t i = 0; i < (size_t)n * 4; i++) c[i] = (T)d->shape_colour[i];
-  for (uint32_t s = 0; s < n; s++) for (int k = 0; k < 12; k++) sg[(size_t)s * 12 + k] = g[(size_t)order[s] * 12 + k];
+  for (uint32_t s = 0; s < n; s++) {
+    const uint32_t i = order[s];
+    if (sizeof(T) == 4)           // the fp32 build scans precomputed records instead of the raw geometry slots
+      rt_fast_record(d->shape_meta[4 * i], d->shape_meta[4 * i + 2], d->shape_geom + (size_t)i * 12, (float *)&sg[(size_t)s * 12]);
+    else
+      for (int k = 0; k < 12; k++) sg[(size_t)s * 12 + k] = g[(size_t)i * 12 + k];
+  }
   RT_HIP(ctx, geom.alloc(g.size() * sizeof(T))); RT_HIP(ctx, colour.alloc(c.size() * sizeof(T))); RT_HIP(ctx, sgeom.alloc(sg.size() * sizeof(T)));
   RT_HIP(ctx, hipMemcpy(geom.p, g.data(), g.size() * sizeof(T), hipMemcpyHostToDevice));
   RT_HIP(ctx, hipMemcpy(colour.p, c.data(), c.size() * sizeof(T), hipMemcpyHostToDevice));

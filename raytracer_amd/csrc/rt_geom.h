@@ -150,26 +150,169 @@ template <typename T> RT_D T isect_any_type(V3<T> o, V3<T> d, int type, int flag
   return miss<T>();
 }
 
+// ------------------------------------------------------------------ fp32 scan records
+// The fp32 build does not follow the reference's operation order (it is held to a tolerance, not to bit
+// parity), so its scans read per-primitive records that the host precomputes in fp64 (rt_fast_record in
+// rt_api.hip) and evaluate a shorter, branch-free form of every test:
+//   plane     n[0-2]  k = a.n [3]
+//   sphere    c[0-2]  r^2 [3]
+//   hemisphere c[0-2] r^2 [3]  n[4-6]  truncMin [7]  truncMax or +inf [8]
+//   cylinder  c[0-2]  r^2 [3]  axis[4-6]  halfHeight or +inf [7]
+//   triangle / square   N = AC x AB [0-2]  A.N [3]  U*[4-6]  A.U* [7]  V*[8-10]  A.V* [11]
+//             (U*, V*: the in-plane dual basis of AB, AC, so that u = (P - A).U*, v = (P - A).V*)
+//   disc / annulus      n[0-2]  c.n [3]  c[4-6]  outer^2 [7]  inner^2 [8]
+// Everything that depends on the ray origin only ("origin terms", RT_OT_STRIDE floats per primitive) is
+// split off: secondary rays compute it per test, the primary pass -- where every ray starts at the camera --
+// computes it once per workgroup into LDS.
+#define RT_OT_STRIDE 5
+
+RT_D float rcp_fast(float x) { return __builtin_amdgcn_rcpf(x); }
+RT_D float sqrt_fast(float x) { return __builtin_amdgcn_sqrtf(x); }       // NaN for x < 0: the caller's compares reject it
+RT_D float dot3(const float *f, V3<float> v) { return f[0] * v.x + f[1] * v.y + f[2] * v.z; }
+
+template <int TYPE> RT_D void origin_terms(const float *f, V3<float> o, float *ot) {
+  if (TYPE == RT_PLANE) {
+    ot[0] = f[3] - dot3(f, o);
+  } else if (TYPE == RT_SPHERE || TYPE == RT_HEMISPHERE) {
+    V3<float> oc = o - ld3(f);
+    ot[0] = oc.x; ot[1] = oc.y; ot[2] = oc.z; ot[3] = sqlen(oc) - f[3];
+    if (TYPE == RT_HEMISPHERE) ot[4] = dot3(f + 4, oc);
+  } else if (TYPE == RT_CYLINDER) {
+    V3<float> v = o - ld3(f);
+    float va = dot3(f + 4, v);
+    ot[0] = v.x; ot[1] = v.y; ot[2] = v.z; ot[3] = va; ot[4] = sqlen(v) - va * va - f[3];
+  } else if (TYPE == RT_TRIANGLE || TYPE == RT_SQUARE) {
+    ot[0] = f[3] - dot3(f, o); ot[1] = dot3(f + 4, o) - f[7]; ot[2] = dot3(f + 8, o) - f[11];
+  } else {                                                  // disc, annulus
+    V3<float> oc = o - ld3(f + 4);
+    ot[0] = f[3] - dot3(f, o); ot[1] = oc.x; ot[2] = oc.y; ot[3] = oc.z;
+  }
+}
+RT_D void origin_terms_any(int type, const float *f, V3<float> o, float *ot) {
+  switch (type) {
+    case RT_PLANE: origin_terms<RT_PLANE>(f, o, ot); break;
+    case RT_SPHERE: origin_terms<RT_SPHERE>(f, o, ot); break;
+    case RT_HEMISPHERE: origin_terms<RT_HEMISPHERE>(f, o, ot); break;
+    case RT_CYLINDER: origin_terms<RT_CYLINDER>(f, o, ot); break;
+    case RT_TRIANGLE: case RT_SQUARE: origin_terms<RT_SQUARE>(f, o, ot); break;
+    default: origin_terms<RT_DISC>(f, o, ot); break;
+  }
+}
+
+// distance along direction d, or a value that fails `t > eps` (-1 or NaN) on a miss
+template <int TYPE> RT_D float isect_fast(const float *f, const float *ot, V3<float> d, float eps, int flags) {
+  const float MISS = -1.0f;
+  if (TYPE == RT_PLANE) {
+    float dn = dot3(f, d);
+    float t = ot[0] * rcp_fast(dn);
+    return fabsf(dn) < eps ? MISS : t;
+  } else if (TYPE == RT_SPHERE) {
+    float hb = d.x * ot[0] + d.y * ot[1] + d.z * ot[2];
+    float sq = sqrt_fast(hb * hb - ot[3]);
+    float t0 = -hb - sq, t1 = -hb + sq;
+    return t0 > eps ? t0 : t1;
+  } else if (TYPE == RT_HEMISPHERE) {
+    float hb = d.x * ot[0] + d.y * ot[1] + d.z * ot[2];
+    float sq = sqrt_fast(hb * hb - ot[3]);
+    float t0 = -hb - sq, t1 = -hb + sq;
+    float dn = dot3(f + 4, d);
+    float p0 = ot[4] + t0 * dn, p1 = ot[4] + t1 * dn;
+    bool ok0 = t0 > eps && p0 > f[7] && p0 < f[8];
+    bool ok1 = t1 > eps && p1 > f[7] && p1 < f[8];
+    return ok0 ? t0 : (ok1 ? t1 : MISS);
+  } else if (TYPE == RT_CYLINDER) {
+    float da = dot3(f + 4, d);
+    float vd = d.x * ot[0] + d.y * ot[1] + d.z * ot[2];
+    float a = 1.0f - da * da;
+    float hb = vd - ot[3] * da;
+    float sq = sqrt_fast(hb * hb - a * ot[4]);
+    float ia = rcp_fast(a);
+    float t0 = (-hb - sq) * ia, t1 = (-hb + sq) * ia;
+    if (flags & RT_FLAG_FIRST_ROOT) return (a == 0.0f || !(t0 > 0.0f)) ? MISS : t0;     // wave-uniform branch
+    float hlim = f[7] - eps;
+    bool ok0 = t0 > eps && fabsf(ot[3] + t0 * da) < hlim;
+    bool ok1 = t1 > eps && fabsf(ot[3] + t1 * da) < hlim;
+    float t = ok0 ? t0 : (ok1 ? t1 : MISS);
+    return a == 0.0f ? MISS : t;
+  } else if (TYPE == RT_TRIANGLE || TYPE == RT_SQUARE) {
+    float dN = dot3(f, d);
+    float t = ot[0] * rcp_fast(dN);
+    float u = ot[1] + t * dot3(f + 4, d), v = ot[2] + t * dot3(f + 8, d);
+    bool ok = !(fabsf(dN) < eps) && u >= 0.0f && u <= 1.0f && v >= 0.0f && (TYPE == RT_SQUARE ? v <= 1.0f : u + v <= 1.0f);
+    return ok ? t : MISS;
+  } else {                                                  // disc, annulus
+    float dn = dot3(f, d);
+    float t = ot[0] * rcp_fast(dn);
+    float hx = ot[1] + t * d.x, hy = ot[2] + t * d.y, hz = ot[3] + t * d.z;
+    float rSq = hx * hx + hy * hy + hz * hz;
+    bool ok = !(fabsf(dn) < eps) && rSq + eps < f[7];
+    if (TYPE == RT_ANNULUS) ok = ok && rSq - eps > f[8];
+    return ok ? t : MISS;
+  }
+}
+
 // Where a scan reads the type-sorted primitives from: the scene's global arrays (the primitive index
-// is wave-uniform, so these become scalar loads) or a copy the workgroup staged in LDS.
-template <typename T> struct ScanSrc { const T *geom; const uint32_t *orig; const uint32_t *flags; };
+// is wave-uniform, so these become scalar loads) or a copy the workgroup staged in LDS.  `ot`: staged
+// origin terms of the fp32 records for the one origin all rays of the workgroup share, or nullptr.
+template <typename T> struct ScanSrc { const T *geom; const uint32_t *orig; const uint32_t *flags; const T *ot; };
 
 // LDS bytes needed to stage n primitives
-template <typename T> constexpr size_t scan_lds_bytes(uint32_t n) { return (size_t)n * (RT_GEOM_STRIDE * sizeof(T) + 8); }
+template <typename T> constexpr size_t scan_lds_bytes(uint32_t n) {
+  return (size_t)n * (RT_GEOM_STRIDE * sizeof(T) + 8 + (sizeof(T) == 4 ? RT_OT_STRIDE * 4 : 0));
+}
 
 // Cooperative, coalesced copy of the type-sorted scene into LDS (all threads of the block must call it).
-template <typename T> RT_D ScanSrc<T> stage_scene_lds(const DevScene<T> &S, void *lds) {
+// With `origin` (fp32 only) the origin terms of every primitive are staged behind it.
+template <typename T> RT_D ScanSrc<T> stage_scene_lds(const DevScene<T> &S, void *lds, const V3<T> *origin = nullptr) {
   T *lg = (T *)lds;
   uint32_t *lo = (uint32_t *)(lg + (size_t)S.n_shapes * RT_GEOM_STRIDE), *lf = lo + S.n_shapes;
   for (uint32_t i = threadIdx.x; i < S.n_shapes * RT_GEOM_STRIDE; i += blockDim.x) lg[i] = S.sgeom[i];
   for (uint32_t i = threadIdx.x; i < S.n_shapes; i += blockDim.x) { lo[i] = S.sorig[i]; lf[i] = S.sflags32[i]; }
+  ScanSrc<T> G; G.geom = lg; G.orig = lo; G.flags = lf; G.ot = nullptr;
+  if constexpr (sizeof(T) == 4) {
+    if (origin) {
+      float *lt = (float *)(lf + S.n_shapes);
+      for (uint32_t i = threadIdx.x; i < S.n_shapes; i += blockDim.x) {
+        int type = 0;
+        while (type < RT_NUM_TYPES - 1 && i >= S.seg[type + 1]) type++;
+        origin_terms_any(type, S.sgeom + (size_t)i * RT_GEOM_STRIDE, *origin, lt + (size_t)i * RT_OT_STRIDE);
+      }
+      G.ot = lt;
+    }
+  }
   __syncthreads();
-  ScanSrc<T> G; G.geom = lg; G.orig = lo; G.flags = lf;
   return G;
 }
 template <typename T> RT_D ScanSrc<T> global_scan_src(const DevScene<T> &S) {
-  ScanSrc<T> G; G.geom = S.sgeom; G.orig = S.sorig; G.flags = S.sflags32;
+  ScanSrc<T> G; G.geom = S.sgeom; G.orig = S.sorig; G.flags = S.sflags32; G.ot = nullptr;
   return G;
+}
+
+// fp32 scan over the precomputed records; same MODEs as scan_scene below.  Equal distances keep the first
+// primitive in type-sorted order.
+template <int MODE, bool OT> RT_D int scan_fast(const DevScene<float> &S, const ScanSrc<float> &G, V3<float> o, V3<float> d, float eps, float limit, float &t_out) {
+  float best = __builtin_huge_valf(); int best_s = -1;
+  const float lim = (MODE == 2) ? limit - eps : 0.0f;
+  bool occluded = false;
+#define RT_FAST_LOOP(TYPE)                                                                              \
+  _Pragma("unroll 2")                                                                                   \
+  for (uint32_t s = S.seg[TYPE]; s < S.seg[TYPE + 1]; s++) {                                            \
+    const float *f = G.geom + (size_t)s * RT_GEOM_STRIDE;                                               \
+    const int flags = (MODE == 1 || MODE == 2 || TYPE == RT_CYLINDER) ? (int)G.flags[s] : 0;            \
+    if ((MODE == 1 || MODE == 2) && (flags & RT_FLAG_LIGHT)) continue;                                  \
+    float otl[RT_OT_STRIDE];                                                                            \
+    const float *ot = otl;                                                                              \
+    if (OT) ot = G.ot + (size_t)s * RT_OT_STRIDE; else origin_terms<TYPE>(f, o, otl);                   \
+    const float t = isect_fast<TYPE>(f, ot, d, eps, flags);                                             \
+    if (MODE == 2) occluded = occluded || (t > eps && t < lim);                                         \
+    else { const bool upd = t > eps && t < best; best = upd ? t : best; best_s = upd ? (int)s : best_s; } \
+  }
+  RT_FAST_LOOP(RT_PLANE) RT_FAST_LOOP(RT_SPHERE) RT_FAST_LOOP(RT_HEMISPHERE) RT_FAST_LOOP(RT_CYLINDER)
+  RT_FAST_LOOP(RT_TRIANGLE) RT_FAST_LOOP(RT_SQUARE) RT_FAST_LOOP(RT_DISC) RT_FAST_LOOP(RT_ANNULUS)
+#undef RT_FAST_LOOP
+  if (MODE == 2) { t_out = 0.0f; return occluded ? 1 : 0; }
+  t_out = best;
+  return best_s >= 0 ? (int)G.orig[best_s] : -1;
 }
 
 // Scan all primitives in type-sorted order.  MODE 0: closest incl. lights (rayphoton.js:1642-1650),
@@ -177,7 +320,9 @@ template <typename T> RT_D ScanSrc<T> global_scan_src(const DevScene<T> &S) {
 // (:1853-1857).  The reference scans in index order and keeps the first of equal distances
 // (strict `<`), so ties go to the lowest original index here too.  MODE 3: closest incl. lights with ties going
 // to the HIGHEST index, for ray.js, which scans in descending index order (ray.js:863).
-template <typename T, int MODE> RT_D int scan_scene(const DevScene<T> &S, const ScanSrc<T> &G, V3<T> o, V3<T> d, T eps, T limit, T &t_out) {
+// OT (fp32 only): G.ot holds the origin terms of `o`, staged by stage_scene_lds.
+template <typename T, int MODE, bool OT = false> RT_D int scan_scene(const DevScene<T> &S, const ScanSrc<T> &G, V3<T> o, V3<T> d, T eps, T limit, T &t_out) {
+  if constexpr (sizeof(T) == 4) return scan_fast<MODE, OT>(S, G, o, d, eps, limit, t_out);
   T best = Limits<T>::inf(); int best_idx = -1;
   const T lim = (MODE == 2) ? limit - eps : T(0);
 #define RT_SCAN_LOOP(TYPE, EXPR)                                                        \

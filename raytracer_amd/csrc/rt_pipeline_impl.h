@@ -87,7 +87,9 @@ template <typename T> static PathSoA<T> carve_paths(void *base, size_t n, size_t
   return P;
 }
 
-template <typename T, bool WHITTED>
+// WHITTED: the older tracer (ray.js).  FULL: direct light and/or photon gathers are on (otherwise kernels with those
+// terms compiled out run: fewer registers, more waves in flight).
+template <typename T, bool WHITTED, bool FULL>
 static int trace_tile_mode(rt_scene *sc, const rt_params *p, DevMap md, DevMap mc, int x0, int y0, int w, int h,
                            double *pre, double *post, uint8_t *rgba8, rt_trace_stats *stats) {
   rt_ctx *ctx = sc->ctx;
@@ -127,52 +129,50 @@ static int trace_tile_mode(rt_scene *sc, const rt_params *p, DevMap md, DevMap m
   RT_HIP(ctx, sc->ws_blocks.reserve(((size_t)max_blocks + 1) * 4));
   unsigned long long *wave_mask = sc->ws_masks.as<unsigned long long>();
   uint32_t *block_count = sc->ws_blocks.as<uint32_t>();
-  uint32_t *counts = ctr->counts;                           // counts[b] = queue length of wavefront pass b (device side)
+  uint32_t *counts = ctr->counts;                           // counts[b] = queue length of pass b (device side)
   const bool lds = scene_fits_lds<T>(S.n_shapes);
   const size_t smem = lds ? scan_lds_bytes<T>(S.n_shapes) : 0;
-  // Wide bounces run as wavefront passes (intersect_closest, shade, ordered compaction of the survivors);
-  // once at most tail_threshold paths are left, one k_tail launch follows each of them to its end.
-  // Queue lengths live on the device; a launch's grid is only an upper bound, so the host reads a
-  // length back only when it needs one to choose the next step (never for tiles <= tail_threshold).
-  uint32_t tail_threshold = 1u << 19;
+  constexpr bool SHADE_SCANS = FULL && !WHITTED;            // only directLight's shadow rays scan primitives while shading
+  // The first pass (k_primary) is fused.  Wide later bounces run as wavefront passes (intersect_closest, shade,
+  // ordered compaction of the survivors); once at most tail_threshold paths are left, one k_tail launch follows
+  // each of them to its end.  Queue lengths live on the device; a launch's grid is only an upper bound, so the
+  // host reads a length back only when it needs one to choose the next step.
+  uint32_t tail_threshold = 1u << 21;
   if (const char *e = getenv("RT355_TAIL_THRESHOLD")) tail_threshold = (uint32_t)strtoul(e, nullptr, 10);
   uint32_t ub = (uint32_t)n_paths;                          // upper bound of the current queue length
-  bool ub_exact = true;
   uint32_t wave_bounces = 0;
   for (;;) {
     const uint32_t blocks = div_up(ub, 256);
     uint32_t *cnt = counts + wave_bounces;
     if ((wave_bounces > 0 && ub <= tail_threshold) || wave_bounces >= RT_MAX_WAVE_BOUNCES) {
       const uint32_t tblocks = div_up(ub, RT_TAIL_THREADS);
-      if (lds) RT_LAUNCH_SMEM(ctx, "tail", (k_tail<T, true, WHITTED>), tblocks, RT_TAIL_THREADS, smem, S, P, C, md, mc, levels, q_cur, cnt, ctr, (int)wave_bounces);
-      else RT_LAUNCH_SMEM(ctx, "tail", (k_tail<T, false, WHITTED>), tblocks, RT_TAIL_THREADS, 0, S, P, C, md, mc, levels, q_cur, cnt, ctr, (int)wave_bounces);
+      if (lds) RT_LAUNCH_SMEM(ctx, "tail", (k_tail<T, true, WHITTED, FULL>), tblocks, RT_TAIL_THREADS, smem, S, P, C, md, mc, levels, q_cur, cnt, ctr, (int)wave_bounces);
+      else RT_LAUNCH_SMEM(ctx, "tail", (k_tail<T, false, WHITTED, FULL>), tblocks, RT_TAIL_THREADS, 0, S, P, C, md, mc, levels, q_cur, cnt, ctr, (int)wave_bounces);
       break;
     }
     if (wave_bounces == 0) {
-      if (lds) RT_LAUNCH_SMEM(ctx, "intersect_closest", (k_intersect_closest<T, true, true, WHITTED>), blocks, 256, smem, S, P, C, q_cur, cnt);
-      else RT_LAUNCH_SMEM(ctx, "intersect_closest", (k_intersect_closest<T, true, false, WHITTED>), blocks, 256, 0, S, P, C, q_cur, cnt);
+      if (lds) RT_LAUNCH_SMEM(ctx, "primary", (k_primary<T, true, WHITTED, FULL>), blocks, 256, smem, S, P, C, md, mc, levels, q_cur, cnt, wave_mask, block_count, ctr);
+      else RT_LAUNCH_SMEM(ctx, "primary", (k_primary<T, false, WHITTED, FULL>), blocks, 256, 0, S, P, C, md, mc, levels, q_cur, cnt, wave_mask, block_count, ctr);
     } else {
-      if (lds) RT_LAUNCH_SMEM(ctx, "intersect_closest", (k_intersect_closest<T, false, true, WHITTED>), blocks, 256, smem, S, P, C, q_cur, cnt);
-      else RT_LAUNCH_SMEM(ctx, "intersect_closest", (k_intersect_closest<T, false, false, WHITTED>), blocks, 256, 0, S, P, C, q_cur, cnt);
+      if (lds) RT_LAUNCH_SMEM(ctx, "intersect_closest", (k_intersect_closest<T, true, WHITTED>), blocks, 256, smem, S, P, C, q_cur, cnt);
+      else RT_LAUNCH_SMEM(ctx, "intersect_closest", (k_intersect_closest<T, false, WHITTED>), blocks, 256, 0, S, P, C, q_cur, cnt);
+      if (lds && SHADE_SCANS && C.use_direct_light)
+        RT_LAUNCH_SMEM(ctx, "shade", (k_shade<T, true, WHITTED, FULL>), blocks, 256, smem, S, P, C, md, mc, levels, q_cur, cnt, wave_mask, block_count, ctr, (int)wave_bounces);
+      else
+        RT_LAUNCH_SMEM(ctx, "shade", (k_shade<T, false, WHITTED, FULL>), blocks, 256, 0, S, P, C, md, mc, levels, q_cur, cnt, wave_mask, block_count, ctr, (int)wave_bounces);
     }
-    if (lds && C.use_direct_light && !WHITTED)      // only the shadow-ray scans of directLight read primitives in this pass
-      RT_LAUNCH_SMEM(ctx, "shade", (k_shade<T, true, WHITTED>), blocks, 256, smem, S, P, C, md, mc, levels, q_cur, cnt, wave_mask, block_count, ctr, (int)wave_bounces);
-    else
-      RT_LAUNCH_SMEM(ctx, "shade", (k_shade<T, false, WHITTED>), blocks, 256, 0, S, P, C, md, mc, levels, q_cur, cnt, wave_mask, block_count, ctr, (int)wave_bounces);
     RT_LAUNCH(ctx, "queue_scan", k_scan_blocks, 1, 1024, block_count, blocks, counts + wave_bounces + 1, cnt);
     RT_LAUNCH(ctx, "queue_scatter", k_queue_scatter, blocks, 256, q_cur, cnt, wave_mask, block_count, q_nxt);
     wave_bounces++;
     std::swap(q_cur, q_nxt);
-    ub_exact = false;
-    // the first two passes of a large frame are launched blind; after that a length is worth a round trip
+    // the first pass of a large frame is followed blind; after that a length is worth a round trip
     if (ub > tail_threshold && wave_bounces >= 2) {
       RT_HIP(ctx, hipMemcpyAsync(ctx->pinned, counts + wave_bounces, 4, hipMemcpyDeviceToHost, ctx->stream));
       RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-      ub = ctx->pinned[0]; ub_exact = true;
+      ub = ctx->pinned[0];
       if (ub == 0) break;
     }
   }
-  (void)ub_exact;
   if (WHITTED)
     RT_LAUNCH(ctx, "resolve", k_resolve_a<T>, div_up(n_pixels, 256), 256, P, levels, (uint32_t)n_paths, (int)p->max_depth, (int)n_pixels,
               (int)p->sub_sample, pre, post, rgba8);
@@ -199,9 +199,11 @@ int pl_trace_tile(rt_scene *sc, const rt_params *p, DevMap md, DevMap mc, int x0
   if (p->mode == RT_MODE_WHITTED) {
     if (!SceneOf<T>::get(sc).surface)
       return rt_fail(sc->ctx, RT_ERR_INVALID, "RT_MODE_WHITTED needs rt_scene_desc.shape_surface (per-shape reflectance, specular)");
-    return trace_tile_mode<T, true>(sc, p, md, mc, x0, y0, w, h, pre, post, rgba8, stats);
+    return trace_tile_mode<T, true, false>(sc, p, md, mc, x0, y0, w, h, pre, post, rgba8, stats);
   }
-  return trace_tile_mode<T, false>(sc, p, md, mc, x0, y0, w, h, pre, post, rgba8, stats);
+  const bool full = p->use_direct_light || (p->use_photon_maps && (md.n || mc.n));
+  if (full) return trace_tile_mode<T, false, true>(sc, p, md, mc, x0, y0, w, h, pre, post, rgba8, stats);
+  return trace_tile_mode<T, false, false>(sc, p, md, mc, x0, y0, w, h, pre, post, rgba8, stats);
 }
 
 // ------------------------------------------------------------------ emission

@@ -1,7 +1,9 @@
-// Wavefront path tracer: SoA path state in HBM, one kernel per stage, survivors compacted
-// into the next queue with a wave ballot + prefix count and one atomic per wave.
+// Wavefront path tracer.  SoA path state in HBM; survivors of a pass are compacted, in order, into the
+// next queue.
 //
-//   raygen -> [ intersect_closest -> shade ]* -> resolve
+//   primary (raygen + closest hit + shade, state in registers)
+//     -> [ intersect_closest -> shade ]*  while many paths are left
+//     -> tail (every remaining path to its end in one launch) -> resolve
 //
 // Semantics are the reference's traceRay / directLight (rayphoton.js:1626-1880).  Every
 // branch of traceRay makes at most one recursive call and adds its result unscaled, so a
@@ -24,6 +26,26 @@ template <typename T> struct PathSoA {
   T *out;                             // n x 4: finished paths' colour
 };
 
+// one path's state in registers
+template <typename T> struct PathState {
+  V3<T> o, d; T max_dist, importance; V3<T> acc;
+  uint32_t draw; int32_t depth; uint64_t stack;
+};
+template <typename T> RT_D PathState<T> load_path(const PathSoA<T> &P, uint32_t p) {
+  PathState<T> st;
+  st.o = mk<T>(P.ox[p], P.oy[p], P.oz[p]); st.d = mk<T>(P.dx[p], P.dy[p], P.dz[p]);
+  st.max_dist = P.max_dist[p]; st.importance = P.importance[p];
+  st.acc = mk<T>(P.acc_r[p], P.acc_g[p], P.acc_b[p]);
+  st.draw = P.draw[p]; st.depth = P.depth[p]; st.stack = P.stack[p];
+  return st;
+}
+template <typename T> RT_D void store_path(const PathSoA<T> &P, uint32_t p, const PathState<T> &st) {
+  P.ox[p] = st.o.x; P.oy[p] = st.o.y; P.oz[p] = st.o.z; P.dx[p] = st.d.x; P.dy[p] = st.d.y; P.dz[p] = st.d.z;
+  P.max_dist[p] = st.max_dist; P.importance[p] = st.importance;
+  P.acc_r[p] = st.acc.x; P.acc_g[p] = st.acc.y; P.acc_b[p] = st.acc.z;
+  P.draw[p] = st.draw; P.depth[p] = st.depth; P.stack[p] = st.stack;
+}
+
 struct TraceCfg {
   double epsilon, max_trace_dist, diffuse_radius, caustic_radius, standard_lamp_area, shadow_bias;
   int32_t max_depth, sub_sample, use_direct_light, use_photon_maps, max_bounces;
@@ -36,10 +58,10 @@ struct TraceCfg {
 // device-side bookkeeping of one rt_trace_tile call; counts[b] = queue length of wavefront pass b
 struct TraceCounters { unsigned long long shadow_rays, gathers, stack_overflows, tail_rays; uint32_t counts[RT_MAX_WAVE_BOUNCES + 2]; };
 
-// traceOnCanvas ray set-up (rayphoton.js:1589-1609, superSampleScale 0) for path p: writes the initial
-// path state and returns the camera ray.
+// traceOnCanvas ray set-up (rayphoton.js:1589-1609, superSampleScale 0) for path p: the initial path state
+// with the camera ray as its segment.
 template <typename T>
-RT_D void raygen_path(const DevScene<T> &S, const PathSoA<T> &P, const TraceCfg &C, uint32_t p, V3<T> &o, V3<T> &d) {
+RT_D PathState<T> raygen_path(const DevScene<T> &S, const TraceCfg &C, uint32_t p) {
   const int SS = C.sub_sample * C.sub_sample;
   uint32_t pix = p / SS, sub = p % SS;
   int X = C.x0 + (int)(pix % C.w), Y = C.y0 + (int)(pix / C.w);
@@ -50,40 +72,43 @@ RT_D void raygen_path(const DevScene<T> &S, const PathSoA<T> &P, const TraceCfg 
   u *= S.camera[12]; v *= S.camera[13];
   V3<T> co = ld3(S.camera), cu = ld3(S.camera + 3), cv = ld3(S.camera + 6), cw = ld3(S.camera + 9);
   V3<T> xyz = ((co + u * cu) + v * cv) + T(-1) * cw;                    // Camera.toXYZ, rayphoton.js:712
-  o = co; d = normalize<T>(xyz - co, T(C.epsilon));
-  P.ox[p] = o.x; P.oy[p] = o.y; P.oz[p] = o.z; P.dx[p] = d.x; P.dy[p] = d.y; P.dz[p] = d.z;
-  P.max_dist[p] = T(C.max_trace_dist); P.importance[p] = T(1);
-  P.acc_r[p] = T(0); P.acc_g[p] = T(0); P.acc_b[p] = T(0);
-  P.draw[p] = rng.draw; P.depth[p] = 0;
-  MatStack st; st.init(); P.stack[p] = st.bits;
+  PathState<T> st;
+  st.o = co; st.d = normalize<T>(xyz - co, T(C.epsilon));
+  st.max_dist = T(C.max_trace_dist); st.importance = T(1);
+  st.acc = mk<T>(0, 0, 0);
+  st.draw = rng.draw; st.depth = 0;
+  MatStack ms; ms.init(); st.stack = ms.bits;
+  return st;
 }
 
-// Closest hit of every queued path against the whole scene (rayphoton.js:1642-1650).
-// This is the VALU-bound kernel: the primitive index is wave-uniform, so primitive operands
-// are scalar loads and every lane spends its cycles on the distance arithmetic.
-// PRIMARY: the queue is the identity and the ray is generated in place (no ray loads); otherwise
-// the segment left by the previous shade pass is read from the path state.
-// WHITTED: ray.js's scan order (equal distances go to the highest index) instead of rayphoton.js's.
-template <typename T, bool PRIMARY, bool LDS, bool WHITTED>
-__global__ void __launch_bounds__(256) k_intersect_closest(DevScene<T> S, PathSoA<T> P, TraceCfg C, uint32_t *queue, uint32_t *count_ptr) {
+// Closest hit of every queued path against the whole scene (rayphoton.js:1642-1650), for the segment the
+// previous pass left in the path state.  This is the VALU-bound kernel: the primitive index is wave-uniform,
+// so primitive operands are broadcast LDS (or scalar) loads and every lane spends its cycles on the distance
+// arithmetic.  WHITTED: ray.js's scan order (equal distances go to the highest index) instead of rayphoton.js's.
+template <typename T, bool LDS, bool WHITTED>
+__global__ void __launch_bounds__(256) k_intersect_closest(DevScene<T> S, PathSoA<T> P, TraceCfg C, const uint32_t *queue, const uint32_t *count_ptr) {
   extern __shared__ __align__(16) unsigned char rt_lds[];
-  // device-side queue length (the grid is only an upper bound); the primary pass knows it and publishes it
-  const uint32_t count = PRIMARY ? C.n_paths : min(*count_ptr, C.n_paths);
-  if (PRIMARY && blockIdx.x == 0 && threadIdx.x == 0) *count_ptr = count;
+  // device-side queue length (the grid is only an upper bound)
+  const uint32_t count = min(*count_ptr, C.n_paths);
   if (blockIdx.x * blockDim.x >= count) return;
   const ScanSrc<T> G = LDS ? stage_scene_lds<T>(S, rt_lds) : global_scan_src<T>(S);
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= count) return;
-  uint32_t p; V3<T> o, d;
-  if (PRIMARY) { p = i; queue[i] = i; raygen_path<T>(S, P, C, p, o, d); }     // also seeds the identity queue the shade pass reads
-  else {
-    p = queue[i];
-    if (p >= C.n_paths) return;                             // (never true; guards the indexed accesses below)
-    o = mk<T>(P.ox[p], P.oy[p], P.oz[p]); d = mk<T>(P.dx[p], P.dy[p], P.dz[p]);
-  }
+  const uint32_t p = queue[i];
+  if (p >= C.n_paths) return;                               // (never true; guards the indexed accesses below)
+  V3<T> o = mk<T>(P.ox[p], P.oy[p], P.oz[p]), d = mk<T>(P.dx[p], P.dy[p], P.dz[p]);
   T t;
   int idx = scan_scene<T, WHITTED ? 3 : 0>(S, G, o, d, T(C.epsilon), T(0), t);
   P.hit_t[p] = t; P.hit_idx[p] = idx;
+}
+
+// stream of path p continued at draw `draw`: the key is (pixel, sub-sample)
+RT_D RngStream path_rng(uint32_t width, const TraceCfg &C, uint32_t p, uint32_t draw) {
+  const int SS = C.sub_sample * C.sub_sample;
+  const uint32_t pix = p / SS;
+  const int X = C.x0 + (int)(pix % C.w), Y = C.y0 + (int)(pix / C.w);
+  RngStream rng; rng.init(C.seed, RT_DOMAIN_RENDER, (uint32_t)(Y * (int)width + X), p % SS, draw);
+  return rng;
 }
 
 // directLight (rayphoton.js:1841-1880): per light one createPhoton() of a RANDOM light, scaled by
@@ -137,77 +162,68 @@ RT_D V3<T> gather_map(const DevMap &M, V3<T> x, V3<T> normal, double r) {
   return mk<T>(sr, sg, sb);
 }
 
-template <typename T> RT_D void finish_path(const PathSoA<T> &P, uint32_t p, V3<T> acc, V3<T> term, T term_a, bool alpha_fixed) {
-  T *o = P.out + (size_t)p * 4;
-  o[0] = acc.x + term.x; o[1] = acc.y + term.y; o[2] = acc.z + term.z;
-  o[3] = alpha_fixed ? T(1) : term_a;
+template <typename T> RT_D void finish_path(T *out, V3<T> acc, V3<T> term, T term_a, bool alpha_fixed) {
+  out[0] = acc.x + term.x; out[1] = acc.y + term.y; out[2] = acc.z + term.z;
+  out[3] = alpha_fixed ? T(1) : term_a;
 }
 
-// One traceRay body per queued path (rayphoton.js:1651-1838).  A path either finishes (its
-// colour goes to P.out) or leaves a new segment in the path state and enters `next_queue`.
 struct ShadeTally { unsigned long long shadow_rays = 0, gathers = 0, overflows = 0; };
 
-template <typename T>
-RT_D bool shade_body(const DevScene<T> &S, const ScanSrc<T> &G, const PathSoA<T> &P, const TraceCfg &C, const DevMap &Md, const DevMap &Mc,
-                     uint32_t p, T t, int idx, int bounce, ShadeTally &tally) {
+// One traceRay body (rayphoton.js:1651-1838) for path p, whose segment `st` hit primitive `idx` at distance t.
+// A path either finishes (its colour goes to out[0..3]) or continues: then `st` holds the new segment and
+// true is returned.  FULL = false compiles the direct-light and photon-gather terms out (for calls that
+// switch both off); the remaining control flow and RNG draws are the same.
+template <typename T, bool FULL>
+RT_D bool shade_body(const DevScene<T> &S, const ScanSrc<T> &G, const TraceCfg &C, const DevMap &Md, const DevMap &Mc,
+                     uint32_t p, PathState<T> &st, T t, int idx, int bounce, T *out, ShadeTally &tally) {
   bool alive = false;
-  unsigned long long &shadow_rays = tally.shadow_rays, &gathers = tally.gathers, &overflows = tally.overflows;
-  {
-    const T eps = T(C.epsilon);
-    V3<T> acc = mk<T>(P.acc_r[p], P.acc_g[p], P.acc_b[p]);
-    const int dword = P.depth[p];
-    const int depth = dword & 0xFFFF; const bool alpha_fixed = dword & 0x10000;
-    const V3<T> ZERO = mk<T>(0, 0, 0);
-    if (idx < 0) {
-      finish_path<T>(P, p, acc, mk<T>(16, 16, 16), T(1), alpha_fixed);                 // COL_VERY_DARK_GREY :1838
-    } else if (S.meta[4 * idx + 2] & RT_FLAG_LIGHT) {                                  // :1654-1656
-      int l = 0;
-      for (uint32_t k = 0; k < S.n_lights; k++) if ((int)S.light_shape[k] == idx) l = (int)k;
-      finish_path<T>(P, p, acc, mk<T>(S.light_data[l][3], S.light_data[l][4], S.light_data[l][5]), S.light_data[l][6], alpha_fixed);
-    } else {
-      V3<T> o = mk<T>(P.ox[p], P.oy[p], P.oz[p]), d = mk<T>(P.dx[p], P.dy[p], P.dz[p]);
-      const T max_dist = P.max_dist[p];
-      V3<T> hit = o + t * d;
-      V3<T> local = shape_colour<T>(S, idx, hit);
-      V3<T> n = shape_normal<T>(S, idx, hit);
-      if (t < max_dist || depth < C.max_depth) {                                       // :1677 (note: OR)
-        const T cos1 = -dot(d, n);
-        const int mat = S.meta[4 * idx + 1] & 7;
-        const bool has_mat = S.meta[4 * idx + 1] < 8;
-        RngStream rng; rng.init(C.seed, RT_DOMAIN_RENDER, 0, 0, P.draw[p]);
-        {   // the stream key is (pixel, sub-sample); recover it from the path index
-          const int SS = C.sub_sample * C.sub_sample;
-          uint32_t pix = p / SS;
-          int X = C.x0 + (int)(pix % C.w), Y = C.y0 + (int)(pix / C.w);
-          rng.a = (uint32_t)(Y * (int)S.width + X); rng.b = p % SS;
-        }
-        if (has_mat && S.mat[0][mat] == T(1)) {                                        // transparent :1679
-          MatStack st; st.bits = P.stack[p];
-          V3<T> ndir; bool ovf = false;
-          if (!fresnel_bounce<T>(S, mat, d, n, cos1, st, rng, ndir, ovf)) {
-            finish_path<T>(P, p, acc, ZERO, T(0), alpha_fixed);                        // COL_BLACK :1699
-          } else {
-            if (ovf) overflows++;
-            ndir = normalize<T>(ndir, eps);
-            P.ox[p] = hit.x; P.oy[p] = hit.y; P.oz[p] = hit.z; P.dx[p] = ndir.x; P.dy[p] = ndir.y; P.dz[p] = ndir.z;
-            P.max_dist[p] = max_dist - t; P.depth[p] = dword + 1; P.stack[p] = st.bits; P.draw[p] = rng.draw;
-            alive = true;                                                              // importance unchanged, >= 0.01
-          }
-        } else if (cos1 < T(0)) {
-          finish_path<T>(P, p, acc, ZERO, T(1), alpha_fixed);                          // inside an opaque object :1736-1747
+  const T eps = T(C.epsilon);
+  const int depth = st.depth & 0xFFFF; const bool alpha_fixed = st.depth & 0x10000;
+  const V3<T> ZERO = mk<T>(0, 0, 0);
+  if (idx < 0 || idx >= (int)S.n_shapes) {
+    finish_path<T>(out, st.acc, mk<T>(16, 16, 16), T(1), alpha_fixed);                 // COL_VERY_DARK_GREY :1838
+  } else if (S.meta[4 * idx + 2] & RT_FLAG_LIGHT) {                                    // :1654-1656
+    int l = 0;
+    for (uint32_t k = 0; k < S.n_lights; k++) if ((int)S.light_shape[k] == idx) l = (int)k;
+    finish_path<T>(out, st.acc, mk<T>(S.light_data[l][3], S.light_data[l][4], S.light_data[l][5]), S.light_data[l][6], alpha_fixed);
+  } else {
+    const V3<T> d = st.d;
+    const V3<T> hit = st.o + t * d;
+    const V3<T> local = shape_colour<T>(S, idx, hit);
+    const V3<T> n = shape_normal<T>(S, idx, hit);
+    if (t < st.max_dist || depth < C.max_depth) {                                      // :1677 (note: OR)
+      const T cos1 = -dot(d, n);
+      const int mat = S.meta[4 * idx + 1] & 7;
+      const bool has_mat = S.meta[4 * idx + 1] < 8;
+      RngStream rng = path_rng(S.width, C, p, st.draw);
+      if (has_mat && S.mat[0][mat] == T(1)) {                                          // transparent :1679
+        MatStack ms; ms.bits = st.stack;
+        V3<T> ndir; bool ovf = false;
+        if (!fresnel_bounce<T>(S, mat, d, n, cos1, ms, rng, ndir, ovf)) {
+          finish_path<T>(out, st.acc, ZERO, T(0), alpha_fixed);                        // COL_BLACK :1699
         } else {
-          const T refl = has_mat ? S.mat[2][mat] : Limits<T>::nan();
-          V3<T> direct = ZERO;
-          if (refl < T(1) && C.use_direct_light) {
-            const T bias = T(C.shadow_bias);
-            direct = direct_light<T>(S, G, C, hit + bias * n, n, local, rng, shadow_rays);          // :1750-1752
-          }
-          bool spec = false;
-          if (rng.next_k() < (has_mat ? S.refl_k[mat] : 0u)) spec = rng.next_k() < S.spec_k[mat];   // :1753, short-circuit
+          if (ovf) tally.overflows++;
+          st.o = hit; st.d = normalize<T>(ndir, eps);
+          st.max_dist = st.max_dist - t; st.depth = st.depth + 1; st.stack = ms.bits; st.draw = rng.draw;
+          alive = true;                                                                // importance unchanged, >= 0.01
+        }
+      } else if (cos1 < T(0)) {
+        finish_path<T>(out, st.acc, ZERO, T(1), alpha_fixed);                          // inside an opaque object :1736-1747
+      } else {
+        const T refl = has_mat ? S.mat[2][mat] : Limits<T>::nan();
+        V3<T> direct = ZERO;
+        if (FULL && refl < T(1) && C.use_direct_light) {
+          const T bias = T(C.shadow_bias);
+          direct = direct_light<T>(S, G, C, hit + bias * n, n, local, rng, tally.shadow_rays);     // :1750-1752
+        }
+        bool spec = false;
+        if (rng.next_k() < (has_mat ? S.refl_k[mat] : 0u)) spec = rng.next_k() < S.spec_k[mat];   // :1753, short-circuit
+        V3<T> acc = st.acc;
+        if (FULL) {
           V3<T> diff = ZERO, caus = ZERO;
           if (C.use_photon_maps) {
-            if (Md.n) { diff = gather_map<T>(Md, hit, n, C.diffuse_radius); gathers++; }
-            if (Mc.n) { caus = gather_map<T>(Mc, hit, n, C.caustic_radius); gathers++; }
+            if (Md.n) { diff = gather_map<T>(Md, hit, n, C.diffuse_radius); tally.gathers++; }
+            if (Mc.n) { caus = gather_map<T>(Mc, hit, n, C.caustic_radius); tally.gathers++; }
           }
           const T PI_ = T(3.141592653589793);
           const T dArea = PI_ * T(C.diffuse_radius * C.diffuse_radius), cArea = PI_ * T(C.caustic_radius * C.caustic_radius);
@@ -216,40 +232,31 @@ RT_D bool shade_body(const DevScene<T> &S, const ScanSrc<T> &G, const PathSoA<T>
           caus = mk<T>(caus.x * lc.x / cArea, caus.y * lc.y / cArea, caus.z * lc.z / cArea);
           V3<T> term = ((T(1) - refl) * direct + diff) + caus;                                    // :1817-1822 minus the child
           acc = acc + term;
-          const T imp = P.importance[p] * refl;
-          if (spec && !(imp < T(0.01))) {                                                         // child would return at :1627
-            V3<T> ndir = normalize<T>(d + (T(2) * cos1) * n, eps);
-            P.ox[p] = hit.x; P.oy[p] = hit.y; P.oz[p] = hit.z; P.dx[p] = ndir.x; P.dy[p] = ndir.y; P.dz[p] = ndir.z;
-            P.max_dist[p] = max_dist - t; P.importance[p] = imp; P.depth[p] = (dword + 1) | 0x10000;
-            P.acc_r[p] = acc.x; P.acc_g[p] = acc.y; P.acc_b[p] = acc.z; P.draw[p] = rng.draw;
-            alive = true;
-          } else {
-            finish_path<T>(P, p, acc, ZERO, T(1), true);
-          }
+        } else if (!(refl == refl)) {
+          acc = mk<T>(refl, refl, refl);                                                          // (1 - undefined) * direct is NaN
         }
-      } else {
-        finish_path<T>(P, p, acc, ZERO, T(1), alpha_fixed);                            // :1828-1833
+        const T imp = st.importance * refl;
+        if (spec && !(imp < T(0.01))) {                                                           // child would return at :1627
+          st.o = hit; st.d = normalize<T>(d + (T(2) * cos1) * n, eps);
+          st.max_dist = st.max_dist - t; st.importance = imp; st.depth = (st.depth + 1) | 0x10000;
+          st.acc = acc; st.draw = rng.draw;
+          alive = true;
+        } else {
+          finish_path<T>(out, acc, ZERO, T(1), true);
+        }
       }
+    } else {
+      finish_path<T>(out, st.acc, ZERO, T(1), alpha_fixed);                            // :1828-1833
     }
-    if (alive && bounce + 1 >= C.max_bounces) {                                        // safety cap; the reference has none
-      finish_path<T>(P, p, mk<T>(P.acc_r[p], P.acc_g[p], P.acc_b[p]), ZERO, T(1), (P.depth[p] & 0x10000) != 0);
-      alive = false;
-    }
+  }
+  if (alive && bounce + 1 >= C.max_bounces) {                                          // safety cap; the reference has none
+    finish_path<T>(out, st.acc, ZERO, T(1), (st.depth & 0x10000) != 0);
+    alive = false;
   }
   return alive;
 }
 
-
 // ------------------------------------------------------------------ the older tracer (ray.js:801-993)
-// stream of path p continued at draw `draw`: the key is (pixel, sub-sample)
-RT_D RngStream path_rng(uint32_t width, const TraceCfg &C, uint32_t p, uint32_t draw) {
-  const int SS = C.sub_sample * C.sub_sample;
-  const uint32_t pix = p / SS;
-  const int X = C.x0 + (int)(pix % C.w), Y = C.y0 + (int)(pix / C.w);
-  RngStream rng; rng.init(C.seed, RT_DOMAIN_RENDER, (uint32_t)(Y * (int)width + X), p % SS, draw);
-  return rng;
-}
-
 // vecPerturb of ray.js:75-100: the frame is not normalised and the lower bound is cos(pi/2)^2. 2 draws.
 template <typename T> RT_D V3<T> vec_perturb_a(V3<T> v, T eps, RngStream &rng) {
   V3<T> m = mk<T>(1, 0, 0);
@@ -271,35 +278,34 @@ template <typename T> RT_D V3<T> vec_perturb_a(V3<T> v, T eps, RngStream &rng) {
 // P.depth; k_resolve_a substitutes the terminal colour back up through the records.
 // Returns true when the path goes on with a new segment.
 template <typename T>
-RT_D bool shade_body_a(const DevScene<T> &S, const PathSoA<T> &P, const TraceCfg &C, T *levels, uint32_t p, T t, int idx, ShadeTally &tally) {
+RT_D bool shade_body_a(const DevScene<T> &S, const TraceCfg &C, T *levels, uint32_t p, PathState<T> &st, T t, int idx, T *out,
+                       int32_t *depth_out, ShadeTally &tally) {
   const T eps = T(C.epsilon);
-  const int level = P.depth[p];
-  T *out = P.out + (size_t)p * 4;
+  const int level = st.depth;
   if (idx < 0 || idx >= (int)S.n_shapes) {                                       // ray.js:992 (the second test is never true)
-    out[0] = T(16); out[1] = T(16); out[2] = T(16); out[3] = T(1);
+    out[0] = T(16); out[1] = T(16); out[2] = T(16); out[3] = T(1); *depth_out = level;
     return false;
   }
   if (level < 0 || level > C.max_depth) {                                        // (never true; guards the record store)
-    out[0] = T(0); out[1] = T(0); out[2] = T(0); out[3] = T(1); tally.overflows++;
+    out[0] = T(0); out[1] = T(0); out[2] = T(0); out[3] = T(1); *depth_out = 0; tally.overflows++;
     return false;
   }
-  const V3<T> o = mk<T>(P.ox[p], P.oy[p], P.oz[p]), d = mk<T>(P.dx[p], P.dy[p], P.dz[p]);
-  const T max_dist = P.max_dist[p];
-  const V3<T> hit = o + t * d;
+  const V3<T> d = st.d;
+  const V3<T> hit = st.o + t * d;
   const V3<T> sc = shape_colour<T>(S, idx, hit);
   const V3<T> n = shape_normal<T>(S, idx, hit);
   const T refl = S.surface ? S.surface[2 * (size_t)idx] : Limits<T>::nan();
   T *rec = levels + ((size_t)level * C.n_paths + p) * 4;
-  if (t < max_dist && level < C.max_depth) {                                     // ray.js:893, depth = max_depth - level
+  if (t < st.max_dist && level < C.max_depth) {                                  // ray.js:893, depth = max_depth - level
     const T cos1 = -dot(d, n);
     const int mat = S.meta[4 * idx + 1] & 7;
     const bool has_mat = S.meta[4 * idx + 1] < 8;
-    RngStream rng = path_rng(S.width, C, p, P.draw[p]);
+    RngStream rng = path_rng(S.width, C, p, st.draw);
     V3<T> ndir;
     if (!(has_mat && S.mat[0][mat] == T(1))) {                                   // MAT_OPAQUE ray.js:895
       if (cos1 < T(0)) {                                                         // ray.js:897-907: undefined, or black far away
         const T v = (t < T(1e5)) ? Limits<T>::nan() : T(0);
-        out[0] = v; out[1] = v; out[2] = v; out[3] = v;
+        out[0] = v; out[1] = v; out[2] = v; out[3] = v; *depth_out = level;
         return false;
       }
       const V3<T> rdir = d + (T(2) * cos1) * n;
@@ -312,36 +318,43 @@ RT_D bool shade_body_a(const DevScene<T> &S, const PathSoA<T> &P, const TraceCfg
         }
       }
     } else {                                                                     // ray.js:925-977, no Fresnel term
-      MatStack st; st.bits = P.stack[p];
-      const T eta1 = st.len() >= 1 ? S.mat[1][st.top()] : Limits<T>::nan();
-      const T eta2 = (dot(d, n) < T(0)) ? S.mat[1][mat] : (st.len() >= 2 ? S.mat[1][st.at(st.len() - 2)] : Limits<T>::nan());
+      MatStack ms; ms.bits = st.stack;
+      const T eta1 = ms.len() >= 1 ? S.mat[1][ms.top()] : Limits<T>::nan();
+      const T eta2 = (dot(d, n) < T(0)) ? S.mat[1][mat] : (ms.len() >= 2 ? S.mat[1][ms.at(ms.len() - 2)] : Limits<T>::nan());
       const T ratio = eta1 / eta2;                                               // an undefined index flows on as NaN
       const T c2sq = T(1) - ratio * ratio * (T(1) - cos1 * cos1);
       if (c2sq < T(0)) ndir = d + (T(2) * cos1) * n;
       else {
         const T pm = (cos1 < T(0)) ? T(-1) : T(1);
         ndir = ratio * d + (ratio * cos1 - pm * rt_sqrt(c2sq)) * n;
-        if (cos1 < T(0)) { if (st.len() > 0) st.pop(); }
-        else if (!st.push(mat)) tally.overflows++;
-        P.stack[p] = st.bits;
+        if (cos1 < T(0)) { if (ms.len() > 0) ms.pop(); }
+        else if (!ms.push(mat)) tally.overflows++;
+        st.stack = ms.bits;
       }
     }
     rec[0] = (T(1) - refl) * sc.x; rec[1] = (T(1) - refl) * sc.y; rec[2] = (T(1) - refl) * sc.z; rec[3] = refl;
-    P.depth[p] = level + 1;
-    const T imp = P.importance[p] * refl;
+    st.depth = level + 1;
+    const T imp = st.importance * refl;
     if (imp < T(0.01)) {                                                         // the child returns COL_WHITE, ray.js:845-847
-      out[0] = T(255); out[1] = T(255); out[2] = T(255); out[3] = T(1);
+      out[0] = T(255); out[1] = T(255); out[2] = T(255); out[3] = T(1); *depth_out = level + 1;
       return false;
     }
-    ndir = normalize<T>(ndir, eps);
-    P.ox[p] = hit.x; P.oy[p] = hit.y; P.oz[p] = hit.z; P.dx[p] = ndir.x; P.dy[p] = ndir.y; P.dz[p] = ndir.z;
-    P.max_dist[p] = max_dist - t; P.importance[p] = imp; P.draw[p] = rng.draw;
+    st.o = hit; st.d = normalize<T>(ndir, eps);
+    st.max_dist = st.max_dist - t; st.importance = imp; st.draw = rng.draw;
     return true;
   }
   rec[0] = (T(1) - refl) * sc.x; rec[1] = (T(1) - refl) * sc.y; rec[2] = (T(1) - refl) * sc.z; rec[3] = refl;
-  P.depth[p] = level + 1;
-  out[0] = sc.x; out[1] = sc.y; out[2] = sc.z; out[3] = T(1);                    // transmittedColour = shapeCol, ray.js:891
+  out[0] = sc.x; out[1] = sc.y; out[2] = sc.z; out[3] = T(1); *depth_out = level + 1;    // transmittedColour = shapeCol, ray.js:891
   return false;
+}
+
+// one shade step of either tracer for path p; finished paths leave their colour in P.out (and, for the older
+// tracer, their level count in P.depth), continuing paths leave the new segment in `st`
+template <typename T, bool WHITTED, bool FULL>
+RT_D bool shade_step(const DevScene<T> &S, const ScanSrc<T> &G, const PathSoA<T> &P, const TraceCfg &C, const DevMap &Md, const DevMap &Mc,
+                     T *levels, uint32_t p, PathState<T> &st, T t, int idx, int bounce, ShadeTally &tally) {
+  if (WHITTED) return shade_body_a<T>(S, C, levels, p, st, t, idx, P.out + (size_t)p * 4, P.depth + p, tally);
+  return shade_body<T, FULL>(S, G, C, Md, Mc, p, st, t, idx, bounce, P.out + (size_t)p * 4, tally);
 }
 
 RT_D void flush_tally(const ShadeTally &t, TraceCounters *ctr) {
@@ -350,9 +363,37 @@ RT_D void flush_tally(const ShadeTally &t, TraceCounters *ctr) {
   if (t.overflows) atomicAdd(&ctr->stack_overflows, t.overflows);
 }
 
-// Wavefront shade pass: one traceRay body per queued path.  Survivors are recorded as one keep-mask per
-// wave plus one count per workgroup; k_scan_blocks and k_queue_scatter then build the next queue in order.
-template <typename T, bool LDS, bool WHITTED>
+// First pass of a frame, fused: camera ray, closest hit and shade of every path with the path state in
+// registers; only paths that go on are written to the path arrays.  Survivors are recorded as one keep-mask
+// per wave plus one count per workgroup; k_scan_blocks and k_queue_scatter then build the next queue in order.
+// In the fp32 build every test's origin-dependent part is staged once per workgroup (all rays start at the camera).
+template <typename T, bool LDS, bool WHITTED, bool FULL>
+__global__ void __launch_bounds__(256) k_primary(DevScene<T> S, PathSoA<T> P, TraceCfg C, DevMap Md, DevMap Mc, T *levels,
+                                                 uint32_t *queue, uint32_t *count_ptr, unsigned long long *wave_mask,
+                                                 uint32_t *block_count, TraceCounters *ctr) {
+  extern __shared__ __align__(16) unsigned char rt_lds[];
+  constexpr bool OT = LDS && sizeof(T) == 4;
+  const uint32_t count = C.n_paths;
+  if (blockIdx.x == 0 && threadIdx.x == 0) *count_ptr = count;          // the queue length the later passes read
+  const V3<T> cam_o = ld3(S.camera);
+  const ScanSrc<T> G = LDS ? stage_scene_lds<T>(S, rt_lds, OT ? &cam_o : nullptr) : global_scan_src<T>(S);
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  bool alive = false;
+  ShadeTally tally;
+  if (p < count) {
+    queue[p] = p;                                                        // identity queue for the compaction
+    PathState<T> st = raygen_path<T>(S, C, p);
+    T t;
+    const int idx = scan_scene<T, WHITTED ? 3 : 0, OT>(S, G, st.o, st.d, T(C.epsilon), T(0), t);
+    alive = shade_step<T, WHITTED, FULL>(S, G, P, C, Md, Mc, levels, p, st, t, idx, 0, tally);
+    if (alive) store_path<T>(P, p, st);
+  }
+  block_publish_masks(alive, wave_mask, block_count);
+  flush_tally(tally, ctr);
+}
+
+// Wavefront shade pass: one traceRay body per queued path, for the hit k_intersect_closest left.
+template <typename T, bool LDS, bool WHITTED, bool FULL>
 __global__ void __launch_bounds__(256) k_shade(DevScene<T> S, PathSoA<T> P, TraceCfg C, DevMap Md, DevMap Mc, T *levels,
                                                const uint32_t *queue, const uint32_t *count_ptr, unsigned long long *wave_mask,
                                                uint32_t *block_count, TraceCounters *ctr, int bounce) {
@@ -366,9 +407,11 @@ __global__ void __launch_bounds__(256) k_shade(DevScene<T> S, PathSoA<T> P, Trac
   if (i < count) {
     const uint32_t p = queue[i];
     if (p >= C.n_paths) tally.overflows++;                  // (never taken; guards the indexed accesses)
-    else if (WHITTED) alive = shade_body_a<T>(S, P, C, levels, p, P.hit_t[p], P.hit_idx[p], tally);
-    else alive = shade_body<T>(S, G, P, C, Md, Mc, p, P.hit_t[p], P.hit_idx[p], bounce, tally);
-    //                                 // (never taken; guards the indexed accesses)
+    else {
+      PathState<T> st = load_path<T>(P, p);
+      alive = shade_step<T, WHITTED, FULL>(S, G, P, C, Md, Mc, levels, p, st, P.hit_t[p], P.hit_idx[p], bounce, tally);
+      if (alive) store_path<T>(P, p, st);
+    }
   }
   block_publish_masks(alive, wave_mask, block_count);
   flush_tally(tally, ctr);
@@ -377,11 +420,11 @@ __global__ void __launch_bounds__(256) k_shade(DevScene<T> S, PathSoA<T> P, Trac
 // Tail of a frame: once few paths are left, a wavefront pass per bounce is all launch and
 // synchronisation overhead, so one launch follows every remaining path to its end.  A workgroup of
 // RT_TAIL_THREADS lanes takes that many queued paths; after every bounce the survivors' path indices
-// are compacted to the front of an LDS queue (the path state itself lives in the SoA arrays, so only
+// are compacted to the front of an LDS queue (the path state itself goes through the SoA arrays, so only
 // the index moves), and waves that are left without a path retire.  The loop is bounded by max_bounces.
 // Segments traced here are counted in ctr->tail_rays.
 #define RT_TAIL_THREADS 512
-template <typename T, bool LDS, bool WHITTED>
+template <typename T, bool LDS, bool WHITTED, bool FULL>
 __global__ void __launch_bounds__(RT_TAIL_THREADS) k_tail(DevScene<T> S, PathSoA<T> P, TraceCfg C, DevMap Md, DevMap Mc, T *levels,
                                                           const uint32_t *queue, const uint32_t *count_ptr, TraceCounters *ctr, int bounce0) {
   extern __shared__ __align__(16) unsigned char rt_lds[];
@@ -404,12 +447,12 @@ __global__ void __launch_bounds__(RT_TAIL_THREADS) k_tail(DevScene<T> S, PathSoA
     if (threadIdx.x < n_live) {
       p = live[cur][threadIdx.x];
       if (p < C.n_paths) {                                  // (always true; guards the indexed accesses below)
-        V3<T> o = mk<T>(P.ox[p], P.oy[p], P.oz[p]), d = mk<T>(P.dx[p], P.dy[p], P.dz[p]);
+        PathState<T> st = load_path<T>(P, p);
         T t;
-        int idx = scan_scene<T, WHITTED ? 3 : 0>(S, G, o, d, T(C.epsilon), T(0), t);
+        const int idx = scan_scene<T, WHITTED ? 3 : 0>(S, G, st.o, st.d, T(C.epsilon), T(0), t);
         rays++;
-        if (WHITTED) alive = shade_body_a<T>(S, P, C, levels, p, t, idx, tally);
-        else alive = shade_body<T>(S, G, P, C, Md, Mc, p, t, idx, b, tally);
+        alive = shade_step<T, WHITTED, FULL>(S, G, P, C, Md, Mc, levels, p, st, t, idx, b, tally);
+        if (alive) store_path<T>(P, p, st);
       } else {
         tally.overflows++;
       }

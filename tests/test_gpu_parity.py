@@ -145,9 +145,11 @@ def test_emission_f32_statistics(rt):
     # same keyed streams: almost every attempt takes the same branches as in fp64
     assert abs(st["attempts_phase1"] - g.meta["stats"]["attempts1"]) < 200
     assert abs(st["attempts_phase2"] - g.meta["stats"]["attempts2"]) < 400
-    same_attempt = e["diffuse_attempt"][:, 1] == g["diffuse_tag"][:, 2]
-    assert same_attempt.mean() > 0.9
-    d = np.abs(e["diffuse"][same_attempt][:, :3] - g["diffuse"][same_attempt][:, :3]).max(axis=1)
+    # (one attempt that stores in one build and not in the other shifts every later list position, so compare sets)
+    common = np.intersect1d(e["diffuse_attempt"][:, 1], g["diffuse_tag"][:, 2]).size
+    assert common / g["diffuse_tag"].shape[0] > 0.97, common
+    _, ia, ib = np.intersect1d(e["diffuse_attempt"][:, 1], g["diffuse_tag"][:, 2], return_indices=True)
+    d = np.abs(e["diffuse"][ia][:, :3] - g["diffuse"][ib][:, :3]).max(axis=1)
     assert np.quantile(d, 0.95) < 1e-3
 
 
