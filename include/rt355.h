@@ -114,8 +114,9 @@ int rt_synchronize(rt_ctx *ctx);
 /* Per-kernel HIP-event timing (off by default).  rt_profile_get sums the launches of one
  * kernel name since the last reset; it synchronises the stream. */
 int rt_profile_enable(rt_ctx *ctx, int on);
-/* restrict event timing to the launches of one kernel name (NULL = all kernels again) */
-int rt_profile_select(rt_ctx *ctx, const char *kernel);
+/* restrict event timing to the launches of the named kernels, comma-separated, e.g. "primary,tail"
+ * (NULL or "" = all kernels again) */
+int rt_profile_select(rt_ctx *ctx, const char *kernels);
 int rt_profile_reset(rt_ctx *ctx);
 int rt_profile_get(rt_ctx *ctx, const char *kernel, double *total_ms, uint64_t *launches);
 

@@ -13,7 +13,7 @@ import numpy as np
 from .scene import FlatScene
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "librt355.so")
+LIB_PATH = os.environ.get("RT355_LIB") or os.path.join(_HERE, "csrc", "librt355.so")      # override: kernel-variant experiments
 
 PRECISION_F32, PRECISION_F64 = 0, 1
 MODE_PHOTON, MODE_WHITTED = 0, 1

@@ -99,7 +99,11 @@ int rt_synchronize(rt_ctx *ctx) {
 }
 
 int rt_profile_enable(rt_ctx *ctx, int on) { if (!ctx) return RT_ERR_INVALID; ctx->profiling = on != 0; return RT_OK; }
-int rt_profile_select(rt_ctx *ctx, const char *kernel) { if (!ctx) return RT_ERR_INVALID; ctx->profile_only = kernel ? kernel : ""; return RT_OK; }
+int rt_profile_select(rt_ctx *ctx, const char *kernels) {
+  if (!ctx) return RT_ERR_INVALID;
+  ctx->profile_only = (kernels && *kernels) ? "," + std::string(kernels) + "," : "";
+  return RT_OK;
+}
 int rt_profile_reset(rt_ctx *ctx) {
   if (!ctx) return RT_ERR_INVALID;
   RT_HIP(ctx, hipStreamSynchronize(ctx->stream));

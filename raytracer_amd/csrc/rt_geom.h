@@ -288,6 +288,9 @@ template <typename T> RT_D ScanSrc<T> global_scan_src(const DevScene<T> &S) {
   return G;
 }
 
+#ifndef RT_SCAN_UNROLL_PRAGMA
+#define RT_SCAN_UNROLL_PRAGMA _Pragma("unroll 2")
+#endif
 // fp32 scan over the precomputed records; same MODEs as scan_scene below.  Equal distances keep the first
 // primitive in type-sorted order.
 template <int MODE, bool OT> RT_D int scan_fast(const DevScene<float> &S, const ScanSrc<float> &G, V3<float> o, V3<float> d, float eps, float limit, float &t_out) {
@@ -295,7 +298,7 @@ template <int MODE, bool OT> RT_D int scan_fast(const DevScene<float> &S, const 
   const float lim = (MODE == 2) ? limit - eps : 0.0f;
   bool occluded = false;
 #define RT_FAST_LOOP(TYPE)                                                                              \
-  _Pragma("unroll 2")                                                                                   \
+  RT_SCAN_UNROLL_PRAGMA                                                                                 \
   for (uint32_t s = S.seg[TYPE]; s < S.seg[TYPE + 1]; s++) {                                            \
     const float *f = G.geom + (size_t)s * RT_GEOM_STRIDE;                                               \
     const int flags = (MODE == 1 || MODE == 2 || TYPE == RT_CYLINDER) ? (int)G.flags[s] : 0;            \

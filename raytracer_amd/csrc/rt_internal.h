@@ -17,7 +17,7 @@ struct rt_ctx {
   hipStream_t stream = nullptr;
   std::string err;
   bool profiling = false;
-  std::string profile_only;      // when non-empty, only launches under this name are timed
+  std::string profile_only;      // when non-empty: ",name1,name2," -- only launches under these names are timed
   std::map<std::string, std::vector<std::pair<hipEvent_t, hipEvent_t>>> events;
   uint32_t *pinned = nullptr;    // small pinned scratch for counters read back each bounce
 };
@@ -59,7 +59,7 @@ int rt_stage_out_end(rt_ctx *ctx, void *dst, size_t bytes, DevMem &tmp);
 struct KernelTimer {
   rt_ctx *ctx; hipEvent_t a = nullptr, b = nullptr; const char *name;
   KernelTimer(rt_ctx *c, const char *n) : ctx(c), name(n) {
-    if (ctx->profiling && (ctx->profile_only.empty() || ctx->profile_only == n)) { (void)hipEventCreate(&a); (void)hipEventCreate(&b); (void)hipEventRecord(a, ctx->stream); }
+    if (ctx->profiling && (ctx->profile_only.empty() || ctx->profile_only.find("," + std::string(n) + ",") != std::string::npos)) { (void)hipEventCreate(&a); (void)hipEventCreate(&b); (void)hipEventRecord(a, ctx->stream); }
   }
   ~KernelTimer() {
     if (a) { (void)hipEventRecord(b, ctx->stream); ctx->events[name].push_back({ a, b }); }

@@ -139,15 +139,25 @@ static int trace_tile_mode(rt_scene *sc, const rt_params *p, DevMap md, DevMap m
   // host reads a length back only when it needs one to choose the next step.
   uint32_t tail_threshold = 1u << 21;
   if (const char *e = getenv("RT355_TAIL_THRESHOLD")) tail_threshold = (uint32_t)strtoul(e, nullptr, 10);
+  // RT355_WHOLE_FRAME=1: the whole frame in ONE launch (k_tail<RT_TAIL_PRIMARY>), every workgroup carrying its paths
+  // from the camera ray to their end -- fewest launches, but the fused first pass then runs at the tail kernel's
+  // lower occupancy; measured slower than the pipeline below on full frames.
+  bool whole_frame = false;
+  if (const char *e = getenv("RT355_WHOLE_FRAME")) whole_frame = atoi(e) != 0;
   uint32_t ub = (uint32_t)n_paths;                          // upper bound of the current queue length
   uint32_t wave_bounces = 0;
+  if (whole_frame) {
+    const uint32_t tblocks = div_up(n_paths, RT_TAIL_THREADS);
+    if (lds) RT_LAUNCH_SMEM(ctx, "trace", (k_tail<T, true, WHITTED, FULL, RT_TAIL_PRIMARY>), tblocks, RT_TAIL_THREADS, smem, S, P, C, md, mc, levels, (const uint32_t *)nullptr, (const uint32_t *)nullptr, ctr, 0);
+    else RT_LAUNCH_SMEM(ctx, "trace", (k_tail<T, false, WHITTED, FULL, RT_TAIL_PRIMARY>), tblocks, RT_TAIL_THREADS, 0, S, P, C, md, mc, levels, (const uint32_t *)nullptr, (const uint32_t *)nullptr, ctr, 0);
+  } else
   for (;;) {
     const uint32_t blocks = div_up(ub, 256);
     uint32_t *cnt = counts + wave_bounces;
     if ((wave_bounces > 0 && ub <= tail_threshold) || wave_bounces >= RT_MAX_WAVE_BOUNCES) {
       const uint32_t tblocks = div_up(ub, RT_TAIL_THREADS);
-      if (lds) RT_LAUNCH_SMEM(ctx, "tail", (k_tail<T, true, WHITTED, FULL>), tblocks, RT_TAIL_THREADS, smem, S, P, C, md, mc, levels, q_cur, cnt, ctr, (int)wave_bounces);
-      else RT_LAUNCH_SMEM(ctx, "tail", (k_tail<T, false, WHITTED, FULL>), tblocks, RT_TAIL_THREADS, 0, S, P, C, md, mc, levels, q_cur, cnt, ctr, (int)wave_bounces);
+      if (lds) RT_LAUNCH_SMEM(ctx, "tail", (k_tail<T, true, WHITTED, FULL, RT_TAIL_QUEUE>), tblocks, RT_TAIL_THREADS, smem, S, P, C, md, mc, levels, q_cur, cnt, ctr, (int)wave_bounces);
+      else RT_LAUNCH_SMEM(ctx, "tail", (k_tail<T, false, WHITTED, FULL, RT_TAIL_QUEUE>), tblocks, RT_TAIL_THREADS, 0, S, P, C, md, mc, levels, q_cur, cnt, ctr, (int)wave_bounces);
       break;
     }
     if (wave_bounces == 0) {
@@ -183,12 +193,24 @@ static int trace_tile_mode(rt_scene *sc, const rt_params *p, DevMap md, DevMap m
   RT_HIP(ctx, hipMemcpyAsync(&hc, ctr, sizeof(hc), hipMemcpyDeviceToHost, ctx->stream));
   RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
   RT_HIP(ctx, hipGetLastError());
+#ifdef RT_TAIL_PROBE
+  if (getenv("RT355_PROBE")) {
+    static const char *ph[5] = { "load", "scan", "shade+store", "compact", "top" };
+    for (int a = 0; a < 3; a++) {
+      fprintf(stderr, "probe %s: block-iterations %llu;", a == 0 ? "iter 1" : (a == 1 ? "iter 2-3" : "iter 4+"), hc.probe[a][5]);
+      for (int k = 0; k < 5; k++) fprintf(stderr, " %s %.0f", ph[k], hc.probe[a][5] ? (double)hc.probe[a][k] / (double)hc.probe[a][5] : 0.0);
+      fprintf(stderr, "  (cycles per block-iteration, lane 0)\n");
+    }
+  }
+#endif
   if (stats) {
-    uint64_t rays = 0;
+    uint64_t rays = 0, tail = 0; uint32_t iters = 0;
     for (uint32_t b = 0; b < wave_bounces; b++) rays += hcounts[b];
-    stats->rays = rays + hc.tail_rays; stats->bounces = wave_bounces + (hc.tail_rays ? 1 : 0);
+    for (int k = 0; k < RT_CTR_SLOTS; k++) { tail += hc.tail_rays[k]; iters = hc.max_iter[k] > iters ? hc.max_iter[k] : iters; }
+    stats->rays = rays + tail; stats->bounces = wave_bounces + iters;
     stats->shadow_rays = hc.shadow_rays; stats->gathers = hc.gathers;
-    stats->stack_overflows = hc.stack_overflows; stats->tail_rays = hc.tail_rays;
+    stats->stack_overflows = hc.stack_overflows;
+    stats->tail_rays = whole_frame ? tail - n_paths : tail;       // segments after the first pass that k_tail traced
   }
   return RT_OK;
 }

@@ -30,13 +30,14 @@ template <typename T> struct PathSoA {
 template <typename T> struct PathState {
   V3<T> o, d; T max_dist, importance; V3<T> acc;
   uint32_t draw; int32_t depth; uint64_t stack;
+  Philox4 blk; uint32_t blk_idx;      // not stored: the stream's current Philox block, if a pass already computed it
 };
 template <typename T> RT_D PathState<T> load_path(const PathSoA<T> &P, uint32_t p) {
   PathState<T> st;
   st.o = mk<T>(P.ox[p], P.oy[p], P.oz[p]); st.d = mk<T>(P.dx[p], P.dy[p], P.dz[p]);
   st.max_dist = P.max_dist[p]; st.importance = P.importance[p];
   st.acc = mk<T>(P.acc_r[p], P.acc_g[p], P.acc_b[p]);
-  st.draw = P.draw[p]; st.depth = P.depth[p]; st.stack = P.stack[p];
+  st.draw = P.draw[p]; st.depth = P.depth[p]; st.stack = P.stack[p]; st.blk_idx = 0xFFFFFFFFu;
   return st;
 }
 template <typename T> RT_D void store_path(const PathSoA<T> &P, uint32_t p, const PathState<T> &st) {
@@ -56,7 +57,15 @@ struct TraceCfg {
 
 #define RT_MAX_WAVE_BOUNCES 62
 // device-side bookkeeping of one rt_trace_tile call; counts[b] = queue length of wavefront pass b
-struct TraceCounters { unsigned long long shadow_rays, gathers, stack_overflows, tail_rays; uint32_t counts[RT_MAX_WAVE_BOUNCES + 2]; };
+#define RT_CTR_SLOTS 64
+struct TraceCounters {
+  unsigned long long shadow_rays, gathers, stack_overflows, tail_rays[RT_CTR_SLOTS];
+  uint32_t max_iter[RT_CTR_SLOTS];          // iterations the longest-lived workgroup of k_tail ran
+  uint32_t counts[RT_MAX_WAVE_BOUNCES + 2];
+#ifdef RT_TAIL_PROBE
+  unsigned long long probe[3][6];           // [first / second / later iterations][phase] cycles seen by lane 0 of each workgroup; [..][5] = iterations
+#endif
+};
 
 // traceOnCanvas ray set-up (rayphoton.js:1589-1609, superSampleScale 0) for path p: the initial path state
 // with the camera ray as its segment.
@@ -76,7 +85,7 @@ RT_D PathState<T> raygen_path(const DevScene<T> &S, const TraceCfg &C, uint32_t 
   st.o = co; st.d = normalize<T>(xyz - co, T(C.epsilon));
   st.max_dist = T(C.max_trace_dist); st.importance = T(1);
   st.acc = mk<T>(0, 0, 0);
-  st.draw = rng.draw; st.depth = 0;
+  st.draw = rng.draw; st.depth = 0; st.blk = rng.block; st.blk_idx = rng.block_idx;
   MatStack ms; ms.init(); st.stack = ms.bits;
   return st;
 }
@@ -102,12 +111,13 @@ __global__ void __launch_bounds__(256) k_intersect_closest(DevScene<T> S, PathSo
   P.hit_t[p] = t; P.hit_idx[p] = idx;
 }
 
-// stream of path p continued at draw `draw`: the key is (pixel, sub-sample)
-RT_D RngStream path_rng(uint32_t width, const TraceCfg &C, uint32_t p, uint32_t draw) {
+// stream of path p continued where its state left it: the key is (pixel, sub-sample)
+template <typename T> RT_D RngStream path_rng(uint32_t width, const TraceCfg &C, uint32_t p, const PathState<T> &st) {
   const int SS = C.sub_sample * C.sub_sample;
   const uint32_t pix = p / SS;
   const int X = C.x0 + (int)(pix % C.w), Y = C.y0 + (int)(pix / C.w);
-  RngStream rng; rng.init(C.seed, RT_DOMAIN_RENDER, (uint32_t)(Y * (int)width + X), p % SS, draw);
+  RngStream rng; rng.init(C.seed, RT_DOMAIN_RENDER, (uint32_t)(Y * (int)width + X), p % SS, st.draw);
+  rng.block = st.blk; rng.block_idx = st.blk_idx;
   return rng;
 }
 
@@ -195,7 +205,7 @@ RT_D bool shade_body(const DevScene<T> &S, const ScanSrc<T> &G, const TraceCfg &
       const T cos1 = -dot(d, n);
       const int mat = S.meta[4 * idx + 1] & 7;
       const bool has_mat = S.meta[4 * idx + 1] < 8;
-      RngStream rng = path_rng(S.width, C, p, st.draw);
+      RngStream rng = path_rng<T>(S.width, C, p, st);
       if (has_mat && S.mat[0][mat] == T(1)) {                                          // transparent :1679
         MatStack ms; ms.bits = st.stack;
         V3<T> ndir; bool ovf = false;
@@ -300,7 +310,7 @@ RT_D bool shade_body_a(const DevScene<T> &S, const TraceCfg &C, T *levels, uint3
     const T cos1 = -dot(d, n);
     const int mat = S.meta[4 * idx + 1] & 7;
     const bool has_mat = S.meta[4 * idx + 1] < 8;
-    RngStream rng = path_rng(S.width, C, p, st.draw);
+    RngStream rng = path_rng<T>(S.width, C, p, st);
     V3<T> ndir;
     if (!(has_mat && S.mat[0][mat] == T(1))) {                                   // MAT_OPAQUE ray.js:895
       if (cos1 < T(0)) {                                                         // ray.js:897-907: undefined, or black far away
@@ -357,10 +367,16 @@ RT_D bool shade_step(const DevScene<T> &S, const ScanSrc<T> &G, const PathSoA<T>
   return shade_body<T, FULL>(S, G, C, Md, Mc, p, st, t, idx, bounce, P.out + (size_t)p * 4, tally);
 }
 
+// adds a wave's tallies to the frame counters: one atomic per wave and counter (call with the wave converged)
 RT_D void flush_tally(const ShadeTally &t, TraceCounters *ctr) {
-  if (t.shadow_rays) atomicAdd(&ctr->shadow_rays, t.shadow_rays);
-  if (t.gathers) atomicAdd(&ctr->gathers, t.gathers);
-  if (t.overflows) atomicAdd(&ctr->stack_overflows, t.overflows);
+  unsigned long long a = t.shadow_rays, b = t.gathers, c = t.overflows;
+  if (__ballot((a | b | c) != 0) == 0) return;
+  for (int off = 32; off > 0; off >>= 1) { a += __shfl_down(a, off, 64); b += __shfl_down(b, off, 64); c += __shfl_down(c, off, 64); }
+  if ((threadIdx.x & 63) == 0) {
+    if (a) atomicAdd(&ctr->shadow_rays, a);
+    if (b) atomicAdd(&ctr->gathers, b);
+    if (c) atomicAdd(&ctr->stack_overflows, c);
+  }
 }
 
 // First pass of a frame, fused: camera ray, closest hit and shade of every path with the path state in
@@ -417,42 +433,81 @@ __global__ void __launch_bounds__(256) k_shade(DevScene<T> S, PathSoA<T> P, Trac
   flush_tally(tally, ctr);
 }
 
-// Tail of a frame: once few paths are left, a wavefront pass per bounce is all launch and
-// synchronisation overhead, so one launch follows every remaining path to its end.  A workgroup of
-// RT_TAIL_THREADS lanes takes that many queued paths; after every bounce the survivors' path indices
-// are compacted to the front of an LDS queue (the path state itself goes through the SoA arrays, so only
-// the index moves), and waves that are left without a path retire.  The loop is bounded by max_bounces.
-// Segments traced here are counted in ctr->tail_rays.
+// One launch that follows paths to their end.  A workgroup of RT_TAIL_THREADS lanes takes that many paths;
+// after every bounce the survivors' path indices are compacted to the front of an LDS queue (the path state
+// itself goes through the SoA arrays, so only the index moves), and waves that are left without a path retire.
+// The loop is bounded by max_bounces.
+//   PRIMARY = false: the tail of a wavefront frame -- the paths are those of `queue`, already under way.
+//   PRIMARY = true:  the whole frame -- the workgroup's paths are blockIdx.x * RT_TAIL_THREADS + lane and the
+//                    first iteration is the fused primary pass (camera ray in registers, staged origin terms).
+//                    Workgroups in their latency-bound late bounces share the CUs with workgroups in their
+//                    arithmetic-bound first pass, and no queue is built at all.
+// Segments traced here are counted in ctr->tail_rays[], the longest path in ctr->max_iter[] (spread over
+// RT_CTR_SLOTS addresses: same-address atomics from thousands of workgroups serialise).
+#ifndef RT_TAIL_THREADS
 #define RT_TAIL_THREADS 512
-template <typename T, bool LDS, bool WHITTED, bool FULL>
-__global__ void __launch_bounds__(RT_TAIL_THREADS) k_tail(DevScene<T> S, PathSoA<T> P, TraceCfg C, DevMap Md, DevMap Mc, T *levels,
+#endif
+#ifndef RT_TAIL_MIN_WAVES
+#define RT_TAIL_MIN_WAVES 1
+#endif
+enum { RT_TAIL_QUEUE = 0, RT_TAIL_PRIMARY = 1 };
+template <typename T, bool LDS, bool WHITTED, bool FULL, int SRC>
+__global__ void __launch_bounds__(RT_TAIL_THREADS, RT_TAIL_MIN_WAVES) k_tail(DevScene<T> S, PathSoA<T> P, TraceCfg C, DevMap Md, DevMap Mc, T *levels,
                                                           const uint32_t *queue, const uint32_t *count_ptr, TraceCounters *ctr, int bounce0) {
   extern __shared__ __align__(16) unsigned char rt_lds[];
   __shared__ uint32_t live[2][RT_TAIL_THREADS];
   __shared__ uint32_t wave_cnt[RT_TAIL_THREADS / 64];
-  const uint32_t count = min(*count_ptr, C.n_paths);
-  if (blockIdx.x * RT_TAIL_THREADS >= count) return;
-  const ScanSrc<T> G = LDS ? stage_scene_lds<T>(S, rt_lds) : global_scan_src<T>(S);
+  constexpr bool PRIMARY = SRC == RT_TAIL_PRIMARY;
+  constexpr bool OT = PRIMARY && LDS && sizeof(T) == 4;
+  const uint32_t count = (SRC == RT_TAIL_QUEUE) ? min(*count_ptr, C.n_paths) : C.n_paths;
+  const uint32_t first_path = blockIdx.x * RT_TAIL_THREADS;
+  if (first_path >= count) return;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  uint32_t n_live = min((uint32_t)RT_TAIL_THREADS, count - blockIdx.x * RT_TAIL_THREADS);
-  if (threadIdx.x < n_live) live[0][threadIdx.x] = queue[blockIdx.x * RT_TAIL_THREADS + threadIdx.x];
-  __syncthreads();
+  uint32_t n_live = min((uint32_t)RT_TAIL_THREADS, count - first_path);
+  const V3<T> cam_o = ld3(S.camera);
+  const ScanSrc<T> G = LDS ? stage_scene_lds<T>(S, rt_lds, OT ? &cam_o : nullptr) : global_scan_src<T>(S);
+  if (SRC == RT_TAIL_QUEUE) {
+    if (threadIdx.x < n_live) live[0][threadIdx.x] = queue[first_path + threadIdx.x];
+    __syncthreads();
+  }
+  if (SRC != RT_TAIL_PRIMARY && (uint32_t)(wv * 64) >= n_live) return;     // waves without a path (no barrier waits for an ended wave)
   ShadeTally tally;
-  unsigned long long rays = 0;
+  unsigned long long rays = 0;                            // segments traced by this workgroup (n_live is workgroup-uniform)
   int cur = 0;
+  uint32_t iters = 0;
+#ifdef RT_TAIL_PROBE
+  unsigned long long pr[3][6] = {}; long long pt0 = clock64();
+#define RT_PROBE(k) { long long t1_ = clock64(); pr[iters > 3 ? 2 : (iters > 1 ? 1 : 0)][k] += (unsigned long long)(t1_ - pt0); pt0 = t1_; }
+#else
+#define RT_PROBE(k)
+#endif
   for (int b = bounce0; n_live > 0 && b < C.max_bounces; b++) {
+    rays += n_live; iters++;
+    RT_PROBE(4)
     // waves 0 .. nw-1 are still running this iteration; the others have retired and their wave_cnt slots are stale
     const int nw = (int)((n_live + 63u) / 64u);
+    const bool first = PRIMARY && b == bounce0;             // workgroup-uniform
     bool alive = false; uint32_t p = 0;
     if (threadIdx.x < n_live) {
-      p = live[cur][threadIdx.x];
+      p = first ? first_path + threadIdx.x : live[cur][threadIdx.x];
       if (p < C.n_paths) {                                  // (always true; guards the indexed accesses below)
-        PathState<T> st = load_path<T>(P, p);
-        T t;
-        const int idx = scan_scene<T, WHITTED ? 3 : 0>(S, G, st.o, st.d, T(C.epsilon), T(0), t);
-        rays++;
+        PathState<T> st;
+        T t; int idx;
+        if (first) {
+          st = raygen_path<T>(S, C, p);
+          idx = scan_scene<T, WHITTED ? 3 : 0, OT>(S, G, st.o, st.d, T(C.epsilon), T(0), t);
+        } else {
+          st = load_path<T>(P, p);
+#ifdef RT_TAIL_PROBE
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+          RT_PROBE(0)
+          idx = scan_scene<T, WHITTED ? 3 : 0>(S, G, st.o, st.d, T(C.epsilon), T(0), t);
+        }
+        RT_PROBE(1)
         alive = shade_step<T, WHITTED, FULL>(S, G, P, C, Md, Mc, levels, p, st, t, idx, b, tally);
         if (alive) store_path<T>(P, p, st);
+        RT_PROBE(2)
       } else {
         tally.overflows++;
       }
@@ -467,10 +522,18 @@ __global__ void __launch_bounds__(RT_TAIL_THREADS) k_tail(DevScene<T> S, PathSoA
     if (alive && slot < RT_TAIL_THREADS) live[cur ^ 1][slot] = p;
     __syncthreads();
     cur ^= 1; n_live = min(total, (uint32_t)RT_TAIL_THREADS);
+    RT_PROBE(3)
     if ((uint32_t)(wv * 64) >= n_live) break;              // this wave has no path left (retired waves do not hold up barriers)
   }
-  for (int off = 32; off > 0; off >>= 1) rays += __shfl_down(rays, off, 64);
-  if (lane == 0 && rays) atomicAdd(&ctr->tail_rays, rays);
+  if (threadIdx.x == 0) {                                   // wave 0 is the last to retire: it has seen every iteration
+    const uint32_t slot = blockIdx.x % RT_CTR_SLOTS;
+    if (rays) atomicAdd(&ctr->tail_rays[slot], rays);
+    atomicMax(&ctr->max_iter[slot], iters);
+#ifdef RT_TAIL_PROBE
+    pr[0][5] = iters > 0; pr[1][5] = iters > 1 ? (iters > 3 ? 2 : iters - 1) : 0; pr[2][5] = iters > 3 ? iters - 3 : 0;
+    for (int a = 0; a < 3; a++) for (int k = 0; k < 6; k++) if (pr[a][k]) atomicAdd(&ctr->probe[a][k], pr[a][k]);
+#endif
+  }
   flush_tally(tally, ctr);
 }
 

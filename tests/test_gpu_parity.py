@@ -384,7 +384,14 @@ def test_image_mode_a_f64_matches_reference(rt, preset, rays, monkeypatch):
     monkeypatch.setenv("RT355_TAIL_THRESHOLD", "0")
     wave = sc.trace_tile(p)
     assert same(wave["pre"], g["rgba"]) and wave["stats"]["tail_rays"] == 0 and wave["stats"]["rays"] == rays
+    monkeypatch.setenv("RT355_TAIL_THRESHOLD", "4000000")    # fused first pass, compaction, then the tail kernel
+    mixed = sc.trace_tile(p)
+    assert same(mixed["pre"], g["rgba"]) and mixed["stats"]["tail_rays"] == rays - g.meta["W"] * g.meta["H"]
     monkeypatch.delenv("RT355_TAIL_THRESHOLD")
+    monkeypatch.setenv("RT355_WHOLE_FRAME", "1")             # one launch for the whole frame
+    mega = sc.trace_tile(p)
+    assert same(mega["pre"], g["rgba"]) and mega["stats"]["rays"] == rays
+    monkeypatch.delenv("RT355_WHOLE_FRAME")
     H = g.meta["H"]
     top, bot = sc.trace_tile(p, h=50), sc.trace_tile(p, y0=50, h=H - 50)
     assert same(np.concatenate([top["pre"], bot["pre"]]), g["rgba"])
@@ -411,3 +418,25 @@ def test_image_mode_a_f32_and_subsamples(rt):
     # a scene without the per-shape surface table cannot be traced in this mode
     with pytest.raises(capi.RtError):
         ctx.upload(load_scene(10, 64, 48)).trace_tile(p)
+
+
+@pytest.mark.parametrize("precision", ["F64", "F32"])
+def test_wavefront_and_whole_frame_pipelines_agree(rt, precision, monkeypatch):
+    """the single-launch pipeline and the multi-pass wavefront pipeline are two schedules of the same paths"""
+    capi, ctx = rt
+    ph = load_bundle("photons_c1")
+    sc = ctx.upload(load_scene(10, 320, 240))
+    md, mc = ctx.photon_map(ph["diffuse"]), ctx.photon_map(ph["caustic"])
+    for kw in (dict(), dict(use_direct_light=0, use_photon_maps=0)):
+        p = capi.default_params(precision=getattr(capi, "PRECISION_" + precision), num_photons_diffuse=10000,
+                                num_photons_caustic=10000, seed=SEED, shadow_bias=1e-4, **kw)
+        monkeypatch.setenv("RT355_WHOLE_FRAME", "1")
+        whole = sc.trace_tile(p, md, mc)
+        monkeypatch.delenv("RT355_WHOLE_FRAME")
+        for thr in ("0", "1000", "4000000"):
+            monkeypatch.setenv("RT355_TAIL_THRESHOLD", thr)
+            wave = sc.trace_tile(p, md, mc)
+            assert same(wave["pre"], whole["pre"]) and same(wave["post"], whole["post"])
+            for k in ("rays", "shadow_rays", "gathers"):
+                assert wave["stats"][k] == whole["stats"][k], (k, thr)
+        monkeypatch.delenv("RT355_TAIL_THRESHOLD")
