@@ -95,10 +95,12 @@ struct rt_photon_map {
   rt_ctx *ctx = nullptr;
   uint32_t n = 0;
   DevMem node, pay, rec64, perm, dim;
+  DevMem ws_flags;                 // per-workgroup fallback flags of the k-nearest gather (grow-only)
+  float bbox[6] = { 0, 0, 0, 0, 0, 0 };   // min xyz, max xyz of the photon positions
   DevMap view() const {
     DevMap m; m.n = n; m.node = node.as<float4>(); m.pay = pay.as<float>(); m.rec64 = rec64.as<double>(); m.perm = perm.as<int32_t>();
     return m;
   }
 };
 
-int rt_kd_build_device(rt_ctx *ctx, const float *d_pos, uint32_t n, int32_t *d_perm, uint8_t *d_dim);
+int rt_kd_build_device(rt_ctx *ctx, const float *d_pos, uint32_t n, int32_t *d_perm, uint8_t *d_dim, float *bbox6);

@@ -121,7 +121,10 @@ __global__ void __launch_bounds__(256) k_kd_split(uint32_t n, const uint32_t *id
   else { sg.pos[i] = 2 * sp + 1; sg.start[i] = s + m + 1; sg.len[i] = len - m - 1; }
 }
 
-int rt_kd_build_device(rt_ctx *ctx, const float *d_pos, uint32_t n, int32_t *d_perm, uint8_t *d_dim) {
+static float unsortable_host(uint32_t u) { u ^= ((u >> 31) ? 0x80000000u : 0xFFFFFFFFu); float f; memcpy(&f, &u, 4); return f; }
+
+// bbox6 (optional, host): min xyz, max xyz of all positions
+int rt_kd_build_device(rt_ctx *ctx, const float *d_pos, uint32_t n, int32_t *d_perm, uint8_t *d_dim, float *bbox6) {
   if (n == 0) return rt_fail(ctx, RT_ERR_EMPTY_TREE, "tried to build a k-d tree with no data!");   // kdtree.js:6
   if (n >= 0x7FFFFFFFu) return rt_fail(ctx, RT_ERR_TOO_LARGE, "photon map too large");
   DevMem idxA, idxB, keyA, keyB, spos, sstart, slen, bbmin, bbmax, segdim, tmp;
@@ -155,6 +158,12 @@ int rt_kd_build_device(rt_ctx *ctx, const float *d_pos, uint32_t n, int32_t *d_p
     RT_LAUNCH(ctx, "kd_split", k_kd_split, grid, 256, n, idx_cur, sg, segdim.as<uint8_t>(), d_perm, d_dim);
   }
   RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (bbox6) {                                              // the root segment's box (heap position 1) is never cleared again
+    uint32_t lo[3], hi[3];
+    RT_HIP(ctx, hipMemcpy(lo, bbmin.as<uint32_t>() + 3, 12, hipMemcpyDeviceToHost));
+    RT_HIP(ctx, hipMemcpy(hi, bbmax.as<uint32_t>() + 3, 12, hipMemcpyDeviceToHost));
+    for (int d = 0; d < 3; d++) { bbox6[d] = unsortable_host(lo[d]); bbox6[3 + d] = unsortable_host(hi[d]); }
+  }
   return RT_OK;
 }
 
@@ -166,7 +175,7 @@ extern "C" int rt_kd_build(rt_ctx *ctx, const float *pos, uint32_t n, int32_t *p
   RT_TRY(rt_stage_in(ctx, pos, (size_t)n * 12, tpos, &dpos));
   RT_TRY(rt_stage_out_begin(ctx, perm, (size_t)n * 4, tperm, &dperm));
   RT_TRY(rt_stage_out_begin(ctx, dim, (size_t)n, tdim, &ddim));
-  RT_TRY(rt_kd_build_device(ctx, (const float *)dpos, n, (int32_t *)dperm, (uint8_t *)ddim));
+  RT_TRY(rt_kd_build_device(ctx, (const float *)dpos, n, (int32_t *)dperm, (uint8_t *)ddim, nullptr));
   RT_TRY(rt_stage_out_end(ctx, perm, (size_t)n * 4, tperm));
   RT_TRY(rt_stage_out_end(ctx, dim, (size_t)n, tdim));
   return RT_OK;
@@ -210,7 +219,7 @@ extern "C" int rt_photon_map_build(rt_ctx *ctx, const double *rec, uint32_t n, r
   if (e != hipSuccess) { delete m; return rt_fail(ctx, RT_ERR_HIP, "photon map allocation failed: %s", hipGetErrorString(e)); }
   const uint32_t grid = div_up(n, 256);
   RT_LAUNCH(ctx, "map_extract_pos", k_map_extract_pos, grid, 256, n, (const double *)drec, tpos.as<float>());
-  int rc = rt_kd_build_device(ctx, tpos.as<float>(), n, m->perm.as<int32_t>(), m->dim.as<uint8_t>());
+  int rc = rt_kd_build_device(ctx, tpos.as<float>(), n, m->perm.as<int32_t>(), m->dim.as<uint8_t>(), m->bbox);
   if (rc != RT_OK) { delete m; return rc; }
   RT_LAUNCH(ctx, "map_permute", k_map_permute, grid, 256, n, (const double *)drec, m->perm.as<int32_t>(), m->dim.as<uint8_t>(),
             m->node.as<float4>(), m->pay.as<float>(), keep64 ? m->rec64.as<double>() : (double *)nullptr);
@@ -393,8 +402,10 @@ __global__ void __launch_bounds__(256) k_gather_radius(DevMap M, const float *hi
   rgb[(size_t)q * 3 + 2] = sb * (h[8] / 255.0f) * inv_area;
 }
 
-__global__ void __launch_bounds__(KNN_LANES) k_gather_knn(DevMap M, const float *hits, uint32_t nq, uint32_t k, float *rgb) {
+// `only` (optional): one flag per workgroup; workgroups whose flag is 0 have nothing to do (k_gather_knn_wave served them)
+__global__ void __launch_bounds__(KNN_LANES) k_gather_knn(DevMap M, const float *hits, uint32_t nq, uint32_t k, float *rgb, const uint8_t *only) {
   extern __shared__ double knn_lds[];
+  if (only && !only[blockIdx.x]) return;
   uint32_t q = blockIdx.x * KNN_LANES + threadIdx.x;
   KnnHeap H; H.d2 = knn_lds; H.slot = (uint32_t *)(knn_lds + (size_t)k * KNN_LANES); H.perm = M.perm; H.k = k; H.size = 0; H.lane = threadIdx.x;
   if (q >= nq) return;
@@ -415,6 +426,170 @@ __global__ void __launch_bounds__(KNN_LANES) k_gather_knn(DevMap M, const float 
   rgb[(size_t)q * 3 + 2] = sb * (h[8] / 255.0f) * inv_area;
 }
 
+
+// ------------------------------------------------------------------ k-nearest gather, one wave per 64 queries
+// Queries that arrive together are neighbours on a surface (the caller orders them by image tile), so their
+// k-nearest sets overlap almost completely.  A wave therefore
+//   1. takes the bounding box of its 64 query points, grows it by a radius R and collects every photon inside
+//      with ONE cooperative walk of the kd-tree (a frontier of nodes in LDS, one node per lane per step);
+//   2. checks that every query has at least k candidates closer than R -- then all of its k nearest photons are
+//      among the candidates, exactly -- and otherwise grows R and walks again;
+//   3. lets every lane find the distance that separates its k nearest candidates from the rest by an
+//      interpolation search on "how many candidates are closer than t" (the candidates are read from LDS as
+//      wave-wide broadcasts; no per-lane storage at all, so occupancy is not limited by a top-k structure);
+//   4. sums the radiance of the selected candidates.
+// Distances are the same fp64 expression as everywhere else (sq_dist), ties at the k-th distance go to the lowest
+// input index, so the selected set is exactly the one rt_kd_knn returns.  A wave whose candidate list or frontier
+// would overflow its LDS buffers reports that in fallback[] and leaves its queries to k_gather_knn.
+#define KNN2_CAP 512
+#define KNN2_FRONT 256
+
+__device__ __forceinline__ double wave_min_d(double v) { for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o, 64)); return v; }
+__device__ __forceinline__ double wave_max_d(double v) { for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64)); return v; }
+__device__ __forceinline__ uint32_t lanes_below(unsigned long long mask, int lane) { return (uint32_t)__popcll(mask & (((unsigned long long)1 << lane) - 1)); }
+
+__global__ void __launch_bounds__(64) k_gather_knn_wave(DevMap M, const float *hits, uint32_t nq, uint32_t k, double r0, float *rgb,
+                                                        uint8_t *fallback) {
+  __shared__ float4 cand[KNN2_CAP];                  // x y z, slot (as bits)
+  __shared__ uint32_t front[2][KNN2_FRONT];
+  const int lane = threadIdx.x;
+  const uint32_t q = blockIdx.x * 64 + lane;
+  const uint32_t qq = q < nq ? q : nq - 1;           // surplus lanes shadow the last query (no output)
+  const float *h = hits + (size_t)qq * 9;
+  const double x0 = h[0], x1 = h[1], x2 = h[2];
+  const float nx = h[3], ny = h[4], nz = h[5];
+  const double bl0 = wave_min_d(x0), bl1 = wave_min_d(x1), bl2 = wave_min_d(x2);
+  const double bh0 = wave_max_d(x0), bh1 = wave_max_d(x1), bh2 = wave_max_d(x2);
+  const uint32_t n = M.n;
+  double R = r0;
+  uint32_t m = 0, c = 0;
+  bool ok = false, overflow = false, all_in = false;
+  for (int attempt = 0; attempt < 40 && !ok && !overflow; attempt++) {
+    const double g = R * (1.0 + 1e-9);               // (the box test must not lose a photon to the rounding of lo/hi)
+    const double lo0 = bl0 - g, lo1 = bl1 - g, lo2 = bl2 - g, hi0 = bh0 + g, hi1 = bh1 + g, hi2 = bh2 + g;
+    // ---- 1. cooperative box walk
+    m = 0;
+    uint32_t ncur = 1; int cur = 0;
+    if (lane == 0) front[0][0] = 1;
+    __syncthreads();
+    while (ncur > 0 && !overflow) {
+      uint32_t nnext = 0;
+      for (uint32_t base = 0; base < ncur && !overflow; base += 64) {
+        const uint32_t i = base + lane;
+        const bool active = i < ncur;
+        const uint32_t pos = active ? front[cur][i] : 1u;                 // 1 <= pos <= n by construction
+        const float4 nd = M.node[pos - 1];
+        const double px = nd.x, py = nd.y, pz = nd.z;
+        const bool inside = active && px >= lo0 && px <= hi0 && py >= lo1 && py <= hi1 && pz >= lo2 && pz <= hi2;
+        const unsigned long long mi = __ballot(inside);
+        const uint32_t ci = (uint32_t)__popcll(mi);
+        if (m + ci > KNN2_CAP) { overflow = true; break; }
+        if (inside) cand[m + lanes_below(mi, lane)] = make_float4(nd.x, nd.y, nd.z, __uint_as_float(pos - 1));
+        m += ci;
+        const int dim = node_dim(nd);
+        const double pd = (dim == 0) ? px : (dim == 1) ? py : pz;
+        const double lod = (dim == 0) ? lo0 : (dim == 1) ? lo1 : lo2, hid = (dim == 0) ? hi0 : (dim == 1) ? hi1 : hi2;
+        // kdtree.js:69-71 for a box: left only if the box ends before the plane, right only if it starts after it
+        const bool gl = active && 2ull * pos <= n && !(lod > pd);
+        const bool gr = active && 2ull * pos + 1 <= n && !(hid < pd);
+        const unsigned long long ml = __ballot(gl), mr = __ballot(gr);
+        const uint32_t cl = (uint32_t)__popcll(ml), cr = (uint32_t)__popcll(mr);
+        if (nnext + cl + cr > KNN2_FRONT) { overflow = true; break; }
+        if (gl) front[cur ^ 1][nnext + lanes_below(ml, lane)] = 2 * pos;
+        if (gr) front[cur ^ 1][nnext + cl + lanes_below(mr, lane)] = 2 * pos + 1;
+        nnext += cl + cr;
+      }
+      __syncthreads();
+      cur ^= 1; ncur = nnext;
+    }
+    if (overflow) break;
+    // ---- 2. does every query have k candidates within R?
+    const double R2 = R * R;
+    c = 0;
+    for (uint32_t j = 0; j < m; j++) { const float4 cd = cand[j]; c += sq_dist(x0, x1, x2, (double)cd.x, (double)cd.y, (double)cd.z) < R2 ? 1u : 0u; }
+    all_in = (m == n);                               // the box holds the whole map: exact whatever R is
+    if (__all(c >= k) || all_in) ok = true; else R *= 1.5;
+    __syncthreads();                                 // (the next walk overwrites cand / front)
+  }
+  if (!ok) { if (lane == 0) fallback[blockIdx.x] = 1; return; }
+  // ---- 3. per lane: t with exactly k candidates closer than t (or a tie group at the k-th distance)
+  double a = 0.0, b = R * R; uint32_t fa = 0, fb = c;           // #(d2 < a) = fa < k,  #(d2 < b) = fb >= k
+  if (all_in && c < k) {                                        // every photon is a candidate but fewer than k lie within R
+    double dmax = 0.0;
+    for (uint32_t j = 0; j < m; j++) { const float4 cd = cand[j]; dmax = fmax(dmax, sq_dist(x0, x1, x2, (double)cd.x, (double)cd.y, (double)cd.z)); }
+    b = dmax * 2.0 + 1e-300; fb = m;                             // m = n >= k (the host sends smaller maps to k_gather_knn)
+  }
+  bool done = (fb == k); double tau = b; bool tie = false; double tie_v = 0.0; uint32_t need = 0;
+  int pass = 0;
+  for (; pass < 200 && !__all(done); pass++) {
+    double t = (pass % 3 == 2) ? 0.5 * (a + b) : a + (b - a) * (((double)k + 0.5 - (double)fa) / ((double)fb - (double)fa));
+    if (!(t > a && t < b)) t = 0.5 * (a + b);
+    if (!(t > a && t < b)) t = b;                                // a and b are neighbouring doubles: count below b, ties sit at a
+    uint32_t cnt = 0, ties = 0; double lmax = -1.0, rmin = __builtin_huge_val();
+    for (uint32_t j = 0; j < m; j++) {
+      const float4 cd = cand[j];
+      const double d2 = sq_dist(x0, x1, x2, (double)cd.x, (double)cd.y, (double)cd.z);
+      if (d2 < t) { cnt++; if (d2 > lmax) { lmax = d2; ties = 1; } else if (d2 == lmax) ties++; }
+      else rmin = fmin(rmin, d2);
+    }
+    if (done) continue;
+    if (cnt == k) { done = true; tau = t; }
+    else if (cnt < k) { a = rmin; fa = cnt; }                    // nothing lies in [t, rmin): #(d2 < rmin) = cnt
+    else if (cnt - ties == k) { done = true; tau = lmax; }       // #(d2 < lmax) = cnt - ties
+    else if (cnt - ties < k) { done = true; tie = true; tie_v = lmax; need = k - (cnt - ties); }
+    else { b = lmax; fb = cnt - ties; }
+  }
+  if (!__all(done)) { if (lane == 0) fallback[blockIdx.x] = 1; return; }
+  // ties at the k-th distance: the `need` lowest input indices among the candidates at distance tie_v
+  int32_t idx_thr = -1;
+  if (__any(tie)) {
+    uint32_t left = tie ? need : 0;
+    for (int guard = 0; guard < (int)KNN2_CAP && __any(left > 0); guard++) {
+      int32_t best = 0x7FFFFFFF;
+      for (uint32_t j = 0; j < m; j++) {
+        const float4 cd = cand[j];
+        const double d2 = sq_dist(x0, x1, x2, (double)cd.x, (double)cd.y, (double)cd.z);
+        const int32_t pi = M.perm[__float_as_uint(cd.w)];
+        if (d2 == tie_v && pi > idx_thr && pi < best) best = pi;
+      }
+      if (left > 0) { idx_thr = best; left--; }
+    }
+  }
+  // ---- 4. radiance of the selected candidates
+  float sr = 0, sg = 0, sb = 0; double dk2 = 0.0;
+  for (uint32_t j = 0; j < m; j++) {
+    const float4 cd = cand[j];
+    const uint32_t slot = __float_as_uint(cd.w);
+    const double d2 = sq_dist(x0, x1, x2, (double)cd.x, (double)cd.y, (double)cd.z);
+    bool sel;
+    if (tie) sel = d2 < tie_v || (d2 == tie_v && M.perm[slot] <= idx_thr);
+    else sel = d2 < tau;
+    if (__any(sel)) {
+      const float *pp = M.pay + (size_t)slot * 6;                // wave-uniform address
+      const float w = fmaxf(0.0f, pp[0] * nx + pp[1] * ny + pp[2] * nz);
+      if (sel) { sr += pp[3] * w; sg += pp[4] * w; sb += pp[5] * w; dk2 = fmax(dk2, d2); }
+    }
+  }
+  if (lane == 0) fallback[blockIdx.x] = 0;
+  if (q < nq) {
+    const double r2 = dk2;                                       // squared distance of the k-th nearest
+    const float inv_area = (float)(1.0 / (3.141592653589793 * r2));
+    rgb[(size_t)q * 3] = sr * (h[6] / 255.0f) * inv_area;
+    rgb[(size_t)q * 3 + 1] = sg * (h[7] / 255.0f) * inv_area;
+    rgb[(size_t)q * 3 + 2] = sb * (h[8] / 255.0f) * inv_area;
+  }
+}
+
+// number of set flags (one workgroup; the flag array is short)
+__global__ void __launch_bounds__(256) k_count_flags(const uint8_t *flags, uint32_t n, uint32_t *out) {
+  __shared__ uint32_t part[256];
+  uint32_t c = 0;
+  for (uint32_t i = threadIdx.x; i < n; i += 256) c += flags[i] ? 1u : 0u;
+  part[threadIdx.x] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) { uint32_t t = 0; for (int i = 0; i < 256; i++) t += part[i]; *out = t; }
+}
+
 extern "C" int rt_gather_radiance(rt_photon_map *m, const float *hits, uint32_t nq, double r, uint32_t k, float *rgb_out) {
   if (!m) return RT_ERR_INVALID;
   rt_ctx *ctx = m->ctx;
@@ -427,10 +602,31 @@ extern "C" int rt_gather_radiance(rt_photon_map *m, const float *hits, uint32_t 
   if (k == 0) {
     RT_LAUNCH(ctx, "gather_radius", k_gather_radius, div_up(nq, 256), 256, m->view(), (const float *)dh, nq, r, (float *)dout);
   } else {
-    RT_HIP(ctx, hipFuncSetAttribute((const void *)k_gather_knn, hipFuncAttributeMaxDynamicSharedMemorySize, knn_lds_bytes(k)));
-    KernelTimer timer_(ctx, "gather_knn");
-    hipLaunchKernelGGL(k_gather_knn, dim3(div_up(nq, KNN_LANES)), dim3(KNN_LANES), knn_lds_bytes(k), ctx->stream, m->view(),
-                       (const float *)dh, nq, k, (float *)dout);
+    const uint32_t blocks = div_up(nq, KNN_LANES);
+    bool heap_all = m->n < k || m->n < 2 * KNN2_CAP || getenv("RT355_KNN_HEAP") != nullptr;     // small maps: nothing to gain
+    uint8_t *flags = nullptr;
+    if (!heap_all) {
+      // first radius: the k-th neighbour distance if the photons were spread evenly over the faces of their bounding box
+      const double dx = (double)m->bbox[3] - m->bbox[0], dy = (double)m->bbox[4] - m->bbox[1], dz = (double)m->bbox[5] - m->bbox[2];
+      const double area = 2.0 * (dx * dy + dy * dz + dz * dx);
+      double r0 = area > 0 ? 1.2 * sqrt((double)k * area / (3.141592653589793 * (double)m->n)) : (dx + dy + dz) * (double)k / (double)m->n;
+      if (!(r0 > 0)) r0 = 1e-6;
+      if (const char *e = getenv("RT355_KNN_R0")) r0 = atof(e);
+      RT_HIP(ctx, m->ws_flags.reserve((size_t)blocks + 16));
+      flags = m->ws_flags.as<uint8_t>();
+      RT_LAUNCH(ctx, "gather_knn", k_gather_knn_wave, blocks, 64, m->view(), (const float *)dh, nq, k, r0, (float *)dout, flags);
+      RT_LAUNCH(ctx, "gather_knn_flags", k_count_flags, 1, 256, flags, blocks, (uint32_t *)(flags + (((size_t)blocks + 3) & ~(size_t)3)));
+      RT_HIP(ctx, hipMemcpyAsync(ctx->pinned, flags + (((size_t)blocks + 3) & ~(size_t)3), 4, hipMemcpyDeviceToHost, ctx->stream));
+      RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      if (ctx->pinned[0] == 0) flags = nullptr;             // every wave succeeded
+      else heap_all = true;                                 // some waves left their queries to the per-lane heap kernel
+    }
+    if (heap_all) {
+      RT_HIP(ctx, hipFuncSetAttribute((const void *)k_gather_knn, hipFuncAttributeMaxDynamicSharedMemorySize, knn_lds_bytes(k)));
+      KernelTimer timer_(ctx, flags ? "gather_knn_heap_fallback" : "gather_knn");
+      hipLaunchKernelGGL(k_gather_knn, dim3(blocks), dim3(KNN_LANES), knn_lds_bytes(k), ctx->stream, m->view(),
+                         (const float *)dh, nq, k, (float *)dout, (const uint8_t *)flags);
+    }
   }
   RT_TRY(rt_stage_out_end(ctx, rgb_out, (size_t)nq * 12, to));
   return RT_OK;

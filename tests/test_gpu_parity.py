@@ -440,3 +440,69 @@ def test_wavefront_and_whole_frame_pipelines_agree(rt, precision, monkeypatch):
             for k in ("rays", "shadow_rays", "gathers"):
                 assert wave["stats"][k] == whole["stats"][k], (k, thr)
         monkeypatch.delenv("RT355_TAIL_THRESHOLD")
+
+
+# ------------------------------------------------------------------ wave-cooperative k-nearest gather
+def _brute_knn_gather(rec, hits, k):
+    """fp64 brute force in the oracle's order (d2, then input index), sampled rows only"""
+    out = np.zeros((hits.shape[0], 3))
+    pos = rec[:, :3]
+    for i in range(hits.shape[0]):
+        idx, d2 = ora.knn_brute(pos, hits[i, :3].astype(np.float64), k)
+        idx = idx[idx >= 0]
+        w = np.maximum(0.0, rec[idx, 3:6] @ hits[i, 3:6].astype(np.float64))
+        s = (rec[idx, 7:10] * rec[idx, 6:7] * w[:, None]).sum(axis=0)
+        out[i] = s * hits[i, 6:9] / 255 / (np.pi * d2[len(idx) - 1])
+    return out
+
+
+def test_knn_gather_wave_kernel_equals_heap_kernel_and_brute_force(rt, monkeypatch):
+    capi, ctx = rt
+    from raytracer_amd import synth
+    rec = synth.box_photons(200_000, seed=11)
+    hits = synth.box_queries(320, 200)                     # tile-ordered: a wave's 64 queries are an 8x8 pixel patch
+    m = ctx.photon_map(rec)
+    K = 64
+    got = m.gather(hits, k=K)
+    monkeypatch.setenv("RT355_KNN_HEAP", "1")
+    heap = m.gather(hits, k=K)
+    monkeypatch.delenv("RT355_KNN_HEAP")
+    scale = max(1.0, float(np.abs(heap).max()))
+    assert np.allclose(got, heap, rtol=2e-5, atol=1e-6 * scale)          # same photon sets; the sums run in another order
+    rows = np.random.default_rng(3).choice(hits.shape[0], 300, replace=False)
+    exp = _brute_knn_gather(rec, hits[rows], K)
+    assert np.allclose(got[rows], exp, rtol=2e-5, atol=1e-6 * scale)
+    # a far too small and a far too large first radius end in the same sets (growth loop / fallback to the heap kernel)
+    for r0 in ("1e-4", "3.0"):
+        monkeypatch.setenv("RT355_KNN_R0", r0)
+        again = m.gather(hits, k=K)
+        assert np.allclose(again, heap, rtol=2e-5, atol=1e-6 * scale), r0
+    monkeypatch.delenv("RT355_KNN_R0")
+    # ragged tail (nq not a multiple of 64), k = 1 and k = 192
+    for k in (1, 192):
+        a = m.gather(hits[:1000], k=k)
+        monkeypatch.setenv("RT355_KNN_HEAP", "1")
+        b = m.gather(hits[:1000], k=k)
+        monkeypatch.delenv("RT355_KNN_HEAP")
+        assert np.allclose(a, b, rtol=2e-5, atol=1e-6 * max(1.0, float(np.abs(b).max()))), k
+
+
+def test_knn_gather_ties_at_the_kth_distance(rt, monkeypatch):
+    """photons on a lattice, queries on lattice points and cell centres: many exactly equal distances, so the
+    k-th distance is usually a tie group that the lowest input indices must win"""
+    capi, ctx = rt
+    g = np.stack(np.meshgrid(np.arange(24), np.arange(24), np.arange(4), indexing="ij"), -1).reshape(-1, 3).astype(np.float64) * 0.25
+    rng = np.random.default_rng(5)
+    rec = np.zeros((g.shape[0], 11))
+    rec[:, :3] = g[rng.permutation(g.shape[0])]
+    rec[:, 3:6] = [0, 0, 1]
+    rec[:, 6] = 1 / 255
+    rec[:, 7:10] = rng.uniform(0, 255, (g.shape[0], 3))
+    m = ctx.photon_map(rec)
+    qx, qy = np.meshgrid(np.arange(16), np.arange(16), indexing="ij")
+    qpos = np.stack([qx.ravel() * 0.125 + 2.0, qy.ravel() * 0.125 + 2.0, np.full(256, 0.25)], -1)
+    hits = np.concatenate([qpos, np.tile([0, 0, 1.0], (256, 1)), np.full((256, 3), 255.0)], axis=1).astype(np.float32)
+    for k in (5, 7, 27, 64):
+        got = m.gather(hits, k=k)
+        exp = _brute_knn_gather(rec, hits, k)
+        assert np.allclose(got, exp, rtol=2e-5, atol=1e-6 * max(1.0, float(np.abs(exp).max()))), k
