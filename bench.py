@@ -135,7 +135,7 @@ def main():
         build_s = time.perf_counter() - tb
         pm.gather(hits, k=args.knn, out=rgb)                               # warm-up
         ctx.profile_enable(True)
-        ctx.profile_select("gather_knn")
+        ctx.profile_select("gather_knn,gather_knn_heap_fallback")
         ctx.profile_reset()
         gsteps = max(2, min(args.steps, 5))
         barrier()
@@ -146,6 +146,7 @@ def main():
         barrier()
         gdt = time.perf_counter() - tg
         g_ms, g_launches = ctx.profile_get("gather_knn")
+        fb_ms, fb_launches = ctx.profile_get("gather_knn_heap_fallback")
         ctx.profile_enable(False)
         gathers = hits.shape[0] * gsteps
         gps = torch.tensor([gathers / gdt], dtype=torch.float64, device=dev)
@@ -153,8 +154,9 @@ def main():
             dist.all_reduce(gps, op=dist.ReduceOp.SUM)
         g_achieved = hits.shape[0] * BYTES_PER_GATHER / (g_ms / g_launches * 1e-3) / 1e9
         extra = {"knn_gathers_per_s": float(gps.item()), "knn_k": args.knn, "photons": args.photons,
-                 "kd_build_s": build_s, "gather_ms_per_step": gdt / gsteps * 1e3}
-        roof_gather = {"kernel": "k_gather_knn", "bound": "hbm", "achieved": g_achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                 "kd_build_s": build_s, "gather_ms_per_step": gdt / gsteps * 1e3,
+                 "heap_fallback_ms_per_step": fb_ms / gsteps, "heap_fallback_launches": fb_launches}
+        roof_gather = {"kernel": "k_gather_knn_wave", "bound": "hbm", "achieved": g_achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                        "frac": g_achieved / PEAK_HBM_GBS, "traffic": None,
                        "algorithmic_bytes_per_gather": BYTES_PER_GATHER, "avg_launch_ms": g_ms / g_launches}
 

@@ -402,11 +402,17 @@ __global__ void __launch_bounds__(256) k_gather_radius(DevMap M, const float *hi
   rgb[(size_t)q * 3 + 2] = sb * (h[8] / 255.0f) * inv_area;
 }
 
-// `only` (optional): one flag per workgroup; workgroups whose flag is 0 have nothing to do (k_gather_knn_wave served them)
-__global__ void __launch_bounds__(KNN_LANES) k_gather_knn(DevMap M, const float *hits, uint32_t nq, uint32_t k, float *rgb, const uint8_t *only) {
+// `units` (optional): the work units of k_gather_knn_wave (see knn_unit_query) that it left over, one per workgroup;
+// without it workgroup b serves queries [64 b, 64 b + 64)
+__global__ void __launch_bounds__(KNN_LANES) k_gather_knn(DevMap M, const float *hits, uint32_t nq, uint32_t k, float *rgb, const uint32_t *units,
+                                                          const uint32_t *groups, uint32_t sub) {
   extern __shared__ double knn_lds[];
-  if (only && !only[blockIdx.x]) return;
   uint32_t q = blockIdx.x * KNN_LANES + threadIdx.x;
+  if (units) {
+    const uint32_t u = units[blockIdx.x], per = 64 / sub;
+    if (threadIdx.x >= per) return;
+    q = groups[u / sub] * 64 + (u % sub) * per + threadIdx.x;
+  }
   KnnHeap H; H.d2 = knn_lds; H.slot = (uint32_t *)(knn_lds + (size_t)k * KNN_LANES); H.perm = M.perm; H.k = k; H.size = 0; H.lane = threadIdx.x;
   if (q >= nq) return;
   const float *h = hits + (size_t)q * 9;
@@ -448,13 +454,25 @@ __device__ __forceinline__ double wave_min_d(double v) { for (int o = 32; o > 0;
 __device__ __forceinline__ double wave_max_d(double v) { for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64)); return v; }
 __device__ __forceinline__ uint32_t lanes_below(unsigned long long mask, int lane) { return (uint32_t)__popcll(mask & (((unsigned long long)1 << lane) - 1)); }
 
+// Work units: workgroup u serves queries [64 u, 64 u + 64) when `groups` is null; otherwise it serves the `sub`-th part
+// (64 / sub consecutive queries, sub a power of two) of group groups[u / sub] -- the second pass over groups whose
+// 64 queries were too spread out, with lanes beyond the part shadowing its queries.
+__device__ __forceinline__ bool knn_unit_query(const uint32_t *groups, uint32_t sub, uint32_t nq, int lane, uint32_t *q_out) {
+  if (!groups) { *q_out = blockIdx.x * 64 + lane; return *q_out < nq; }
+  const uint32_t per = 64 / sub;
+  const uint32_t q = groups[blockIdx.x / sub] * 64 + (blockIdx.x % sub) * per + ((uint32_t)lane % per);
+  *q_out = q;
+  return (uint32_t)lane < per && q < nq;
+}
+
 __global__ void __launch_bounds__(64) k_gather_knn_wave(DevMap M, const float *hits, uint32_t nq, uint32_t k, double r0, float *rgb,
-                                                        uint8_t *fallback) {
+                                                        uint8_t *fallback, const uint32_t *groups, uint32_t sub) {
   __shared__ float4 cand[KNN2_CAP];                  // x y z, slot (as bits)
   __shared__ uint32_t front[2][KNN2_FRONT];
   const int lane = threadIdx.x;
-  const uint32_t q = blockIdx.x * 64 + lane;
-  const uint32_t qq = q < nq ? q : nq - 1;           // surplus lanes shadow the last query (no output)
+  uint32_t q;
+  const bool valid = knn_unit_query(groups, sub, nq, lane, &q);
+  const uint32_t qq = q < nq ? q : nq - 1;           // surplus lanes shadow a query (no output)
   const float *h = hits + (size_t)qq * 9;
   const double x0 = h[0], x1 = h[1], x2 = h[2];
   const float nx = h[3], ny = h[4], nz = h[5];
@@ -571,7 +589,7 @@ __global__ void __launch_bounds__(64) k_gather_knn_wave(DevMap M, const float *h
     }
   }
   if (lane == 0) fallback[blockIdx.x] = 0;
-  if (q < nq) {
+  if (valid) {
     const double r2 = dk2;                                       // squared distance of the k-th nearest
     const float inv_area = (float)(1.0 / (3.141592653589793 * r2));
     rgb[(size_t)q * 3] = sr * (h[6] / 255.0f) * inv_area;
@@ -580,14 +598,18 @@ __global__ void __launch_bounds__(64) k_gather_knn_wave(DevMap M, const float *h
   }
 }
 
-// number of set flags (one workgroup; the flag array is short)
-__global__ void __launch_bounds__(256) k_count_flags(const uint8_t *flags, uint32_t n, uint32_t *out) {
+// list of the set flags' positions, in order, and their number (one workgroup; the flag array is short)
+__global__ void __launch_bounds__(256) k_compact_flags(const uint8_t *flags, uint32_t n, uint32_t *list, uint32_t *out_count) {
   __shared__ uint32_t part[256];
+  const uint32_t chunk = (n + 255) / 256, lo = threadIdx.x * chunk, hi = min(n, lo + chunk);
   uint32_t c = 0;
-  for (uint32_t i = threadIdx.x; i < n; i += 256) c += flags[i] ? 1u : 0u;
+  for (uint32_t i = lo; i < hi; i++) c += flags[i] ? 1u : 0u;
   part[threadIdx.x] = c;
   __syncthreads();
-  if (threadIdx.x == 0) { uint32_t t = 0; for (int i = 0; i < 256; i++) t += part[i]; *out = t; }
+  uint32_t base = 0;
+  for (uint32_t t = 0; t < threadIdx.x; t++) base += part[t];
+  for (uint32_t i = lo; i < hi; i++) if (flags[i]) { if (base < n) list[base] = i; base++; }
+  if (threadIdx.x == 255) *out_count = base;
 }
 
 extern "C" int rt_gather_radiance(rt_photon_map *m, const float *hits, uint32_t nq, double r, uint32_t k, float *rgb_out) {
@@ -604,7 +626,6 @@ extern "C" int rt_gather_radiance(rt_photon_map *m, const float *hits, uint32_t 
   } else {
     const uint32_t blocks = div_up(nq, KNN_LANES);
     bool heap_all = m->n < k || m->n < 2 * KNN2_CAP || getenv("RT355_KNN_HEAP") != nullptr;     // small maps: nothing to gain
-    uint8_t *flags = nullptr;
     if (!heap_all) {
       // first radius: the k-th neighbour distance if the photons were spread evenly over the faces of their bounding box
       const double dx = (double)m->bbox[3] - m->bbox[0], dy = (double)m->bbox[4] - m->bbox[1], dz = (double)m->bbox[5] - m->bbox[2];
@@ -612,20 +633,44 @@ extern "C" int rt_gather_radiance(rt_photon_map *m, const float *hits, uint32_t 
       double r0 = area > 0 ? 1.2 * sqrt((double)k * area / (3.141592653589793 * (double)m->n)) : (dx + dy + dz) * (double)k / (double)m->n;
       if (!(r0 > 0)) r0 = 1e-6;
       if (const char *e = getenv("RT355_KNN_R0")) r0 = atof(e);
-      RT_HIP(ctx, m->ws_flags.reserve((size_t)blocks + 16));
-      flags = m->ws_flags.as<uint8_t>();
-      RT_LAUNCH(ctx, "gather_knn", k_gather_knn_wave, blocks, 64, m->view(), (const float *)dh, nq, k, r0, (float *)dout, flags);
-      RT_LAUNCH(ctx, "gather_knn_flags", k_count_flags, 1, 256, flags, blocks, (uint32_t *)(flags + (((size_t)blocks + 3) & ~(size_t)3)));
-      RT_HIP(ctx, hipMemcpyAsync(ctx->pinned, flags + (((size_t)blocks + 3) & ~(size_t)3), 4, hipMemcpyDeviceToHost, ctx->stream));
+      // pass 1: one wave per 64 consecutive queries.  pass 2: the groups whose queries were too spread out for the LDS
+      // buffers, again with the wave kernel, in KNN_SPLIT parts each.  pass 3: parts still left over, per-lane heaps.
+      const uint32_t KNN_SPLIT = 64;                      // one query per wave: its box is a point and always fits
+      const size_t units2_max = (size_t)blocks * KNN_SPLIT;
+      RT_HIP(ctx, m->ws_flags.reserve(((size_t)blocks + units2_max) * 5 + 64));
+      uint32_t *list1 = m->ws_flags.as<uint32_t>(), *count1 = list1 + blocks;
+      uint32_t *list2 = count1 + 1, *count2 = list2 + units2_max;
+      uint8_t *flags1 = (uint8_t *)(count2 + 1), *flags2 = flags1 + blocks;
+      RT_LAUNCH(ctx, "gather_knn", k_gather_knn_wave, blocks, 64, m->view(), (const float *)dh, nq, k, r0, (float *)dout, flags1,
+                (const uint32_t *)nullptr, 1u);
+      RT_LAUNCH(ctx, "gather_knn_flags", k_compact_flags, 1, 256, flags1, blocks, list1, count1);
+      RT_HIP(ctx, hipMemcpyAsync(ctx->pinned, count1, 4, hipMemcpyDeviceToHost, ctx->stream));
       RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-      if (ctx->pinned[0] == 0) flags = nullptr;             // every wave succeeded
-      else heap_all = true;                                 // some waves left their queries to the per-lane heap kernel
+      const uint32_t left1 = ctx->pinned[0] <= blocks ? ctx->pinned[0] : blocks;
+      uint32_t left2 = 0;
+      if (left1 > 0) {
+        const uint32_t units2 = left1 * KNN_SPLIT;
+        RT_LAUNCH(ctx, "gather_knn_split", k_gather_knn_wave, units2, 64, m->view(), (const float *)dh, nq, k, r0, (float *)dout, flags2,
+                  (const uint32_t *)list1, KNN_SPLIT);
+        RT_LAUNCH(ctx, "gather_knn_flags", k_compact_flags, 1, 256, flags2, units2, list2, count2);
+        RT_HIP(ctx, hipMemcpyAsync(ctx->pinned, count2, 4, hipMemcpyDeviceToHost, ctx->stream));
+        RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        left2 = ctx->pinned[0] <= units2 ? ctx->pinned[0] : units2;
+        if (left2 > 0) {
+          RT_HIP(ctx, hipFuncSetAttribute((const void *)k_gather_knn, hipFuncAttributeMaxDynamicSharedMemorySize, knn_lds_bytes(k)));
+          KernelTimer timer_(ctx, "gather_knn_heap_fallback");
+          hipLaunchKernelGGL(k_gather_knn, dim3(left2), dim3(KNN_LANES), knn_lds_bytes(k), ctx->stream, m->view(),
+                             (const float *)dh, nq, k, (float *)dout, (const uint32_t *)list2, (const uint32_t *)list1, KNN_SPLIT);
+        }
+      }
+      if (getenv("RT355_KNN_VERBOSE"))
+        fprintf(stderr, "rt_gather_radiance: %u query groups; %u split into %u parts each; %u parts left to the heap kernel\n", blocks, left1, KNN_SPLIT, left2);
     }
     if (heap_all) {
       RT_HIP(ctx, hipFuncSetAttribute((const void *)k_gather_knn, hipFuncAttributeMaxDynamicSharedMemorySize, knn_lds_bytes(k)));
-      KernelTimer timer_(ctx, flags ? "gather_knn_heap_fallback" : "gather_knn");
+      KernelTimer timer_(ctx, "gather_knn");
       hipLaunchKernelGGL(k_gather_knn, dim3(blocks), dim3(KNN_LANES), knn_lds_bytes(k), ctx->stream, m->view(),
-                         (const float *)dh, nq, k, (float *)dout, (const uint8_t *)flags);
+                         (const float *)dh, nq, k, (float *)dout, (const uint32_t *)nullptr, (const uint32_t *)nullptr, 1u);
     }
   }
   RT_TRY(rt_stage_out_end(ctx, rgb_out, (size_t)nq * 12, to));
