@@ -538,17 +538,49 @@ __global__ void __launch_bounds__(64) k_gather_knn_wave(DevMap M, const float *h
     b = dmax * 2.0 + 1e-300; fb = m;                             // m = n >= k (the host sends smaller maps to k_gather_knn)
   }
   bool done = (fb == k); double tau = b; bool tie = false; double tie_v = 0.0; uint32_t need = 0;
+  // The count of candidates closer than t grows almost linearly with t (photons lie on surfaces), so a few
+  // interpolation steps bracket the k-th distance.  While some lane's bracket still holds many candidates a pass only
+  // counts, at three pivots around the interpolated guess; once every bracket is narrow the passes also track the
+  // candidate values next to the pivot, which is what settles the exact k-th value and ties.
   int pass = 0;
   for (; pass < 200 && !__all(done); pass++) {
-    double t = (pass % 3 == 2) ? 0.5 * (a + b) : a + (b - a) * (((double)k + 0.5 - (double)fa) / ((double)fb - (double)fa));
+    const double span = (double)fb - (double)fa;                  // candidates in [a, b), > 0
+    const bool narrow = span <= 6.0 || pass >= 5;
+    double t = (pass % 3 == 2) ? 0.5 * (a + b) : a + (b - a) * (((double)k + 0.5 - (double)fa) / span);
     if (!(t > a && t < b)) t = 0.5 * (a + b);
+    if (__any(!done && !narrow)) {
+      // ---- counting pass, pivots t1 < t < t3
+      const double dt = (b - a) / span * (1.0 + 0.6 * sqrt(span));
+      double t1 = t - dt, t3 = t + dt;
+      if (!(t1 > a)) t1 = 0.5 * (a + t);
+      if (!(t3 < b)) t3 = 0.5 * (t + b);
+      uint32_t c1 = 0, c2 = 0, c3 = 0;
+      for (uint32_t j = 0; j < m; j++) {
+        const float4 cd = cand[j];
+        const double d2 = sq_dist(x0, x1, x2, (double)cd.x, (double)cd.y, (double)cd.z);
+        c1 += d2 < t1 ? 1u : 0u; c2 += d2 < t ? 1u : 0u; c3 += d2 < t3 ? 1u : 0u;
+      }
+      if (done || !(t1 > a && t1 < t && t < t3 && t3 < b)) continue;       // (a degenerate bracket waits for the tracking passes)
+      if (c1 == k) { done = true; tau = t1; }
+      else if (c2 == k) { done = true; tau = t; }
+      else if (c3 == k) { done = true; tau = t3; }
+      else {
+        if (c3 < k) { a = t3; fa = c3; } else if (c2 < k) { a = t; fa = c2; } else if (c1 < k) { a = t1; fa = c1; }
+        if (c1 > k) { b = t1; fb = c1; } else if (c2 > k) { b = t; fb = c2; } else if (c3 > k) { b = t3; fb = c3; }
+      }
+      continue;
+    }
+    // ---- tracking pass
     if (!(t > a && t < b)) t = b;                                // a and b are neighbouring doubles: count below b, ties sit at a
     uint32_t cnt = 0, ties = 0; double lmax = -1.0, rmin = __builtin_huge_val();
     for (uint32_t j = 0; j < m; j++) {
       const float4 cd = cand[j];
       const double d2 = sq_dist(x0, x1, x2, (double)cd.x, (double)cd.y, (double)cd.z);
-      if (d2 < t) { cnt++; if (d2 > lmax) { lmax = d2; ties = 1; } else if (d2 == lmax) ties++; }
-      else rmin = fmin(rmin, d2);
+      const bool lt = d2 < t, up = lt && d2 > lmax, eq = lt && d2 == lmax;
+      cnt += lt ? 1u : 0u;
+      ties = up ? 1u : ties + (eq ? 1u : 0u);
+      lmax = up ? d2 : lmax;
+      rmin = (!lt && d2 < rmin) ? d2 : rmin;
     }
     if (done) continue;
     if (cnt == k) { done = true; tau = t; }
