@@ -480,7 +480,10 @@ __global__ void __launch_bounds__(64) k_gather_knn_wave(DevMap M, const float *h
   const double bh0 = wave_max_d(x0), bh1 = wave_max_d(x1), bh2 = wave_max_d(x2);
   const uint32_t n = M.n;
   double R = r0;
-  uint32_t m = 0, c = 0;
+  uint32_t m = 0, c = 0, pc1 = 0, pc2 = 0, pc3 = 0;
+  // pivots of the first counting pass: r0 is 1.2 x the expected k-th distance
+  const double pt2 = r0 * r0 / 1.44, pdt = pt2 / (double)k * (1.0 + 0.6 * sqrt((double)k));
+  const double pt1 = pt2 - pdt > 0.0 ? pt2 - pdt : 0.5 * pt2, pt3 = pt2 + pdt < r0 * r0 ? pt2 + pdt : 0.5 * (pt2 + r0 * r0);
   bool ok = false, overflow = false, all_in = false;
   for (int attempt = 0; attempt < 40 && !ok && !overflow; attempt++) {
     const double g = R * (1.0 + 1e-9);               // (the box test must not lose a photon to the rounding of lo/hi)
@@ -521,10 +524,15 @@ __global__ void __launch_bounds__(64) k_gather_knn_wave(DevMap M, const float *h
       cur ^= 1; ncur = nnext;
     }
     if (overflow) break;
-    // ---- 2. does every query have k candidates within R?
+    // ---- 2. does every query have k candidates within R?  (the same pass counts at three pivots around the k-th
+    // distance the first radius was derived from: the first step of the search below)
     const double R2 = R * R;
-    c = 0;
-    for (uint32_t j = 0; j < m; j++) { const float4 cd = cand[j]; c += sq_dist(x0, x1, x2, (double)cd.x, (double)cd.y, (double)cd.z) < R2 ? 1u : 0u; }
+    c = 0; pc1 = 0; pc2 = 0; pc3 = 0;
+    for (uint32_t j = 0; j < m; j++) {
+      const float4 cd = cand[j];
+      const double d2 = sq_dist(x0, x1, x2, (double)cd.x, (double)cd.y, (double)cd.z);
+      c += d2 < R2 ? 1u : 0u; pc1 += d2 < pt1 ? 1u : 0u; pc2 += d2 < pt2 ? 1u : 0u; pc3 += d2 < pt3 ? 1u : 0u;
+    }
     all_in = (m == n);                               // the box holds the whole map: exact whatever R is
     if (__all(c >= k) || all_in) ok = true; else R *= 1.5;
     __syncthreads();                                 // (the next walk overwrites cand / front)
@@ -538,6 +546,15 @@ __global__ void __launch_bounds__(64) k_gather_knn_wave(DevMap M, const float *h
     b = dmax * 2.0 + 1e-300; fb = m;                             // m = n >= k (the host sends smaller maps to k_gather_knn)
   }
   bool done = (fb == k); double tau = b; bool tie = false; double tie_v = 0.0; uint32_t need = 0;
+  if (!done && !(all_in && c < k)) {                             // bracket from the first pass's pivots (0 < pt1 < pt2 < pt3 < R^2)
+    if (pc1 == k) { done = true; tau = pt1; }
+    else if (pc2 == k) { done = true; tau = pt2; }
+    else if (pc3 == k) { done = true; tau = pt3; }
+    else {
+      if (pc3 < k) { a = pt3; fa = pc3; } else if (pc2 < k) { a = pt2; fa = pc2; } else if (pc1 < k) { a = pt1; fa = pc1; }
+      if (pc1 > k) { b = pt1; fb = pc1; } else if (pc2 > k) { b = pt2; fb = pc2; } else if (pc3 > k) { b = pt3; fb = pc3; }
+    }
+  }
   // The count of candidates closer than t grows almost linearly with t (photons lie on surfaces), so a few
   // interpolation steps bracket the k-th distance.  While some lane's bracket still holds many candidates a pass only
   // counts, at three pivots around the interpolated guess; once every bracket is narrow the passes also track the
