@@ -447,8 +447,18 @@ __global__ void __launch_bounds__(KNN_LANES) k_gather_knn(DevMap M, const float 
 // Distances are the same fp64 expression as everywhere else (sq_dist), ties at the k-th distance go to the lowest
 // input index, so the selected set is exactly the one rt_kd_knn returns.  A wave whose candidate list or frontier
 // would overflow its LDS buffers reports that in fallback[] and leaves its queries to k_gather_knn.
+#ifndef KNN2_CAP
 #define KNN2_CAP 512
+#endif
+#ifndef KNN2_FRONT
 #define KNN2_FRONT 256
+#endif
+#ifdef RT_KNN_PROBE
+__device__ unsigned long long knn_probe[8];          // cycles (lane 0 of every wave): walk, radius check, search, ties, sum; [5] waves, [6] passes, [7] candidates
+#define KNN_PROBE(k) { if (lane == 0) { long long t1_ = clock64(); atomicAdd(&knn_probe[k], (unsigned long long)(t1_ - pt0)); pt0 = t1_; } }
+#else
+#define KNN_PROBE(k)
+#endif
 
 __device__ __forceinline__ double wave_min_d(double v) { for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o, 64)); return v; }
 __device__ __forceinline__ double wave_max_d(double v) { for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64)); return v; }
@@ -480,6 +490,9 @@ __global__ void __launch_bounds__(64) k_gather_knn_wave(DevMap M, const float *h
   const double bh0 = wave_max_d(x0), bh1 = wave_max_d(x1), bh2 = wave_max_d(x2);
   const uint32_t n = M.n;
   double R = r0;
+#ifdef RT_KNN_PROBE
+  long long pt0 = clock64();
+#endif
   uint32_t m = 0, c = 0, pc1 = 0, pc2 = 0, pc3 = 0;
   // pivots of the first counting pass: r0 is 1.2 x the expected k-th distance
   const double pt2 = r0 * r0 / 1.44, pdt = pt2 / (double)k * (1.0 + 0.6 * sqrt((double)k));
@@ -489,6 +502,9 @@ __global__ void __launch_bounds__(64) k_gather_knn_wave(DevMap M, const float *h
     const double g = R * (1.0 + 1e-9);               // (the box test must not lose a photon to the rounding of lo/hi)
     const double lo0 = bl0 - g, lo1 = bl1 - g, lo2 = bl2 - g, hi0 = bh0 + g, hi1 = bh1 + g, hi2 = bh2 + g;
     // ---- 1. cooperative box walk
+#ifdef RT_KNN_PROBE
+    pt0 = clock64();
+#endif
     m = 0;
     uint32_t ncur = 1; int cur = 0;
     if (lane == 0) front[0][0] = 1;
@@ -524,6 +540,7 @@ __global__ void __launch_bounds__(64) k_gather_knn_wave(DevMap M, const float *h
       cur ^= 1; ncur = nnext;
     }
     if (overflow) break;
+    KNN_PROBE(0)
     // ---- 2. does every query have k candidates within R?  (the same pass counts at three pivots around the k-th
     // distance the first radius was derived from: the first step of the search below)
     const double R2 = R * R;
@@ -533,6 +550,7 @@ __global__ void __launch_bounds__(64) k_gather_knn_wave(DevMap M, const float *h
       const double d2 = sq_dist(x0, x1, x2, (double)cd.x, (double)cd.y, (double)cd.z);
       c += d2 < R2 ? 1u : 0u; pc1 += d2 < pt1 ? 1u : 0u; pc2 += d2 < pt2 ? 1u : 0u; pc3 += d2 < pt3 ? 1u : 0u;
     }
+    KNN_PROBE(1)
     all_in = (m == n);                               // the box holds the whole map: exact whatever R is
     if (__all(c >= k) || all_in) ok = true; else R *= 1.5;
     __syncthreads();                                 // (the next walk overwrites cand / front)
@@ -607,6 +625,10 @@ __global__ void __launch_bounds__(64) k_gather_knn_wave(DevMap M, const float *h
     else { b = lmax; fb = cnt - ties; }
   }
   if (!__all(done)) { if (lane == 0) fallback[blockIdx.x] = 1; return; }
+  KNN_PROBE(2)
+#ifdef RT_KNN_PROBE
+  if (lane == 0) { atomicAdd(&knn_probe[5], 1ull); atomicAdd(&knn_probe[6], (unsigned long long)pass); atomicAdd(&knn_probe[7], (unsigned long long)m); }
+#endif
   // ties at the k-th distance: the `need` lowest input indices among the candidates at distance tie_v
   int32_t idx_thr = -1;
   if (__any(tie)) {
@@ -622,21 +644,36 @@ __global__ void __launch_bounds__(64) k_gather_knn_wave(DevMap M, const float *h
       if (left > 0) { idx_thr = best; left--; }
     }
   }
+  KNN_PROBE(3)
   // ---- 4. radiance of the selected candidates
+  // The candidates' payloads (direction, power * colour) come in through LDS, 64 at a time: one scattered load per
+  // lane and chunk instead of one dependent global load per candidate.
   float sr = 0, sg = 0, sb = 0; double dk2 = 0.0;
-  for (uint32_t j = 0; j < m; j++) {
-    const float4 cd = cand[j];
-    const uint32_t slot = __float_as_uint(cd.w);
-    const double d2 = sq_dist(x0, x1, x2, (double)cd.x, (double)cd.y, (double)cd.z);
-    bool sel;
-    if (tie) sel = d2 < tie_v || (d2 == tie_v && M.perm[slot] <= idx_thr);
-    else sel = d2 < tau;
-    if (__any(sel)) {
-      const float *pp = M.pay + (size_t)slot * 6;                // wave-uniform address
-      const float w = fmaxf(0.0f, pp[0] * nx + pp[1] * ny + pp[2] * nz);
-      if (sel) { sr += pp[3] * w; sg += pp[4] * w; sb += pp[5] * w; dk2 = fmax(dk2, d2); }
+  float *pay_lds = (float *)&front[0][0];                        // 64 x 6 floats; the frontier buffers are free now
+  static_assert(sizeof(front) >= 64 * 6 * sizeof(float), "payload staging needs 1536 bytes");
+  for (uint32_t base = 0; base < m; base += 64) {
+    __syncthreads();                                             // the previous chunk has been consumed
+    if (base + lane < m) {
+      const uint32_t slot = __float_as_uint(cand[base + lane].w);
+      const float2 *pp = (const float2 *)(M.pay + (size_t)slot * 6);      // 24-byte records: 8-byte aligned
+      const float2 p0 = pp[0], p1 = pp[1], p2 = pp[2];
+      float *dst = pay_lds + lane * 6;
+      dst[0] = p0.x; dst[1] = p0.y; dst[2] = p1.x; dst[3] = p1.y; dst[4] = p2.x; dst[5] = p2.y;
+    }
+    __syncthreads();
+    const uint32_t nc = min(64u, m - base);
+    for (uint32_t jj = 0; jj < nc; jj++) {
+      const float4 cd = cand[base + jj];
+      const double d2 = sq_dist(x0, x1, x2, (double)cd.x, (double)cd.y, (double)cd.z);
+      bool sel;
+      if (tie) sel = d2 < tie_v || (d2 == tie_v && M.perm[__float_as_uint(cd.w)] <= idx_thr);
+      else sel = d2 < tau;
+      const float *pl = pay_lds + jj * 6;
+      const float w = fmaxf(0.0f, pl[0] * nx + pl[1] * ny + pl[2] * nz);
+      if (sel) { sr += pl[3] * w; sg += pl[4] * w; sb += pl[5] * w; dk2 = fmax(dk2, d2); }
     }
   }
+  KNN_PROBE(4)
   if (lane == 0) fallback[blockIdx.x] = 0;
   if (valid) {
     const double r2 = dk2;                                       // squared distance of the k-th nearest
@@ -712,6 +749,16 @@ extern "C" int rt_gather_radiance(rt_photon_map *m, const float *hits, uint32_t 
                              (const float *)dh, nq, k, (float *)dout, (const uint32_t *)list2, (const uint32_t *)list1, KNN_SPLIT);
         }
       }
+#ifdef RT_KNN_PROBE
+      if (getenv("RT355_KNN_VERBOSE")) {
+        unsigned long long hp[8], zero[8] = { 0 };
+        RT_HIP(ctx, hipMemcpyFromSymbol(hp, HIP_SYMBOL(knn_probe), sizeof hp));
+        RT_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(knn_probe), zero, sizeof zero));
+        const double w = hp[5] ? (double)hp[5] : 1.0;
+        fprintf(stderr, "knn probe per wave: walk %.0f check %.0f search %.0f ties %.0f sum %.0f cycles; passes %.2f candidates %.1f (%llu waves)\n",
+                hp[0] / w, hp[1] / w, hp[2] / w, hp[3] / w, hp[4] / w, hp[6] / w, hp[7] / w, hp[5]);
+      }
+#endif
       if (getenv("RT355_KNN_VERBOSE"))
         fprintf(stderr, "rt_gather_radiance: %u query groups; %u split into %u parts each; %u parts left to the heap kernel\n", blocks, left1, KNN_SPLIT, left2);
     }

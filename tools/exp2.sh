@@ -1,5 +1,4 @@
 set -e
-for v in u4 u1 t256; do
-  RT355_LIB=$PWD/gpurun_variants/librt355_$v.so timeout -k 10 120 python bench.py --no-cpu-baseline --no-gather > gpurun_out/exp_v$v.json
+for v in cap256 cap320 cap384; do
+  RT355_KNN_VERBOSE=1 RT355_LIB=$PWD/gpurun_variants/librt355_$v.so timeout -k 10 120 python bench.py --no-cpu-baseline --steps 5 > gpurun_out/exp_$v.json 2> gpurun_out/exp_$v.err
 done
-timeout -k 10 120 python bench.py --no-cpu-baseline --no-gather > gpurun_out/exp_vbase.json
