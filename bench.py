@@ -32,18 +32,49 @@ def flop_per_ray_pass(flat):
     return int(sum(FLOP_PER_TEST[int(t)] for t in flat.shape_meta[:, 0]))
 
 
-def cpu_baseline(flat, seed):
-    """The CPU oracle (fp64 restatement of the reference) on the same frame, one host core."""
+def cpu_baseline(flat, seed, budget_s=12.0):
+    """The CPU oracle (fp64 restatement of the reference) on the same workload, one host core: whole frames with
+    successive seeds until about budget_s seconds have been spent."""
     from oracle import oracle as ora
     osc = ora.Scene(flat)
-    op = ora.params(seed=seed, use_direct_light=0, use_photon_maps=0)
-    rows = flat.height
+    rays_total, frames = 0, 0
     t0 = time.perf_counter()
-    _, _, rays, _ = ora.render(osc, op, None, 0, 0, flat.width, rows)
+    while True:
+        op = ora.params(seed=seed + frames, use_direct_light=0, use_photon_maps=0)
+        _, _, rays, _ = ora.render(osc, op, None, 0, 0, flat.width, flat.height)
+        rays_total += rays
+        frames += 1
+        dt = time.perf_counter() - t0
+        if dt >= budget_s or frames >= 64:
+            break
+    return {"value": rays_total / dt / 1e6, "unit": "Mrays/s", "cores": 1, "kind": "port",
+            "sample": f"{frames} full {flat.width}x{flat.height} frames of the same workload (seeds {seed}..{seed + frames - 1}), "
+                      f"{rays_total} rays in {dt:.2f} s, oracle/rt_oracle.c (fp64, bit-exact with the reference JS on its golden frames)"}
+
+
+def cpu_baseline_gather(rec, hits, k, n_queries=100_000):
+    """CPU side of the photon-map leg: the oracle's kd-tree (the reference's makeTree / nearestNeighbours restated in C)
+    built on the same photons, and its radius query at the radius that holds k photons on average -- the reference has
+    no k-nearest query -- for a sample of the same hit points, one core."""
+    from oracle import oracle as ora
+    pos = np.ascontiguousarray(rec[:, :3])
+    t0 = time.perf_counter()
+    perm, dim = ora.kd_build(pos)
+    build_s = time.perf_counter() - t0
+    lo, hi = pos.min(axis=0), pos.max(axis=0)
+    d = hi - lo
+    area = 2.0 * (d[0] * d[1] + d[1] * d[2] + d[2] * d[0])
+    r = float(np.sqrt(k * area / (np.pi * pos.shape[0])))
+    rows = np.random.default_rng(0).choice(hits.shape[0], min(n_queries, hits.shape[0]), replace=False)
+    q = hits[rows, :3].astype(np.float64)
+    t0 = time.perf_counter()
+    found = 0
+    for i in range(q.shape[0]):
+        found += ora.kd_radius(pos, perm, dim, q[i], r, cap=1024).size
     dt = time.perf_counter() - t0
-    return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": 1, "kind": "port",
-            "sample": f"the full {flat.width}x{rows} frame of the same workload, {rays} rays in {dt:.2f} s, "
-                      "oracle/rt_oracle.c (fp64, bit-exact with the reference JS on its golden frame)"}
+    return {"value": q.shape[0] / dt, "unit": "gathers/s", "cores": 1, "kind": "port", "kd_build_s": build_s,
+            "sample": f"{q.shape[0]} of the {hits.shape[0]} hit points, radius query r={r:.4f} ({found / q.shape[0]:.1f} photons per query) "
+                      f"on the oracle's kd-tree of the same {pos.shape[0]} photons, {dt:.2f} s"}
 
 
 def main():
@@ -90,11 +121,11 @@ def main():
     def step():
         return sc.trace_tile(p, out_rgba8=frame, want=())["stats"]
 
-    for _ in range(args.warmup):
-        step()
     ctx.profile_enable(os.environ.get("RT355_BENCH_NO_EVENTS") is None)
-    ctx.profile_select(None if os.environ.get("RT355_BENCH_ALL_EVENTS") else "primary,tail")   # time the two trace kernels only
-    ctx.profile_reset()
+    ctx.profile_select(None if os.environ.get("RT355_BENCH_ALL_EVENTS") else "primary")   # time the roofline kernel only: every event pair costs ~8 us of stream time
+    for _ in range(max(args.warmup, 1)):
+        step()
+    ctx.profile_reset()                     # (the warm-up's timing events go back to the library's pool)
     barrier()
     t0 = time.perf_counter()
     rays = 0
@@ -107,7 +138,13 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     k_ms, k_launches = ctx.profile_get("primary")        # the fused first pass: the roofline kernel
-    tail_ms, _ = ctx.profile_get("tail")
+    # the tail kernel's duration, for the report only: a few extra steps outside the timed region
+    ctx.profile_select("tail")
+    ctx.profile_reset()
+    for _ in range(3):
+        step()
+    tail_ms, tail_launches = ctx.profile_get("tail")
+    tail_ms = tail_ms / max(1, tail_launches) * args.steps
     ctx.profile_enable(False)
 
     tot = torch.tensor([float(rays), dt], dtype=torch.float64, device=dev)
@@ -126,8 +163,9 @@ def main():
     extra = {}
     roof_gather = None
     if not args.no_gather:
-        rec = torch.from_numpy(synth.box_photons(args.photons, seed=7)).to(dev)
-        hits = torch.from_numpy(synth.box_queries(W, H)).to(dev)
+        rec_host, hits_host = synth.box_photons(args.photons, seed=7), synth.box_queries(W, H)
+        rec = torch.from_numpy(rec_host).to(dev)
+        hits = torch.from_numpy(hits_host).to(dev)
         rgb = torch.empty((hits.shape[0], 3), dtype=torch.float32, device=dev)
         torch.cuda.synchronize()
         tb = time.perf_counter()
@@ -183,6 +221,8 @@ def main():
         line["extra"] = extra
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(flat, seed)
+            if not args.no_gather:
+                line["cpu_baseline_gather"] = cpu_baseline_gather(rec_host, hits_host, args.knn)
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

@@ -85,6 +85,7 @@ void rt_shutdown(rt_ctx *ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   for (auto &kv : ctx->events) for (auto &ev : kv.second) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+  for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
   (void)hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -107,7 +108,7 @@ int rt_profile_select(rt_ctx *ctx, const char *kernels) {
 int rt_profile_reset(rt_ctx *ctx) {
   if (!ctx) return RT_ERR_INVALID;
   RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  for (auto &kv : ctx->events) for (auto &ev : kv.second) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+  for (auto &kv : ctx->events) for (auto &ev : kv.second) { ctx->event_pool.push_back(ev.first); ctx->event_pool.push_back(ev.second); }
   ctx->events.clear();
   return RT_OK;
 }

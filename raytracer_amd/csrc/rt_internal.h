@@ -19,6 +19,11 @@ struct rt_ctx {
   bool profiling = false;
   std::string profile_only;      // when non-empty: ",name1,name2," -- only launches under these names are timed
   std::map<std::string, std::vector<std::pair<hipEvent_t, hipEvent_t>>> events;
+  std::vector<hipEvent_t> event_pool;   // events free for reuse (creating one per launch costs more than recording it)
+  hipEvent_t take_event() {
+    if (!event_pool.empty()) { hipEvent_t e = event_pool.back(); event_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr; (void)hipEventCreate(&e); return e;
+  }
   uint32_t *pinned = nullptr;    // small pinned scratch for counters read back each bounce
 };
 
@@ -59,7 +64,7 @@ int rt_stage_out_end(rt_ctx *ctx, void *dst, size_t bytes, DevMem &tmp);
 struct KernelTimer {
   rt_ctx *ctx; hipEvent_t a = nullptr, b = nullptr; const char *name;
   KernelTimer(rt_ctx *c, const char *n) : ctx(c), name(n) {
-    if (ctx->profiling && (ctx->profile_only.empty() || ctx->profile_only.find("," + std::string(n) + ",") != std::string::npos)) { (void)hipEventCreate(&a); (void)hipEventCreate(&b); (void)hipEventRecord(a, ctx->stream); }
+    if (ctx->profiling && (ctx->profile_only.empty() || ctx->profile_only.find("," + std::string(n) + ",") != std::string::npos)) { a = ctx->take_event(); b = ctx->take_event(); (void)hipEventRecord(a, ctx->stream); }
   }
   ~KernelTimer() {
     if (a) { (void)hipEventRecord(b, ctx->stream); ctx->events[name].push_back({ a, b }); }

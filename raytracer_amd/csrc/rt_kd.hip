@@ -62,29 +62,64 @@ __global__ void __launch_bounds__(256) k_kd_bbox_clear(uint32_t first, uint32_t 
   bbmin[(size_t)first * 3 + i] = 0xFFFFFFFFu; bbmax[(size_t)first * 3 + i] = 0u;
 }
 
-// min/max of every active segment (kdtree.js:85-92).  Waves that lie inside one segment reduce
-// across lanes first and issue one atomic per axis; mixed waves fall back to per-lane atomics.
+// min/max of every active segment (kdtree.js:85-92).  A workgroup takes KD_BBOX_ITEMS * 256 consecutive array
+// positions.  Near the root they all lie in one segment: the workgroup reduces in registers, across lanes and through
+// LDS and issues one atomic per axis and bound (thousands of same-address atomics would serialise).  Further down,
+// waves that lie inside one segment reduce across lanes first; mixed waves fall back to per-lane atomics, which by
+// then go to many different addresses.
+#define KD_BBOX_ITEMS 16
 __global__ void __launch_bounds__(256) k_kd_bbox(uint32_t n, const float *pos3, const uint32_t *idx, SegState sg,
                                                  uint32_t *bbmin, uint32_t *bbmax) {
-  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  uint32_t sp = (i < n) ? sg.pos[i] : 0;
-  uint32_t lo[3] = { 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu }, hi[3] = { 0, 0, 0 };
-  if (sp) {
-    const float *p = pos3 + (size_t)idx[i] * 3;
-    for (int d = 0; d < 3; d++) { uint32_t u = sortable(p[d]); lo[d] = u; hi[d] = u; }
-  }
-  uint32_t sp0 = __shfl(sp, 0, 64);
-  bool uniform = __all(sp == sp0 || sp == 0) && sp0 != 0;
-  if (uniform) {
+  __shared__ uint32_t red[4][6];
+  const uint32_t c0 = blockIdx.x * (256u * KD_BBOX_ITEMS);
+  if (c0 >= n) return;
+  const uint32_t c1 = min(n, c0 + 256u * KD_BBOX_ITEMS);
+  // segments are contiguous runs of active positions, so the chunk lies in one segment iff the segment of its first
+  // position reaches its end
+  const uint32_t sp_first = sg.pos[c0];
+  const bool one_segment = sp_first != 0 && sg.start[c0] + sg.len[c0] >= c1;
+  if (one_segment) {
+    uint32_t lo[3] = { 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu }, hi[3] = { 0, 0, 0 };
+    for (uint32_t i = c0 + threadIdx.x; i < c1; i += 256) {
+      const float *p = pos3 + (size_t)idx[i] * 3;
+      for (int d = 0; d < 3; d++) { uint32_t u = sortable(p[d]); lo[d] = min(lo[d], u); hi[d] = max(hi[d], u); }
+    }
     for (int off = 32; off > 0; off >>= 1)
       for (int d = 0; d < 3; d++) {
         uint32_t a = __shfl_xor(lo[d], off, 64), b = __shfl_xor(hi[d], off, 64);
         lo[d] = min(lo[d], a); hi[d] = max(hi[d], b);
       }
-    if ((threadIdx.x & 63) == 0)
-      for (int d = 0; d < 3; d++) { atomicMin(&bbmin[(size_t)sp0 * 3 + d], lo[d]); atomicMax(&bbmax[(size_t)sp0 * 3 + d], hi[d]); }
-  } else if (sp) {
-    for (int d = 0; d < 3; d++) { atomicMin(&bbmin[(size_t)sp * 3 + d], lo[d]); atomicMax(&bbmax[(size_t)sp * 3 + d], hi[d]); }
+    const int wv = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) for (int d = 0; d < 3; d++) { red[wv][d] = lo[d]; red[wv][3 + d] = hi[d]; }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+      const int d = threadIdx.x;
+      atomicMin(&bbmin[(size_t)sp_first * 3 + d], min(min(red[0][d], red[1][d]), min(red[2][d], red[3][d])));
+      atomicMax(&bbmax[(size_t)sp_first * 3 + d], max(max(red[0][3 + d], red[1][3 + d]), max(red[2][3 + d], red[3][3 + d])));
+    }
+    return;
+  }
+  for (uint32_t row = 0; row < KD_BBOX_ITEMS; row++) {            // (workgroup-uniform trip count: the shuffles below need whole waves)
+    const uint32_t i = c0 + row * 256u + threadIdx.x;
+    uint32_t sp = (i < n) ? sg.pos[i] : 0;
+    uint32_t lo[3] = { 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu }, hi[3] = { 0, 0, 0 };
+    if (sp) {
+      const float *p = pos3 + (size_t)idx[i] * 3;
+      for (int d = 0; d < 3; d++) { uint32_t u = sortable(p[d]); lo[d] = u; hi[d] = u; }
+    }
+    uint32_t sp0 = __shfl(sp, 0, 64);
+    bool uniform = __all(sp == sp0 || sp == 0) && sp0 != 0;
+    if (uniform) {
+      for (int off = 32; off > 0; off >>= 1)
+        for (int d = 0; d < 3; d++) {
+          uint32_t a = __shfl_xor(lo[d], off, 64), b = __shfl_xor(hi[d], off, 64);
+          lo[d] = min(lo[d], a); hi[d] = max(hi[d], b);
+        }
+      if ((threadIdx.x & 63) == 0)
+        for (int d = 0; d < 3; d++) { atomicMin(&bbmin[(size_t)sp0 * 3 + d], lo[d]); atomicMax(&bbmax[(size_t)sp0 * 3 + d], hi[d]); }
+    } else if (sp) {
+      for (int d = 0; d < 3; d++) { atomicMin(&bbmin[(size_t)sp * 3 + d], lo[d]); atomicMax(&bbmax[(size_t)sp * 3 + d], hi[d]); }
+    }
   }
 }
 
@@ -146,7 +181,7 @@ int rt_kd_build_device(rt_ctx *ctx, const float *d_pos, uint32_t n, int32_t *d_p
   for (uint32_t first = 1; first <= n; first <<= 1) {                   // heap positions [first, 2*first) form one level
     uint32_t count = (2 * (uint64_t)first - 1 <= n) ? first : n - first + 1;
     RT_LAUNCH(ctx, "kd_bbox_clear", k_kd_bbox_clear, div_up((uint64_t)count * 3, 256), 256, first, count, bbmin.as<uint32_t>(), bbmax.as<uint32_t>());
-    RT_LAUNCH(ctx, "kd_bbox", k_kd_bbox, grid, 256, n, d_pos, idx_cur, sg, bbmin.as<uint32_t>(), bbmax.as<uint32_t>());
+    RT_LAUNCH(ctx, "kd_bbox", k_kd_bbox, div_up(n, 256u * KD_BBOX_ITEMS), 256, n, d_pos, idx_cur, sg, bbmin.as<uint32_t>(), bbmax.as<uint32_t>());
     RT_LAUNCH(ctx, "kd_keys", k_kd_keys, grid, 256, n, d_pos, idx_cur, sg, bbmin.as<uint32_t>(), bbmax.as<uint32_t>(),
               segdim.as<uint8_t>(), keyA.as<uint64_t>());
     {

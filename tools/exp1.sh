@@ -1,4 +1,3 @@
 set -e
-timeout -k 10 400 python -u -m pytest tests -m gpu -x -q --timeout 120 --timeout-method thread > gpurun_out/gpu_tests.log 2>&1
-RT355_KNN_VERBOSE=1 RT355_LIB=$PWD/gpurun_variants/librt355_knnprobe.so timeout -k 10 200 python bench.py --no-cpu-baseline --steps 3 > gpurun_out/exp_probe.json 2> gpurun_out/exp_probe.err
-timeout -k 10 200 python bench.py --no-cpu-baseline > gpurun_out/exp_full.json 2> gpurun_out/exp_full.err
+timeout -k 10 300 python bench.py --no-cpu-baseline > gpurun_out/exp_full.json 2> gpurun_out/exp_full.err
+RT355_BENCH_NO_EVENTS=1 timeout -k 10 300 python bench.py --no-cpu-baseline --no-gather > gpurun_out/exp_noev.json 2> gpurun_out/exp_noev.err
