@@ -28,6 +28,16 @@ PEAK_HBM_GBS = 8000.0
 BYTES_PER_GATHER = 64 * 36 + 36 + 12
 
 
+def measured_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC passes of this same command (rocprofv3 cannot run
+    inside the benchmark): profiles/r01_b_traffic.json, written by tools/profile_round.sh + the extraction in DESIGN.md."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_b_traffic.json")) as f:
+            return json.load(f)[kernel]["traffic_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def flop_per_ray_pass(flat):
     return int(sum(FLOP_PER_TEST[int(t)] for t in flat.shape_meta[:, 0]))
 
@@ -195,7 +205,7 @@ def main():
                  "kd_build_s": build_s, "gather_ms_per_step": gdt / gsteps * 1e3,
                  "heap_fallback_ms_per_step": fb_ms / gsteps, "heap_fallback_launches": fb_launches}
         roof_gather = {"kernel": "k_gather_knn_wave", "bound": "hbm", "achieved": g_achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                       "frac": g_achieved / PEAK_HBM_GBS, "traffic": None,
+                       "frac": g_achieved / PEAK_HBM_GBS, "traffic": measured_traffic("k_gather_knn_wave"),
                        "algorithmic_bytes_per_gather": BYTES_PER_GATHER, "avg_launch_ms": g_ms / g_launches}
 
     if rank == 0:
@@ -210,7 +220,7 @@ def main():
                        "parallelism": f"{world} independent frame(s), one per GPU", "rays_per_step": rays // args.steps,
                        "longest_path_segments": bounces // args.steps},
             "roofline": {"kernel": "k_primary<float> (camera ray + closest-hit scan of all primitives + shade, one lane per primary ray)", "bound": "valu", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_VALU_TFLOPS, "traffic": None,
+                         "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_VALU_TFLOPS, "traffic": measured_traffic("k_primary"),
                          "algorithmic_flop_per_ray_pass": fl, "avg_launch_ms": k_ms / max(1, k_launches),
                          "launches_per_step": k_launches / args.steps, "kernel_ms_per_step": k_ms / args.steps,
                          "rays_per_launch": W * H, "tail_kernel_ms_per_step": tail_ms / args.steps,
