@@ -92,6 +92,8 @@ typedef struct rt_trace_stats {
   uint64_t bounces;             /* wavefront iterations */
   uint64_t stack_overflows;     /* paths whose material stack exceeded the fixed capacity */
   uint64_t tail_rays;           /* of `rays`: segments traced by the per-lane tail kernel instead of a wavefront pass */
+  uint64_t prim_tests;          /* ray-primitive distance tests executed for `rays` (+ shadow rays when a hierarchy is used) */
+  uint64_t prims_per_ray_brute_force;   /* primitives in the scene: rays * this = the tests of the reference's loops */
 } rt_trace_stats;
 
 typedef struct rt_emit_stats {

@@ -4,8 +4,10 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdarg.h>
+#include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <vector>
 #include "rt_emit.h"
 #include "rt_pipeline.h"
 
@@ -158,6 +160,130 @@ static void rt_fast_record(int type, int flags, const double *g, float *f) {
   for (int k = 0; k < 12; k++) f[k] = (float)r[k];
 }
 
+// ------------------------------------------------------------------ hierarchy for large scenes
+// Axis-aligned box of a primitive from the boundary's geometry slots; false for unbounded primitives (planes,
+// infinite cylinders), which stay outside the hierarchy.
+static bool rt_prim_box(int type, int flags, const double *g, double lo[3], double hi[3]) {
+  auto set = [&](const double c[3], const double e[3]) { for (int k = 0; k < 3; k++) { lo[k] = c[k] - e[k]; hi[k] = c[k] + e[k]; } };
+  switch (type) {
+    case RT_SPHERE: case RT_HEMISPHERE: { double e[3] = { g[6], g[6], g[6] }; set(g, e); return true; }
+    case RT_CYLINDER: {
+      if (!(flags & RT_FLAG_HALF_HEIGHT) || (flags & RT_FLAG_FIRST_ROOT)) return false;
+      const double n = sqrt(g[3] * g[3] + g[4] * g[4] + g[5] * g[5]);
+      double e[3];
+      for (int k = 0; k < 3; k++) { double a = n > 0 ? g[3 + k] / n : 0; double s2 = 1 - a * a; e[k] = g[7] * fabs(a) + g[6] * sqrt(s2 > 0 ? s2 : 0); }
+      set(g, e); return true;
+    }
+    case RT_TRIANGLE: case RT_SQUARE: {
+      for (int k = 0; k < 3; k++) {
+        double p0 = g[k], p1 = g[k] + g[3 + k], p2 = g[k] + g[6 + k], p3 = (type == RT_SQUARE) ? g[k] + g[3 + k] + g[6 + k] : p0;
+        lo[k] = fmin(fmin(p0, p1), fmin(p2, p3)); hi[k] = fmax(fmax(p0, p1), fmax(p2, p3));
+      }
+      return true;
+    }
+    case RT_DISC: case RT_ANNULUS: {
+      const double n = sqrt(g[3] * g[3] + g[4] * g[4] + g[5] * g[5]);
+      double e[3];
+      for (int k = 0; k < 3; k++) { double a = n > 0 ? g[3 + k] / n : 0; double s2 = 1 - a * a; e[k] = g[6] * sqrt(s2 > 0 ? s2 : 0); }
+      set(g, e); return true;
+    }
+    default: return false;                                  // plane
+  }
+}
+
+struct BvhBuild {
+  std::vector<BvhNode> nodes;
+  std::vector<uint32_t> prims;                              // leaf entries
+  std::vector<double> lo, hi;                               // per bounded item
+  std::vector<uint32_t> entry, order;                       // per bounded item: encoded entry; working permutation
+  static float down(double v) { float f = (float)v; return ((double)f > v) ? nextafterf(f, -INFINITY) : f; }
+  static float up(double v) { float f = (float)v; return ((double)f < v) ? nextafterf(f, INFINITY) : f; }
+  // nodes in depth-first order; returns the node's index
+  uint32_t build(uint32_t b, uint32_t e) {
+    double nlo[3] = { INFINITY, INFINITY, INFINITY }, nhi[3] = { -INFINITY, -INFINITY, -INFINITY };
+    double clo[3] = { INFINITY, INFINITY, INFINITY }, chi[3] = { -INFINITY, -INFINITY, -INFINITY };
+    for (uint32_t i = b; i < e; i++) {
+      const uint32_t it = order[i];
+      for (int k = 0; k < 3; k++) {
+        nlo[k] = fmin(nlo[k], lo[3 * it + k]); nhi[k] = fmax(nhi[k], hi[3 * it + k]);
+        const double c = 0.5 * (lo[3 * it + k] + hi[3 * it + k]);
+        clo[k] = fmin(clo[k], c); chi[k] = fmax(chi[k], c);
+      }
+    }
+    const uint32_t me = (uint32_t)nodes.size();
+    nodes.push_back(BvhNode());
+    for (int k = 0; k < 3; k++) {
+      // padding: the boxes only steer the walk, a box that is too large costs tests, one that is too small loses hits
+      const double pad = 1e-4 * (nhi[k] - nlo[k]) + 1e-4;
+      nodes[me].lo[k] = down(nlo[k] - pad); nodes[me].hi[k] = up(nhi[k] + pad);
+    }
+    int axis = 0;
+    for (int k = 1; k < 3; k++) if (chi[k] - clo[k] > chi[axis] - clo[axis]) axis = k;
+    if (e - b <= 4 || !(chi[axis] - clo[axis] > 0)) {
+      if (e - b > 255) {                                    // many items with one centre: chain of leaves under a split by position
+        const uint32_t mid = b + (e - b) / 2;
+        nodes[me].leaf = 0;
+        build(b, mid); build(mid, e);
+        nodes[me].skip = (uint32_t)nodes.size();
+        return me;
+      }
+      nodes[me].leaf = (uint32_t)prims.size() | ((e - b) << 24);
+      for (uint32_t i = b; i < e; i++) prims.push_back(entry[order[i]]);
+      nodes[me].skip = (uint32_t)nodes.size();
+      return me;
+    }
+    const uint32_t mid = b + (e - b) / 2;
+    std::nth_element(order.begin() + b, order.begin() + mid, order.begin() + e, [&](uint32_t x, uint32_t y) {
+      const double cx = lo[3 * x + axis] + hi[3 * x + axis], cy = lo[3 * y + axis] + hi[3 * y + axis];
+      return cx < cy || (cx == cy && x < y);
+    });
+    nodes[me].leaf = 0;
+    build(b, mid); build(mid, e);
+    nodes[me].skip = (uint32_t)nodes.size();
+    return me;
+  }
+};
+
+// Scenes whose type-sorted copy does not fit the scan kernels' LDS budget (or every scene, with RT355_BVH=1, for
+// tests) get a hierarchy; `order` maps sorted slot -> original index.
+static int rt_build_bvh(rt_ctx *ctx, const rt_scene_desc *d, const std::vector<uint32_t> &order, rt_scene *sc, bool &built) {
+  built = false;
+  const uint32_t n = d->n_shapes;
+  const char *e = getenv("RT355_BVH");
+  const bool want = e ? atoi(e) != 0 : (size_t)n * (RT_GEOM_STRIDE * 4 + 8 + RT_OT_STRIDE * 4) > 56 * 1024;
+  if (!want || n == 0) return RT_OK;
+  if (n >= (1u << 24)) return rt_fail(ctx, RT_ERR_TOO_LARGE, "hierarchy supports up to 2^24 primitives");
+  BvhBuild B;
+  std::vector<uint32_t> unbounded;
+  for (uint32_t s = 0; s < n; s++) {
+    const uint32_t i = order[s];
+    const int type = d->shape_meta[4 * i], flags = d->shape_meta[4 * i + 2];
+    const uint32_t entry = s | ((uint32_t)type << 28);
+    double lo[3], hi[3];
+    if (rt_prim_box(type, flags, d->shape_geom + (size_t)i * 12, lo, hi) && lo[0] == lo[0] && hi[0] == hi[0]) {
+      for (int k = 0; k < 3; k++) { B.lo.push_back(lo[k]); B.hi.push_back(hi[k]); }
+      B.entry.push_back(entry);
+    } else unbounded.push_back(entry);
+  }
+  B.order.resize(B.entry.size());
+  for (uint32_t i = 0; i < B.order.size(); i++) B.order[i] = i;
+  if (!B.order.empty()) B.build(0, (uint32_t)B.order.size());
+  auto up = [&](DevMem &m, const void *src, size_t bytes) -> int {
+    RT_HIP(ctx, m.alloc(bytes)); if (bytes) RT_HIP(ctx, hipMemcpy(m.p, src, bytes, hipMemcpyHostToDevice)); return RT_OK;
+  };
+  RT_TRY(up(sc->bvh_nodes, B.nodes.data(), B.nodes.size() * sizeof(BvhNode)));
+  RT_TRY(up(sc->bvh_prims, B.prims.data(), B.prims.size() * 4));
+  RT_TRY(up(sc->bvh_unbounded, unbounded.data(), unbounded.size() * 4));
+  for (int pass = 0; pass < 2; pass++) {
+    if (pass == 0) { sc->d32.bvh = sc->bvh_nodes.as<BvhNode>(); sc->d32.bvh_prims = sc->bvh_prims.as<uint32_t>(); sc->d32.unbounded = sc->bvh_unbounded.as<uint32_t>();
+                     sc->d32.n_bvh_nodes = (uint32_t)B.nodes.size(); sc->d32.n_unbounded = (uint32_t)unbounded.size(); }
+    else { sc->d64.bvh = sc->bvh_nodes.as<BvhNode>(); sc->d64.bvh_prims = sc->bvh_prims.as<uint32_t>(); sc->d64.unbounded = sc->bvh_unbounded.as<uint32_t>();
+           sc->d64.n_bvh_nodes = (uint32_t)B.nodes.size(); sc->d64.n_unbounded = (uint32_t)unbounded.size(); }
+  }
+  built = true;
+  return RT_OK;
+}
+
 template <typename T> static int upload_typed(rt_ctx *ctx, const rt_scene_desc *d, const std::vector<uint32_t> &order, DevMem &geom,
                                               DevMem &colour, DevMem &sgeom, DevMem &surface, DevScene<T> &S, rt_scene *sc) {
   const uint32_t n = d->n_shapes;
@@ -243,6 +369,8 @@ int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *d, rt_scene **out) {
       (rc = upload_typed<double>(ctx, d, order, sc->geom64, sc->colour64, sc->sgeom64, sc->surface64, sc->d64, sc))) {
     delete sc; return rc;
   }
+  bool has_bvh = false;
+  if ((rc = rt_build_bvh(ctx, d, order, sc, has_bvh))) { delete sc; return rc; }
   memcpy(sc->d32.seg, seg, sizeof seg); memcpy(sc->d64.seg, seg, sizeof seg);
   *out = sc;
   return RT_OK;

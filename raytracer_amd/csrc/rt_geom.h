@@ -10,6 +10,13 @@
 #define RT_MAX_LIGHTS 16
 #define RT_GEOM_STRIDE 12
 
+// Node of the hierarchy, nodes in depth-first order: the first child of an interior node is the next node, and `skip`
+// is the node to go on with when this node's box is missed or its subtree is done (n_bvh_nodes = end).  No stack.
+struct BvhNode {
+  float lo[3]; uint32_t skip;
+  float hi[3]; uint32_t leaf;     // 0 for interior nodes, else first entry in bvh_prims | count << 24
+};
+
 // Device view of an uploaded scene.  Shapes are kept twice: in the host's order (for shading:
 // normals, colours, materials by original index) and sorted by primitive type (for the scan
 // loops: one branch-free inner loop per type, wave-uniform primitive loads).
@@ -30,6 +37,11 @@ template <typename T> struct DevScene {
   uint32_t refl_k[8], spec_k[8];    // integer thresholds of `U < reflectance`, `U < specular`
   const T *surface;           // n x 2 per-shape reflectance, specular (ray.js shape model) or nullptr
   const uint32_t *spec_gt_k;  // per shape: smallest 24-bit draw k with k * 2^-24 > specular
+  // bounding-volume hierarchy over the bounded primitives (scenes too large for the all-primitives scan), or nullptr
+  const BvhNode *bvh;
+  const uint32_t *bvh_prims;  // leaf entries: sorted slot | type << 28
+  const uint32_t *unbounded;  // entries of the same form for planes and infinite cylinders: always tested
+  uint32_t n_bvh_nodes, n_unbounded;
 };
 
 // A miss is reported as -1 (every accepted distance is > epsilon > 0).
@@ -318,13 +330,81 @@ template <int MODE, bool OT> RT_D int scan_fast(const DevScene<float> &S, const 
   return best_s >= 0 ? (int)G.orig[best_s] : -1;
 }
 
+RT_D float isect_fast_any(int type, const float *f, V3<float> o, V3<float> d, float eps, int flags) {
+  float ot[RT_OT_STRIDE];
+  switch (type) {
+    case RT_PLANE: origin_terms<RT_PLANE>(f, o, ot); return isect_fast<RT_PLANE>(f, ot, d, eps, flags);
+    case RT_SPHERE: origin_terms<RT_SPHERE>(f, o, ot); return isect_fast<RT_SPHERE>(f, ot, d, eps, flags);
+    case RT_HEMISPHERE: origin_terms<RT_HEMISPHERE>(f, o, ot); return isect_fast<RT_HEMISPHERE>(f, ot, d, eps, flags);
+    case RT_CYLINDER: origin_terms<RT_CYLINDER>(f, o, ot); return isect_fast<RT_CYLINDER>(f, ot, d, eps, flags);
+    case RT_TRIANGLE: origin_terms<RT_TRIANGLE>(f, o, ot); return isect_fast<RT_TRIANGLE>(f, ot, d, eps, flags);
+    case RT_SQUARE: origin_terms<RT_SQUARE>(f, o, ot); return isect_fast<RT_SQUARE>(f, ot, d, eps, flags);
+    case RT_DISC: origin_terms<RT_DISC>(f, o, ot); return isect_fast<RT_DISC>(f, ot, d, eps, flags);
+    default: origin_terms<RT_ANNULUS>(f, o, ot); return isect_fast<RT_ANNULUS>(f, ot, d, eps, flags);
+  }
+}
+
+// The same scans through the hierarchy.  Every primitive whose box the ray can reach before the best hit so far is
+// tested with the same distance function as in the all-primitives scan, and equal distances are settled on the
+// original index, so the result is the all-primitives scan's (boxes are padded; a NaN slab interval counts as hit).
+template <typename T, int MODE> RT_D int scan_bvh(const DevScene<T> &S, V3<T> o, V3<T> d, T eps, T limit, T &t_out, uint32_t *tests) {
+  T best = Limits<T>::inf(); int best_idx = -1;
+  const T lim = (MODE == 2) ? limit - eps : T(0);
+  uint32_t n_tests = 0;
+  auto test = [&](uint32_t entry) -> bool {                 // true: an occluder was found (MODE 2)
+    const uint32_t s = entry & 0x0FFFFFFFu; const int type = (int)(entry >> 28);
+    if (s >= S.n_shapes) return false;                      // (never true; guards the indexed accesses)
+    const int flags = (int)S.sflags32[s];
+    if ((MODE == 1 || MODE == 2) && (flags & RT_FLAG_LIGHT)) return false;
+    const T *g = S.sgeom + (size_t)s * RT_GEOM_STRIDE;
+    T t;
+    if constexpr (sizeof(T) == 4) t = isect_fast_any(type, g, o, d, eps, flags);
+    else t = isect_any_type<T>(o, d, type, flags, g, eps);
+    n_tests++;
+    if (MODE == 2) return t > eps && t < lim;
+    const int orig = (int)S.sorig[s];
+    if (t > eps && (t < best || (t == best && best_idx >= 0 && (MODE == 3 ? orig > best_idx : orig < best_idx)))) { best = t; best_idx = orig; }
+    return false;
+  };
+  bool occluded = false;
+  for (uint32_t u = 0; u < S.n_unbounded && !occluded; u++) occluded = test(S.unbounded[u]);
+  const T ix = T(1) / d.x, iy = T(1) / d.y, iz = T(1) / d.z;
+  uint32_t i = 0, guard = 0;
+  while (i < S.n_bvh_nodes && !occluded && guard++ < 2u * S.n_bvh_nodes) {
+    const BvhNode nd = S.bvh[i];
+    // slabs; fmin/fmax return the other operand for a NaN (0 * inf), which keeps the interval conservative
+    T t1 = (T(nd.lo[0]) - o.x) * ix, t2 = (T(nd.hi[0]) - o.x) * ix;
+    T tn = rt_fmin(t1, t2), tf = rt_fmax(t1, t2);
+    t1 = (T(nd.lo[1]) - o.y) * iy; t2 = (T(nd.hi[1]) - o.y) * iy;
+    tn = rt_fmax(tn, rt_fmin(t1, t2)); tf = rt_fmin(tf, rt_fmax(t1, t2));
+    t1 = (T(nd.lo[2]) - o.z) * iz; t2 = (T(nd.hi[2]) - o.z) * iz;
+    tn = rt_fmax(tn, rt_fmin(t1, t2)); tf = rt_fmin(tf, rt_fmax(t1, t2));
+    const T reach = (MODE == 2) ? lim : best;
+    const bool hit = !(tf < T(0)) && !(tn > tf) && !(tn > reach);
+    if (!hit) { i = nd.skip; continue; }
+    if (nd.leaf) {
+      const uint32_t first = nd.leaf & 0x00FFFFFFu, count = nd.leaf >> 24;
+      for (uint32_t k = 0; k < count && !occluded; k++) occluded = test(S.bvh_prims[first + k]);
+      i = nd.skip;
+    } else {
+      i = i + 1;
+    }
+  }
+  if (tests) *tests += n_tests;
+  if (MODE == 2) { t_out = T(0); return occluded ? 1 : 0; }
+  t_out = best;
+  return best_idx;
+}
+
 // Scan all primitives in type-sorted order.  MODE 0: closest incl. lights (rayphoton.js:1642-1650),
 // MODE 1: closest excluding lights (:1467-1475), MODE 2: any occluder closer than limit - eps
 // (:1853-1857).  The reference scans in index order and keeps the first of equal distances
 // (strict `<`), so ties go to the lowest original index here too.  MODE 3: closest incl. lights with ties going
 // to the HIGHEST index, for ray.js, which scans in descending index order (ray.js:863).
 // OT (fp32 only): G.ot holds the origin terms of `o`, staged by stage_scene_lds.
-template <typename T, int MODE, bool OT = false> RT_D int scan_scene(const DevScene<T> &S, const ScanSrc<T> &G, V3<T> o, V3<T> d, T eps, T limit, T &t_out) {
+template <typename T, int MODE, bool OT = false> RT_D int scan_scene(const DevScene<T> &S, const ScanSrc<T> &G, V3<T> o, V3<T> d, T eps, T limit, T &t_out,
+                                                                     uint32_t *tests = nullptr) {
+  if (S.bvh) return scan_bvh<T, MODE>(S, o, d, eps, limit, t_out, tests);
   if constexpr (sizeof(T) == 4) return scan_fast<MODE, OT>(S, G, o, d, eps, limit, t_out);
   T best = Limits<T>::inf(); int best_idx = -1;
   const T lim = (MODE == 2) ? limit - eps : T(0);

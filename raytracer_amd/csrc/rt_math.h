@@ -23,6 +23,10 @@ RT_D float rt_sqrt(float x) { return sqrtf(x); }
 RT_D double rt_sqrt(double x) { return sqrt(x); }
 RT_D float rt_abs(float x) { return fabsf(x); }
 RT_D double rt_abs(double x) { return fabs(x); }
+RT_D float rt_fmin(float a, float b) { return fminf(a, b); }
+RT_D double rt_fmin(double a, double b) { return fmin(a, b); }
+RT_D float rt_fmax(float a, float b) { return fmaxf(a, b); }
+RT_D double rt_fmax(double a, double b) { return fmax(a, b); }
 RT_D float rt_floor(float x) { return floorf(x); }
 RT_D double rt_floor(double x) { return floor(x); }
 RT_D float rt_fmod(float x, float y) { return fmodf(x, y); }

@@ -130,7 +130,7 @@ static int trace_tile_mode(rt_scene *sc, const rt_params *p, DevMap md, DevMap m
   unsigned long long *wave_mask = sc->ws_masks.as<unsigned long long>();
   uint32_t *block_count = sc->ws_blocks.as<uint32_t>();
   uint32_t *counts = ctr->counts;                           // counts[b] = queue length of pass b (device side)
-  const bool lds = scene_fits_lds<T>(S.n_shapes);
+  const bool lds = !S.bvh && scene_fits_lds<T>(S.n_shapes);       // hierarchy scans read the primitives they reach from global memory
   const size_t smem = lds ? scan_lds_bytes<T>(S.n_shapes) : 0;
   constexpr bool SHADE_SCANS = FULL && !WHITTED;            // only directLight's shadow rays scan primitives while shading
   // The first pass (k_primary) is fused.  Wide later bounces run as wavefront passes (intersect_closest, shade,
@@ -164,8 +164,8 @@ static int trace_tile_mode(rt_scene *sc, const rt_params *p, DevMap md, DevMap m
       if (lds) RT_LAUNCH_SMEM(ctx, "primary", (k_primary<T, true, WHITTED, FULL>), blocks, 256, smem, S, P, C, md, mc, levels, q_cur, cnt, wave_mask, block_count, ctr);
       else RT_LAUNCH_SMEM(ctx, "primary", (k_primary<T, false, WHITTED, FULL>), blocks, 256, 0, S, P, C, md, mc, levels, q_cur, cnt, wave_mask, block_count, ctr);
     } else {
-      if (lds) RT_LAUNCH_SMEM(ctx, "intersect_closest", (k_intersect_closest<T, true, WHITTED>), blocks, 256, smem, S, P, C, q_cur, cnt);
-      else RT_LAUNCH_SMEM(ctx, "intersect_closest", (k_intersect_closest<T, false, WHITTED>), blocks, 256, 0, S, P, C, q_cur, cnt);
+      if (lds) RT_LAUNCH_SMEM(ctx, "intersect_closest", (k_intersect_closest<T, true, WHITTED>), blocks, 256, smem, S, P, C, q_cur, cnt, ctr);
+      else RT_LAUNCH_SMEM(ctx, "intersect_closest", (k_intersect_closest<T, false, WHITTED>), blocks, 256, 0, S, P, C, q_cur, cnt, ctr);
       if (lds && SHADE_SCANS && C.use_direct_light)
         RT_LAUNCH_SMEM(ctx, "shade", (k_shade<T, true, WHITTED, FULL>), blocks, 256, smem, S, P, C, md, mc, levels, q_cur, cnt, wave_mask, block_count, ctr, (int)wave_bounces);
       else
@@ -211,6 +211,11 @@ static int trace_tile_mode(rt_scene *sc, const rt_params *p, DevMap md, DevMap m
     stats->shadow_rays = hc.shadow_rays; stats->gathers = hc.gathers;
     stats->stack_overflows = hc.stack_overflows;
     stats->tail_rays = whole_frame ? tail - n_paths : tail;       // segments after the first pass that k_tail traced
+    uint64_t tests = 0;
+    for (int k = 0; k < RT_CTR_SLOTS; k++) tests += hc.prim_tests[k * 16];
+    // without a hierarchy every segment is tested against every primitive (shadow rays stop at the first occluder)
+    stats->prim_tests = S.bvh ? tests : stats->rays * (uint64_t)S.n_shapes;
+    stats->prims_per_ray_brute_force = S.n_shapes;
   }
   return RT_OK;
 }
@@ -238,7 +243,7 @@ int pl_emit_batch(rt_scene *sc, const rt_params *p, int phase, uint64_t a0, uint
   if (!sc->ws_misc.p) { RT_HIP(ctx, sc->ws_misc.alloc(256)); RT_HIP(ctx, hipMemsetAsync(sc->ws_misc.p, 0, 256, ctx->stream)); }
   EmitCfg C; C.epsilon = working_eps<T>(p); C.max_depth = p->max_depth; C.num_diffuse = p->num_photons_diffuse;
   C.num_caustic = p->num_photons_caustic; C.seed = p->seed;
-  if (scene_fits_lds<T>(S.n_shapes))
+  if (!S.bvh && scene_fits_lds<T>(S.n_shapes))
     RT_LAUNCH_SMEM(ctx, "photon_emit_bounce", (k_emit<T, true>), div_up(count, 256), 256, scan_lds_bytes<T>(S.n_shapes), S, C, phase,
                    (unsigned long long)a0, count, sc->ws_emit_kind.as<uint8_t>(), sc->ws_emit_rec.as<T>(), sc->ws_misc.as<EmitCounters>());
   else

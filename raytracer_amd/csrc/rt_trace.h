@@ -60,12 +60,30 @@ struct TraceCfg {
 #define RT_CTR_SLOTS 64
 struct TraceCounters {
   unsigned long long shadow_rays, gathers, stack_overflows, tail_rays[RT_CTR_SLOTS];
+  unsigned long long prim_tests[RT_CTR_SLOTS * 16];   // ray-primitive tests counted by the hierarchy scans; slot s at [16 s]
   uint32_t max_iter[RT_CTR_SLOTS];          // iterations the longest-lived workgroup of k_tail ran
   uint32_t counts[RT_MAX_WAVE_BOUNCES + 2];
 #ifdef RT_TAIL_PROBE
   unsigned long long probe[3][6];           // [first / second / later iterations][phase] cycles seen by lane 0 of each workgroup; [..][5] = iterations
 #endif
 };
+
+// per-lane tallies of a kernel; tests: ray-primitive tests (counted by the hierarchy scans only)
+struct ShadeTally { unsigned long long shadow_rays = 0, gathers = 0, overflows = 0; uint32_t tests = 0; };
+
+// adds a wave's tallies to the frame counters: one atomic per wave and counter (call with the wave converged)
+RT_D void flush_tally(const ShadeTally &t, TraceCounters *ctr) {
+  unsigned long long a = t.shadow_rays, b = t.gathers, c = t.overflows, e = t.tests;
+  if (__ballot((a | b | c | e) != 0) == 0) return;
+  for (int off = 32; off > 0; off >>= 1) { a += __shfl_down(a, off, 64); b += __shfl_down(b, off, 64); c += __shfl_down(c, off, 64); e += __shfl_down(e, off, 64); }
+  if ((threadIdx.x & 63) == 0) {
+    if (e) atomicAdd(&ctr->prim_tests[((blockIdx.x * 8 + (threadIdx.x >> 6)) % RT_CTR_SLOTS) * 16], e);   // one cache line per slot
+    if (a) atomicAdd(&ctr->shadow_rays, a);
+    if (b) atomicAdd(&ctr->gathers, b);
+    if (c) atomicAdd(&ctr->stack_overflows, c);
+  }
+}
+
 
 // traceOnCanvas ray set-up (rayphoton.js:1589-1609, superSampleScale 0) for path p: the initial path state
 // with the camera ray as its segment.
@@ -95,20 +113,23 @@ RT_D PathState<T> raygen_path(const DevScene<T> &S, const TraceCfg &C, uint32_t 
 // so primitive operands are broadcast LDS (or scalar) loads and every lane spends its cycles on the distance
 // arithmetic.  WHITTED: ray.js's scan order (equal distances go to the highest index) instead of rayphoton.js's.
 template <typename T, bool LDS, bool WHITTED>
-__global__ void __launch_bounds__(256) k_intersect_closest(DevScene<T> S, PathSoA<T> P, TraceCfg C, const uint32_t *queue, const uint32_t *count_ptr) {
+__global__ void __launch_bounds__(256) k_intersect_closest(DevScene<T> S, PathSoA<T> P, TraceCfg C, const uint32_t *queue, const uint32_t *count_ptr,
+                                                           TraceCounters *ctr) {
   extern __shared__ __align__(16) unsigned char rt_lds[];
   // device-side queue length (the grid is only an upper bound)
   const uint32_t count = min(*count_ptr, C.n_paths);
   if (blockIdx.x * blockDim.x >= count) return;
   const ScanSrc<T> G = LDS ? stage_scene_lds<T>(S, rt_lds) : global_scan_src<T>(S);
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= count) return;
-  const uint32_t p = queue[i];
-  if (p >= C.n_paths) return;                               // (never true; guards the indexed accesses below)
-  V3<T> o = mk<T>(P.ox[p], P.oy[p], P.oz[p]), d = mk<T>(P.dx[p], P.dy[p], P.dz[p]);
-  T t;
-  int idx = scan_scene<T, WHITTED ? 3 : 0>(S, G, o, d, T(C.epsilon), T(0), t);
-  P.hit_t[p] = t; P.hit_idx[p] = idx;
+  ShadeTally tally;
+  const uint32_t p = i < count ? queue[i] : 0xFFFFFFFFu;
+  if (p < C.n_paths) {                                      // (false only for the lanes past the end of the queue)
+    V3<T> o = mk<T>(P.ox[p], P.oy[p], P.oz[p]), d = mk<T>(P.dx[p], P.dy[p], P.dz[p]);
+    T t;
+    int idx = scan_scene<T, WHITTED ? 3 : 0>(S, G, o, d, T(C.epsilon), T(0), t, &tally.tests);
+    P.hit_t[p] = t; P.hit_idx[p] = idx;
+  }
+  flush_tally(tally, ctr);
 }
 
 // stream of path p continued where its state left it: the key is (pixel, sub-sample)
@@ -125,7 +146,7 @@ template <typename T> RT_D RngStream path_rng(uint32_t width, const TraceCfg &C,
 // THIS light's area; an unclamped cosine; floor at the end.
 template <typename T>
 RT_D V3<T> direct_light(const DevScene<T> &S, const ScanSrc<T> &G, const TraceCfg &C, V3<T> point, V3<T> normal, V3<T> local, RngStream &rng,
-                        unsigned long long &shadow_rays) {
+                        unsigned long long &shadow_rays, uint32_t *tests) {
   const T eps = T(C.epsilon);
   V3<T> col = mk<T>(0, 0, 0);
   for (uint32_t l = 0; l < S.n_lights; l++) {
@@ -135,7 +156,7 @@ RT_D V3<T> direct_light(const DevScene<T> &S, const ScanSrc<T> &G, const TraceCf
     T source_dist = rt_sqrt(sqlen(point - ph.o));
     T thit;
     shadow_rays++;
-    if (!scan_scene<T, 2>(S, G, point, dir, eps, source_dist, thit)) {
+    if (!scan_scene<T, 2>(S, G, point, dir, eps, source_dist, thit, tests)) {
       T dn = dot(dir, normal);
       T k = T(C.standard_lamp_area);
       col.x += (ph.r / T(255)) * local.x * dn * power / k;
@@ -177,7 +198,6 @@ template <typename T> RT_D void finish_path(T *out, V3<T> acc, V3<T> term, T ter
   out[3] = alpha_fixed ? T(1) : term_a;
 }
 
-struct ShadeTally { unsigned long long shadow_rays = 0, gathers = 0, overflows = 0; };
 
 // One traceRay body (rayphoton.js:1651-1838) for path p, whose segment `st` hit primitive `idx` at distance t.
 // A path either finishes (its colour goes to out[0..3]) or continues: then `st` holds the new segment and
@@ -224,7 +244,7 @@ RT_D bool shade_body(const DevScene<T> &S, const ScanSrc<T> &G, const TraceCfg &
         V3<T> direct = ZERO;
         if (FULL && refl < T(1) && C.use_direct_light) {
           const T bias = T(C.shadow_bias);
-          direct = direct_light<T>(S, G, C, hit + bias * n, n, local, rng, tally.shadow_rays);     // :1750-1752
+          direct = direct_light<T>(S, G, C, hit + bias * n, n, local, rng, tally.shadow_rays, &tally.tests);     // :1750-1752
         }
         bool spec = false;
         if (rng.next_k() < (has_mat ? S.refl_k[mat] : 0u)) spec = rng.next_k() < S.spec_k[mat];   // :1753, short-circuit
@@ -367,17 +387,6 @@ RT_D bool shade_step(const DevScene<T> &S, const ScanSrc<T> &G, const PathSoA<T>
   return shade_body<T, FULL>(S, G, C, Md, Mc, p, st, t, idx, bounce, P.out + (size_t)p * 4, tally);
 }
 
-// adds a wave's tallies to the frame counters: one atomic per wave and counter (call with the wave converged)
-RT_D void flush_tally(const ShadeTally &t, TraceCounters *ctr) {
-  unsigned long long a = t.shadow_rays, b = t.gathers, c = t.overflows;
-  if (__ballot((a | b | c) != 0) == 0) return;
-  for (int off = 32; off > 0; off >>= 1) { a += __shfl_down(a, off, 64); b += __shfl_down(b, off, 64); c += __shfl_down(c, off, 64); }
-  if ((threadIdx.x & 63) == 0) {
-    if (a) atomicAdd(&ctr->shadow_rays, a);
-    if (b) atomicAdd(&ctr->gathers, b);
-    if (c) atomicAdd(&ctr->stack_overflows, c);
-  }
-}
 
 // First pass of a frame, fused: camera ray, closest hit and shade of every path with the path state in
 // registers; only paths that go on are written to the path arrays.  Survivors are recorded as one keep-mask
@@ -400,7 +409,7 @@ __global__ void __launch_bounds__(256) k_primary(DevScene<T> S, PathSoA<T> P, Tr
     queue[p] = p;                                                        // identity queue for the compaction
     PathState<T> st = raygen_path<T>(S, C, p);
     T t;
-    const int idx = scan_scene<T, WHITTED ? 3 : 0, OT>(S, G, st.o, st.d, T(C.epsilon), T(0), t);
+    const int idx = scan_scene<T, WHITTED ? 3 : 0, OT>(S, G, st.o, st.d, T(C.epsilon), T(0), t, &tally.tests);
     alive = shade_step<T, WHITTED, FULL>(S, G, P, C, Md, Mc, levels, p, st, t, idx, 0, tally);
     if (alive) store_path<T>(P, p, st);
   }
@@ -495,14 +504,14 @@ __global__ void __launch_bounds__(RT_TAIL_THREADS, RT_TAIL_MIN_WAVES) k_tail(Dev
         T t; int idx;
         if (first) {
           st = raygen_path<T>(S, C, p);
-          idx = scan_scene<T, WHITTED ? 3 : 0, OT>(S, G, st.o, st.d, T(C.epsilon), T(0), t);
+          idx = scan_scene<T, WHITTED ? 3 : 0, OT>(S, G, st.o, st.d, T(C.epsilon), T(0), t, &tally.tests);
         } else {
           st = load_path<T>(P, p);
 #ifdef RT_TAIL_PROBE
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
           RT_PROBE(0)
-          idx = scan_scene<T, WHITTED ? 3 : 0>(S, G, st.o, st.d, T(C.epsilon), T(0), t);
+          idx = scan_scene<T, WHITTED ? 3 : 0>(S, G, st.o, st.d, T(C.epsilon), T(0), t, &tally.tests);
         }
         RT_PROBE(1)
         alive = shade_step<T, WHITTED, FULL>(S, G, P, C, Md, Mc, levels, p, st, t, idx, b, tally);

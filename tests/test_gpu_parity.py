@@ -506,3 +506,66 @@ def test_knn_gather_ties_at_the_kth_distance(rt, monkeypatch):
         got = m.gather(hits, k=k)
         exp = _brute_knn_gather(rec, hits, k)
         assert np.allclose(got, exp, rtol=2e-5, atol=1e-6 * max(1.0, float(np.abs(exp).max()))), k
+
+
+# ------------------------------------------------------------------ hierarchy scans (large scenes)
+@pytest.mark.parametrize("preset", [10, 4, 7, 9])
+def test_hierarchy_scans_equal_the_golden_scans(rt, preset, monkeypatch):
+    """RT355_BVH=1 builds the hierarchy for a small scene too: the fp64 scans through it must still be the reference's"""
+    capi, ctx = rt
+    b = load_bundle(f"closest_preset{preset}")
+    monkeypatch.setenv("RT355_BVH", "1")
+    sc = ctx.upload(load_scene(preset))
+    monkeypatch.delenv("RT355_BVH")
+    p = capi.default_params(precision=capi.PRECISION_F64)
+    t, idx = sc.intersect(p, capi.SCAN_CLOSEST, b["ray_o"], b["ray_d"])
+    assert np.array_equal(idx, b["idx_all"]) and same(t, b["t_all"])
+    t, idx = sc.intersect(p, capi.SCAN_CLOSEST_NOLIGHT, b["ray_o"], b["ray_d"])
+    assert np.array_equal(idx, b["idx_nolight"]) and same(t, b["t_nolight"])
+    _, occ = sc.intersect(p, capi.SCAN_ANY, b["ray_o"], b["ray_d"], b["source_dist"])
+    assert np.array_equal(occ, b["occluded"])
+    # fp32: the same hits as the all-primitives fp32 scan (equal distances may be settled differently)
+    flat = ctx.upload(load_scene(preset))
+    p32 = capi.default_params(precision=capi.PRECISION_F32)
+    t_h, i_h = sc.intersect(p32, capi.SCAN_CLOSEST, b["ray_o"], b["ray_d"])
+    t_b, i_b = flat.intersect(p32, capi.SCAN_CLOSEST, b["ray_o"], b["ray_d"])
+    assert (i_h == i_b).mean() > 0.999 and same(t_h[i_h == i_b], t_b[i_h == i_b])
+
+
+def test_hierarchy_frames_equal_all_primitive_frames(rt, monkeypatch):
+    capi, ctx = rt
+    # the reference's golden frames through the hierarchy: mode B with photon maps and direct light, mode A
+    g = load_bundle("image_c1_modeB")
+    ph = load_bundle("photons_c1")
+    monkeypatch.setenv("RT355_BVH", "1")
+    sc = ctx.upload(load_scene(10, g.meta["W"], g.meta["H"]))
+    sca = ctx.upload(load_rayjs_scene(3))
+    monkeypatch.delenv("RT355_BVH")
+    ref = ctx.upload(load_scene(10, g.meta["W"], g.meta["H"]))
+    md, mc = ctx.photon_map(ph["diffuse"]), ctx.photon_map(ph["caustic"])
+    p = capi.default_params(precision=capi.PRECISION_F64, num_photons_diffuse=10000, num_photons_caustic=10000, seed=SEED)
+    a, b = sc.trace_tile(p, md, mc), ref.trace_tile(p, md, mc)
+    assert same(a["pre"], b["pre"]) and a["stats"]["rays"] == b["stats"]["rays"] == 110353
+    assert 0 < a["stats"]["prim_tests"] < b["stats"]["prim_tests"] + b["stats"]["shadow_rays"] * 33
+    ga = load_bundle("image_rayjs3")
+    pa = capi.default_params(precision=capi.PRECISION_F64, mode=capi.MODE_WHITTED, seed=ga.meta["seed"], **RAYJS_PARAMS)
+    assert same(sca.trace_tile(pa)["pre"], ga["rgba"])
+    # photon emission through the hierarchy: the reference's lists
+    e = sc.emit_many(p)
+    assert same(e["diffuse"], ph["diffuse"]) and same(e["caustic"], ph["caustic"])
+    # a 10 000-primitive scene: hierarchy (chosen automatically) against the all-primitives scan, both precisions
+    from raytracer_amd import synth
+    flat = synth.many_primitive_scene(10000, seed=42, width=192, height=108)
+    big = ctx.upload(flat)
+    monkeypatch.setenv("RT355_BVH", "0")
+    brute = ctx.upload(flat)
+    monkeypatch.delenv("RT355_BVH")
+    for prec in (capi.PRECISION_F64, capi.PRECISION_F32):
+        q = capi.default_params(precision=prec, use_photon_maps=0, seed=3, max_depth=8, shadow_bias=1e-4)
+        x, y = big.trace_tile(q), brute.trace_tile(q)
+        if prec == capi.PRECISION_F64:
+            assert same(x["pre"], y["pre"])
+        else:
+            assert same_px(x["pre"], y["pre"]).mean() > 0.995
+        assert x["stats"]["rays"] == y["stats"]["rays"] or prec == capi.PRECISION_F32
+        assert x["stats"]["prim_tests"] * 20 < y["stats"]["prim_tests"]       # > 95 % of the tests avoided
