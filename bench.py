@@ -98,6 +98,7 @@ def main():
     ap.add_argument("--knn", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="skip the photon-map (k-NN gather) leg")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the short legs for the older tracer, the 10k-primitive scene and photon emission")
     args = ap.parse_args()
 
     import torch
@@ -207,6 +208,43 @@ def main():
         roof_gather = {"kernel": "k_gather_knn_wave", "bound": "hbm", "achieved": g_achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                        "frac": g_achieved / PEAK_HBM_GBS, "traffic": measured_traffic("k_gather_knn_wave"),
                        "algorithmic_bytes_per_gather": BYTES_PER_GATHER, "avg_launch_ms": g_ms / g_launches}
+
+    # ---- short legs for the other BASELINE configs (reported under "extra", never part of `value`) ----
+    if not args.no_other_configs:
+        def timed_frames(scene, params, out, n=5):
+            for _ in range(2):
+                stt = scene.trace_tile(params, out_rgba8=out, want=())["stats"]
+            ctx.synchronize()
+            t_ = time.perf_counter()
+            for _ in range(n):
+                stt = scene.trace_tile(params, out_rgba8=out, want=())["stats"]
+            ctx.synchronize()
+            return (time.perf_counter() - t_) / n, stt
+        # the older tracer (ray.js) on its preset 3 at the same resolution
+        flat_a = FlatScene.from_json(os.path.join(ROOT, "tests", "golden", "scene_rayjs3_flat.json")).with_size(W, H)
+        pa = capi.default_params(precision=capi.PRECISION_F32, mode=capi.MODE_WHITTED, seed=seed, max_trace_dist=100.0, max_depth=20, sub_sample=1)
+        dt_a, st_a = timed_frames(ctx.upload(flat_a), pa, frame)
+        extra["mode_a_rayjs_preset3"] = {"Mrays_per_s": st_a["rays"] / dt_a / 1e6, "ms_per_frame": dt_a * 1e3, "rays_per_frame": st_a["rays"],
+                                         "primitives": int(flat_a.n_shapes), "resolution": [W, H]}
+        # configs[3]: 10 000 primitives at 3840x2160, paths of up to 8 segments, through the hierarchy
+        flat4 = synth.many_primitive_scene(10000, seed=42, width=3840, height=2160)
+        frame4 = torch.empty((2160, 3840, 4), dtype=torch.uint8, device=dev)
+        p4 = capi.default_params(precision=capi.PRECISION_F32, use_direct_light=0, use_photon_maps=0, seed=seed, sub_sample=1, max_bounces=8)
+        dt4, st4 = timed_frames(ctx.upload(flat4), p4, frame4, n=3)
+        brute = st4["rays"] * st4["prims_per_ray_brute_force"]
+        extra["config4_10k_primitives_4k"] = {"Mrays_per_s": st4["rays"] / dt4 / 1e6, "ms_per_frame": dt4 * 1e3, "rays_per_frame": st4["rays"],
+                                              "primitives": int(flat4.n_shapes), "prim_tests": st4["prim_tests"], "brute_force_tests": brute,
+                                              "tests_avoided_frac": 1.0 - st4["prim_tests"] / brute}
+        del frame4
+        # photon emission (the configs[4] kernel on one GPU's share): 2 M diffuse + 2 M caustic photons of the default scene
+        pe = capi.default_params(precision=capi.PRECISION_F32, num_photons_diffuse=2_000_000, num_photons_caustic=2_000_000, seed=seed)
+        sc.emit_many(pe, strict=False)
+        t_ = time.perf_counter()
+        em = sc.emit_many(pe, strict=False)["stats"]
+        dte = time.perf_counter() - t_
+        extra["photon_emission"] = {"stored_photons_per_s": (em["n_diffuse"] + em["n_caustic"]) / dte, "segments_per_s": em["segments"] / dte,
+                                    "attempts": em["attempts_phase1"] + em["attempts_phase2"], "seconds": dte,
+                                    "note": "includes copying the 11-double records to host memory"}
 
     if rank == 0:
         fl = flop_per_ray_pass(flat)

@@ -2,6 +2,7 @@
 // device buffers, host/device pointer staging and per-kernel HIP-event timing.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <map>
@@ -64,25 +65,27 @@ int rt_stage_out_end(rt_ctx *ctx, void *dst, size_t bytes, DevMem &tmp);
 struct KernelTimer {
   rt_ctx *ctx; hipEvent_t a = nullptr, b = nullptr; const char *name;
   KernelTimer(rt_ctx *c, const char *n) : ctx(c), name(n) {
-    if (ctx->profiling && (ctx->profile_only.empty() || ctx->profile_only.find("," + std::string(n) + ",") != std::string::npos)) { a = ctx->take_event(); b = ctx->take_event(); (void)hipEventRecord(a, ctx->stream); }
+    if (ctx->profiling && (ctx->profile_only.empty() || ctx->profile_only.find("," + std::string(n) + ",") != std::string::npos)) { a = ctx->take_event(); b = ctx->take_event(); (void)hipEventRecord(a, ctx->stream); }   // (library routines: events around the call)
   }
   ~KernelTimer() {
     if (a) { (void)hipEventRecord(b, ctx->stream); ctx->events[name].push_back({ a, b }); }
   }
 };
 
-// launch on the context's stream, timed under `name` when profiling is on
-#define RT_LAUNCH(ctx, name, kernel, grid, block, ...)                                         \
-  do {                                                                                         \
-    KernelTimer timer_((ctx), (name));                                                         \
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, (ctx)->stream, __VA_ARGS__);        \
-  } while (0)
+static inline bool rt_timing(const rt_ctx *ctx, const char *name) {
+  return ctx->profiling && (ctx->profile_only.empty() || ctx->profile_only.find("," + std::string(name) + ",") != std::string::npos);
+}
 
+// launch on the context's stream; when profiling is on for `name`, the dispatch itself carries the start/stop events
+// (hipExtLaunchKernelGGL), which does not put extra barrier packets between the kernels of a frame
 #define RT_LAUNCH_SMEM(ctx, name, kernel, grid, block, smem, ...)                              \
   do {                                                                                         \
-    KernelTimer timer_((ctx), (name));                                                         \
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), (smem), (ctx)->stream, __VA_ARGS__);   \
+    hipEvent_t ev_a_ = nullptr, ev_b_ = nullptr;                                               \
+    if (rt_timing((ctx), (name))) { ev_a_ = (ctx)->take_event(); ev_b_ = (ctx)->take_event(); } \
+    hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(block), (smem), (ctx)->stream, ev_a_, ev_b_, 0, __VA_ARGS__); \
+    if (ev_a_) (ctx)->events[(name)].push_back({ ev_a_, ev_b_ });                              \
   } while (0)
+#define RT_LAUNCH(ctx, name, kernel, grid, block, ...) RT_LAUNCH_SMEM(ctx, name, kernel, grid, block, 0, __VA_ARGS__)
 
 static inline uint32_t div_up(uint64_t a, uint32_t b) { return (uint32_t)((a + b - 1) / b); }
 

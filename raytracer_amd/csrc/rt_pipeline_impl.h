@@ -261,7 +261,7 @@ int pl_emit_compact(rt_scene *sc, uint32_t count, int want, uint64_t a0, uint32_
   RT_HIP(ctx, sc->ws_emit_blocks.reserve(((size_t)blocks + 1) * 4));
   uint32_t *bc = sc->ws_emit_blocks.as<uint32_t>();
   RT_LAUNCH(ctx, "compact_count", k_compact_count, blocks, 256, sc->ws_emit_kind.as<uint8_t>(), count, want, bc);
-  RT_LAUNCH(ctx, "compact_scan", k_scan_blocks, 1, 1024, bc, blocks, bc + blocks);
+  RT_LAUNCH(ctx, "compact_scan", k_scan_blocks, 1, 1024, bc, blocks, bc + blocks, (const uint32_t *)nullptr);
   RT_LAUNCH(ctx, "compact_scatter", k_compact_scatter<T>, blocks, 256, sc->ws_emit_kind.as<uint8_t>(), sc->ws_emit_rec.as<T>(), count,
             want, bc, (unsigned long long)a0, out_base, out_cap, out_rec, (long long *)out_attempt, out_kind);
   RT_HIP(ctx, hipMemcpyAsync(ctx->pinned, bc + blocks, 4, hipMemcpyDeviceToHost, ctx->stream));
