@@ -113,6 +113,9 @@ static int trace_tile_mode(rt_scene *sc, const rt_params *p, DevMap md, DevMap m
   C.max_depth = p->max_depth; C.sub_sample = p->sub_sample; C.use_direct_light = p->use_direct_light;
   C.use_photon_maps = p->use_photon_maps; C.max_bounces = p->max_bounces > 0 ? p->max_bounces : 64;
   C.seed = p->seed; C.x0 = x0; C.y0 = y0; C.w = w; C.h = h; C.n_paths = (uint32_t)n_paths;
+  C.magic_w = (uint32_t)(0x100000000ull / (uint64_t)w); C.magic_ss = (uint32_t)(0x100000000ull / (uint64_t)(p->sub_sample * p->sub_sample));
+  C.magic_s = (uint32_t)(0x100000000ull / (uint64_t)p->sub_sample);
+  C.fuse_resolve = (!WHITTED && p->sub_sample == 1) ? 1 : 0; C.pre = pre; C.post = post; C.rgba8 = rgba8;
   if (!p->use_photon_maps) { md.n = 0; mc.n = 0; }
   T *levels = nullptr;
   if (WHITTED) {      // one record of 4 values per path and recursion level (levels 0 .. max_depth)
@@ -186,7 +189,7 @@ static int trace_tile_mode(rt_scene *sc, const rt_params *p, DevMap md, DevMap m
   if (WHITTED)
     RT_LAUNCH(ctx, "resolve", k_resolve_a<T>, div_up(n_pixels, 256), 256, P, levels, (uint32_t)n_paths, (int)p->max_depth, (int)n_pixels,
               (int)p->sub_sample, pre, post, rgba8);
-  else
+  else if (!C.fuse_resolve)
     RT_LAUNCH(ctx, "resolve", k_resolve<T>, div_up(n_pixels, 256), 256, P, (int)n_pixels, (int)p->sub_sample, pre, post, rgba8);
   TraceCounters hc;
   const uint32_t *hcounts = hc.counts;

@@ -53,6 +53,10 @@ struct TraceCfg {
   uint64_t seed;
   int32_t x0, y0, w, h;
   uint32_t n_paths;                   // w * h * sub_sample^2
+  uint32_t magic_w, magic_ss, magic_s; // floor(2^32 / d) for d = w, sub_sample^2, sub_sample (see div_by)
+  // with one sub-sample per pixel a finished path is the finished pixel: the shading kernels write the tile's outputs
+  // themselves (any of the three may be null) and no resolve pass runs
+  int32_t fuse_resolve; double *pre, *post; uint8_t *rgba8;
 };
 
 #define RT_MAX_WAVE_BOUNCES 62
@@ -85,14 +89,31 @@ RT_D void flush_tally(const ShadeTally &t, TraceCounters *ctr) {
 }
 
 
+// q = x / d and r = x % d without the ~40-instruction integer division: one multiply-high with m = floor(2^32 / d)
+// (never above the quotient, at most 2 below it for x < 2^32) and two corrections
+RT_D uint32_t div_by(uint32_t x, uint32_t d, uint32_t m, uint32_t &r) {
+  if (d == 1) { r = 0; return x; }
+  uint32_t q = __umulhi(x, m);
+  r = x - q * d;
+  if (r >= d) { q++; r -= d; }
+  if (r >= d) { q++; r -= d; }
+  return q;
+}
+// pixel and sub-sample of path p
+RT_D void path_pixel(const TraceCfg &C, uint32_t p, int &X, int &Y, uint32_t &sub) {
+  uint32_t col;
+  const uint32_t pix = div_by(p, (uint32_t)(C.sub_sample * C.sub_sample), C.magic_ss, sub);
+  const uint32_t row = div_by(pix, (uint32_t)C.w, C.magic_w, col);
+  X = C.x0 + (int)col; Y = C.y0 + (int)row;
+}
+
 // traceOnCanvas ray set-up (rayphoton.js:1589-1609, superSampleScale 0) for path p: the initial path state
 // with the camera ray as its segment.
 template <typename T>
 RT_D PathState<T> raygen_path(const DevScene<T> &S, const TraceCfg &C, uint32_t p) {
-  const int SS = C.sub_sample * C.sub_sample;
-  uint32_t pix = p / SS, sub = p % SS;
-  int X = C.x0 + (int)(pix % C.w), Y = C.y0 + (int)(pix / C.w);
-  int sx = sub % C.sub_sample, sy = sub / C.sub_sample;
+  int X, Y; uint32_t sub, sxu;
+  path_pixel(C, p, X, Y, sub);
+  const int sy = (int)div_by(sub, (uint32_t)C.sub_sample, C.magic_s, sxu), sx = (int)sxu;
   RngStream rng; rng.init(C.seed, RT_DOMAIN_RENDER, (uint32_t)(Y * (int)S.width + X), sub);
   T u = ((T(X) + (T(sx) + rng.next<T>()) / T(C.sub_sample)) * T(2) / T(S.width)) - T(1);
   T v = -(((T(Y) + (T(sy) + rng.next<T>()) / T(C.sub_sample)) * T(2) / T(S.height)) - T(1));
@@ -134,10 +155,9 @@ __global__ void __launch_bounds__(256) k_intersect_closest(DevScene<T> S, PathSo
 
 // stream of path p continued where its state left it: the key is (pixel, sub-sample)
 template <typename T> RT_D RngStream path_rng(uint32_t width, const TraceCfg &C, uint32_t p, const PathState<T> &st) {
-  const int SS = C.sub_sample * C.sub_sample;
-  const uint32_t pix = p / SS;
-  const int X = C.x0 + (int)(pix % C.w), Y = C.y0 + (int)(pix / C.w);
-  RngStream rng; rng.init(C.seed, RT_DOMAIN_RENDER, (uint32_t)(Y * (int)width + X), p % SS, st.draw);
+  int X, Y; uint32_t sub;
+  path_pixel(C, p, X, Y, sub);
+  RngStream rng; rng.init(C.seed, RT_DOMAIN_RENDER, (uint32_t)(Y * (int)width + X), sub, st.draw);
   rng.block = st.blk; rng.block_idx = st.blk_idx;
   return rng;
 }
@@ -380,13 +400,37 @@ RT_D bool shade_body_a(const DevScene<T> &S, const TraceCfg &C, T *levels, uint3
 
 // one shade step of either tracer for path p; finished paths leave their colour in P.out (and, for the older
 // tracer, their level count in P.depth), continuing paths leave the new segment in `st`
+RT_D double clamp01(double x, double lo, double hi) { return (x < lo) ? lo : ((x > hi) ? hi : x); }
+
+// what k_resolve does for a pixel with one sub-sample (rayphoton.js:1610-1621): clamp, floor; pre = the unclamped colour
+template <typename T> RT_D void resolve_store(const TraceCfg &C, uint32_t pix, const T *o) {
+  uint32_t packed = 0;
+  for (int c = 0; c < 4; c++) {
+    const T last = o[c], hi = (c == 3) ? T(1) : T(255);
+    const T v = rt_floor((last < T(0)) ? T(0) : ((last > hi) ? hi : last));     // exact in either precision
+    if (C.pre) C.pre[(size_t)pix * 4 + c] = (double)last;
+    if (C.post) C.post[(size_t)pix * 4 + c] = (double)v;
+    const T b = (c == 3) ? v * T(255) : v;                                       // 0..255, or NaN
+    packed |= ((b == b) ? (uint32_t)b : 0u) << (8 * c);
+  }
+  if (C.rgba8) ((uint32_t *)C.rgba8)[pix] = packed;          // (the tile's byte image is 4-byte aligned: one store per pixel)
+}
+
+// one shade step of either tracer for path p; finished paths leave their colour in P.out (and, for the older
+// tracer, their level count in P.depth) or, when the resolve is fused, in the tile's outputs; continuing paths
+// leave the new segment in `st`
 template <typename T, bool WHITTED, bool FULL>
 RT_D bool shade_step(const DevScene<T> &S, const ScanSrc<T> &G, const PathSoA<T> &P, const TraceCfg &C, const DevMap &Md, const DevMap &Mc,
                      T *levels, uint32_t p, PathState<T> &st, T t, int idx, int bounce, ShadeTally &tally) {
   if (WHITTED) return shade_body_a<T>(S, C, levels, p, st, t, idx, P.out + (size_t)p * 4, P.depth + p, tally);
-  return shade_body<T, FULL>(S, G, C, Md, Mc, p, st, t, idx, bounce, P.out + (size_t)p * 4, tally);
+  T o4[4];
+  const bool alive = shade_body<T, FULL>(S, G, C, Md, Mc, p, st, t, idx, bounce, o4, tally);
+  if (!alive) {
+    if (C.fuse_resolve) resolve_store<T>(C, p, o4);
+    else { T *out = P.out + (size_t)p * 4; out[0] = o4[0]; out[1] = o4[1]; out[2] = o4[2]; out[3] = o4[3]; }
+  }
+  return alive;
 }
-
 
 // First pass of a frame, fused: camera ray, closest hit and shade of every path with the path state in
 // registers; only paths that go on are written to the path arrays.  Survivors are recorded as one keep-mask
@@ -545,8 +589,6 @@ __global__ void __launch_bounds__(RT_TAIL_THREADS, RT_TAIL_MIN_WAVES) k_tail(Dev
   }
   flush_tally(tally, ctr);
 }
-
-RT_D double clamp01(double x, double lo, double hi) { return (x < lo) ? lo : ((x > hi) ? hi : x); }
 
 // Pixel resolve (rayphoton.js:1610-1623): clamp each sub-sample (`colour()`), sum, floor of the
 // mean.  pre = the last sub-sample's unclamped colour; rgba8 = post as bytes.
