@@ -642,19 +642,27 @@ __global__ void __launch_bounds__(64) k_gather_knn_wave(DevMap M, const float *h
     }
     // ---- tracking pass
     if (!(t > a && t < b)) t = b;                                // a and b are neighbouring doubles: count below b, ties sit at a
-    uint32_t cnt = 0, ties = 0; double lmax = -1.0, rmin = __builtin_huge_val();
+    uint32_t cnt = 0, ties = 0, rties = 0; double lmax = -1.0, rmin = __builtin_huge_val();
     for (uint32_t j = 0; j < m; j++) {
       const float4 cd = cand[j];
       const double d2 = sq_dist(x0, x1, x2, (double)cd.x, (double)cd.y, (double)cd.z);
       const bool lt = d2 < t, up = lt && d2 > lmax, eq = lt && d2 == lmax;
+      const bool dn = !lt && d2 < rmin, req = !lt && d2 == rmin;
       cnt += lt ? 1u : 0u;
       ties = up ? 1u : ties + (eq ? 1u : 0u);
       lmax = up ? d2 : lmax;
-      rmin = (!lt && d2 < rmin) ? d2 : rmin;
+      rties = dn ? 1u : rties + (req ? 1u : 0u);
+      rmin = dn ? d2 : rmin;
     }
     if (done) continue;
+    // lmax (x ties) is the largest candidate value below t, rmin (x rties) the smallest at or above it
     if (cnt == k) { done = true; tau = t; }
-    else if (cnt < k) { a = rmin; fa = cnt; }                    // nothing lies in [t, rmin): #(d2 < rmin) = cnt
+    else if (cnt < k) {
+      const double above = __longlong_as_double(__double_as_longlong(rmin) + 1);      // next double after rmin (>= 0, finite)
+      if (cnt + rties == k) { done = true; tau = above; }                               // d2 < above  <=>  d2 <= rmin
+      else if (cnt + rties > k) { done = true; tie = true; tie_v = rmin; need = k - cnt; }
+      else { a = above; fa = cnt + rties; }
+    }
     else if (cnt - ties == k) { done = true; tau = lmax; }       // #(d2 < lmax) = cnt - ties
     else if (cnt - ties < k) { done = true; tie = true; tie_v = lmax; need = k - (cnt - ties); }
     else { b = lmax; fb = cnt - ties; }
