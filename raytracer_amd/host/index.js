@@ -227,5 +227,45 @@ class Scene {
   }
 }
 
-module.exports = Object.assign({}, S, { Scene, Ray, Photon, KdTree, PRECISION, DEFAULTS, context, addon,
-  photonsToRecords, recordsToPhotons });
+// A scene given as a flat description file (tests/golden/scene_*_flat.json and anything written in that layout)
+// instead of constructor calls.  Same rendering / emission methods as Scene.
+class FlatFileScene extends Scene {
+  constructor(ctx, flat, options) {
+    super(ctx, options);
+    this._flatSource = typeof flat === 'string' ? JSON.parse(require('fs').readFileSync(flat, 'utf8')) : flat;
+    this.lights = this._flatSource.lights.map((l) => l.shape);
+  }
+  flatten() { return S.flattenFromJSON(this._flatSource, this.canvasWidth, this.canvasHeight); }
+  initLights() { this._device = null; }                      // the file carries intensities and probabilities
+}
+
+// The older tracer, ray.js ("mode A"): no lights, no photons; shapes carry reflectance / specular themselves and its
+// four materials are AIR, OPAQUE, GLASS, WATER (ray.js:39-61).  Constants of ray.js:8-12 as defaults.
+const WHITTED_DEFAULTS = { mode: 1, maxTraceDist: 100, maxDepth: 20, subSample: 1 };
+const WHITTED_MATERIALS = {
+  transparent: [true, false, true, true, false, false, false, false], refrIndex: [1.0, undefined, 1.5, 1.33, undefined, undefined, undefined, undefined],
+  reflectance: new Array(8).fill(undefined), specular: new Array(8).fill(undefined),
+};
+class WhittedScene extends FlatFileScene {
+  // flat: a flat description whose shapes carry `reflectance` and `specular`, or null to fill `shapes` with this
+  // host's primitives (give each shape .reflectance / .specular, cylinders .firstRootOnly = true) and set `camera`
+  constructor(ctx, flat, options) {
+    super(ctx, flat || { shapes: [], lights: [] }, Object.assign({}, WHITTED_DEFAULTS, options || {}));
+    this.materials = WHITTED_MATERIALS;
+    this._fromFile = !!flat;
+  }
+  flatten() { return this._fromFile ? super.flatten() : S.flatten(this); }
+  emitManyPhotons() { /* ray.js has no photon pass */ }
+}
+
+// Binary PPM (P6) of an rgba8 frame as render() returns it; alpha is dropped.
+function writePPM(file, rgba8, width, height) {
+  const fs = require('fs');
+  const head = Buffer.from(`P6\n${width} ${height}\n255\n`, 'ascii');
+  const body = Buffer.alloc(width * height * 3);
+  for (let p = 0; p < width * height; p++) { body[3 * p] = rgba8[4 * p]; body[3 * p + 1] = rgba8[4 * p + 1]; body[3 * p + 2] = rgba8[4 * p + 2]; }
+  fs.writeFileSync(file, Buffer.concat([head, body]));
+}
+
+module.exports = Object.assign({}, S, { Scene, FlatFileScene, WhittedScene, Ray, Photon, KdTree, PRECISION, DEFAULTS, WHITTED_DEFAULTS,
+  context, addon, photonsToRecords, recordsToPhotons, writePPM });

@@ -37,8 +37,8 @@ const COL = {
 };
 
 const TYPE_ID = { plane: 0, sphere: 1, hemisphere: 2, cylinder: 3, triangle: 4, square: 5, disc: 6, annulus: 7 };
-const FLAG = { CONVEX: 1, LIGHT: 2, TRUNC_MAX: 4, HALF_HEIGHT: 8 };
-const PROC = { NONE: 0, STRIPE_CHECKER: 1, EIGHT_BALL: 2, TILE_GRID: 3, ROTATED_CHECKER: 4 };
+const FLAG = { CONVEX: 1, LIGHT: 2, TRUNC_MAX: 4, HALF_HEIGHT: 8, FIRST_ROOT: 16 };
+const PROC = { NONE: 0, STRIPE_CHECKER: 1, EIGHT_BALL: 2, TILE_GRID: 3, ROTATED_CHECKER: 4, STRIPE_CHECKER3: 5 };
 
 // ---------------------------------------------------------------- primitives
 class Shape {
@@ -251,6 +251,7 @@ function flattenShape(s) {
   }
   if (s.convex) flags |= FLAG.CONVEX;
   if (s.isLight) flags |= FLAG.LIGHT;
+  if (s.firstRootOnly) flags |= FLAG.FIRST_ROOT;              // the older tracer's cylinder (ray.js:443-461)
   return { typeId: TYPE_ID[s.type], material: (s._material === undefined) ? 255 : s._material, flags, proc: s.procColour || 0, g };
 }
 
@@ -277,9 +278,49 @@ function flatten(scene) {
   });
   const cam = scene.camera;
   out.camera.set([...cam.origin.slice(0, 3), ...cam.ONBu, ...cam.ONBv, ...cam.ONBw, cam.fovScaleWidth, cam.fovScaleHeight]);
+  const mats = scene.materials || MATERIALS;
   ['transparent', 'refrIndex', 'reflectance', 'specular'].forEach((k, r) => {
-    for (let m = 0; m < 8; m++) { const v = MATERIALS[k][m]; out.materials[r * 8 + m] = (typeof v === 'boolean') ? (v ? 1 : 0) : nan(v); }
+    for (let m = 0; m < 8; m++) { const v = mats[k][m]; out.materials[r * 8 + m] = (typeof v === 'boolean') ? (v ? 1 : 0) : nan(v === null ? undefined : v); }
   });
+  // the older tracer keeps reflectance / specular on the shape (ray.js:244-385)
+  if (scene.shapes.some((s) => s.reflectance !== undefined || s.specular !== undefined)) {
+    out.shapeSurface = new Float64Array(n * 2);
+    scene.shapes.forEach((s, i) => { out.shapeSurface[2 * i] = nan(s.reflectance); out.shapeSurface[2 * i + 1] = nan(s.specular); });
+  }
+  return out;
+}
+
+// The flat scene files (tests/golden/scene_*_flat.json; the same layout FlatScene.from_flat reads in Python) -> the
+// typed arrays of rt_scene_desc.  null stands for `undefined`.
+function flattenFromJSON(d, width, height) {
+  const n = d.shapes.length, nl = d.lights.length;
+  const nan = (x) => (x === undefined || x === null ? NaN : x);
+  const W = width || d.width, H = height || d.height;
+  const out = {
+    nShapes: n, shapeMeta: new Uint8Array(n * 4), shapeGeom: new Float64Array(n * 12), shapeColour: new Float64Array(n * 4),
+    nLights: nl, lightShape: new Uint32Array(nl), lightData: new Float64Array(nl * 8),
+    camera: new Float64Array(16), width: W, height: H, materials: new Float64Array(32),
+  };
+  d.shapes.forEach((s, i) => {
+    out.shapeMeta.set([s.typeId, s.material, s.flags, s.proc || 0], i * 4);
+    out.shapeGeom.set(s.g, i * 12);
+    out.shapeColour.set(s.colour.map(nan), i * 4);
+  });
+  d.lights.forEach((l, i) => {
+    out.lightShape[i] = l.shape;
+    out.lightData.set([l.wattage, l.area, nan(l.prob), ...l.colour.map(nan), 0], i * 8);
+  });
+  const c = d.camera;
+  // fovScaleHeight follows the canvas (rayphoton.js:694)
+  out.camera.set([...c.origin.slice(0, 3), ...c.u, ...c.v, ...c.w, c.fovScaleWidth, (W === d.width && H === d.height) ? c.fovScaleHeight : c.fovScaleWidth * H / W]);
+  const mats = d.materials || MATERIALS;
+  ['transparent', 'refrIndex', 'reflectance', 'specular'].forEach((k, r) => {
+    for (let m = 0; m < 8; m++) { const v = mats[k][m]; out.materials[r * 8 + m] = (typeof v === 'boolean') ? (v ? 1 : 0) : nan(v); }
+  });
+  if (n && d.shapes[0].reflectance !== undefined) {
+    out.shapeSurface = new Float64Array(n * 2);
+    d.shapes.forEach((s, i) => { out.shapeSurface[2 * i] = nan(s.reflectance); out.shapeSurface[2 * i + 1] = nan(s.specular); });
+  }
   return out;
 }
 
@@ -287,5 +328,5 @@ module.exports = {
   LITTLE_SPACE, MAT, MATERIALS, COL, TYPE_ID, FLAG, PROC,
   Shape, Plane, Sphere, Hemisphere, Cylinder, Triangle, Square, Disc, Annulus,
   Box, Prism, Cuboctahedron, Ball, Can, Tube, Halfball, Bowl, Spotlight, Camera,
-  flatten, flattenShape,
+  flatten, flattenShape, flattenFromJSON,
 };

@@ -92,4 +92,22 @@ for (let y = 64; y < 128; y++) for (let x = 96; x < 160; x++) for (let c = 0; c 
 for (let c = 0; c < 4; c++) if (!same(filled[(7 * W + 5) * 4 + c], img.post_floor[(7 * W + 5) * 4 + c])) tileBad++;
 check('Scene.traceTile / traceOnCanvas -> fillRect', tileBad <= 2, `${tileBad} pixels differ`);
 
+// the older tracer (ray.js) from its flat scene file, fp64: every pixel of the reference's frame
+{
+  const path = require('path');
+  const ga = loadBundle('image_rayjs3');
+  const wa = ga.meta.W, ha = ga.meta.H;
+  const sa = new rt.WhittedScene({ width: wa, height: ha }, path.join(__dirname, '..', '..', '..', 'tests', 'golden', 'scene_rayjs3_flat.json'),
+    { seed: ga.meta.seed, precision: rt.PRECISION.F64 });
+  const oa = sa.render(0, 0, wa, ha);
+  let badA = 0;
+  for (let i = 0; i < wa * ha * 4; i++) if (!same(oa.pre[i], ga.rgba[i])) badA++;
+  check('WhittedScene.render (ray.js preset 3)', badA === 0, `${badA} values differ, ${oa.stats.rays} rays`);
+  const os = require('os'), fs = require('fs');
+  const ppm = path.join(os.tmpdir(), 'rt355_check.ppm');
+  rt.writePPM(ppm, oa.rgba8, wa, ha);
+  check('writePPM', fs.statSync(ppm).size === 15 + wa * ha * 3, `${fs.statSync(ppm).size} bytes`);
+  fs.unlinkSync(ppm);
+}
+
 process.exit(failures ? 1 : 0);
