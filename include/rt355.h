@@ -81,7 +81,8 @@ typedef struct rt_params {
   double shadow_bias;           /* offset along the normal for shadow rays; 0 = the working epsilon (rayphoton.js:1751) */
   double epsilon_f32;           /* the epsilon the fp32 kernels use instead of `epsilon` (0 = 1e-4): 1e-6 is below
                                    fp32 resolution at scene scale, so on-surface origins would re-hit their surface */
-  int32_t max_bounces;          /* hard cap on path segments (0 = 64); the reference has none */
+  int32_t max_bounces;          /* hard cap on path segments (0 = 4096); the reference has none: a path caught between
+                                   glass surfaces goes on until max_trace_dist is used up (hundreds of segments) */
   int32_t reserved;
 } rt_params;
 

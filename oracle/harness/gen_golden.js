@@ -42,6 +42,20 @@ function genScenes() {
   }
 }
 
+// every preset of rayphoton.js (:731-1305) as a flat scene description, for the host's loadPreset and the all-preset
+// parity tests.  The RNG-built presets (5, 6, 'giacometti') are the instances drawn from stream (AUX, 1000 + id).
+function genPresets() {
+  const dir = path.resolve(__dirname, '../../raytracer_amd/presets');
+  fs.mkdirSync(dir, { recursive: true });
+  for (const preset of [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 'rmt', 'giacometti']) {
+    let built;
+    try { built = buildScene(preset); } catch (e) { console.log(`preset ${preset}: reference threw ${e.message}`); continue; }
+    const flat = flattenScene(built.scene, built.L.ex, preset);
+    fs.writeFileSync(path.join(dir, `preset_${preset}.json`), JSON.stringify(flat));
+    console.log(`preset ${preset}: ${flat.shapes.length} shapes, ${flat.lights.length} lights`);
+  }
+}
+
 // ---------------------------------------------------------------- intersect
 function genIntersect() {
   const L = loadRayphoton({ seed: SEED });
@@ -370,6 +384,7 @@ fs.mkdirSync(OUT, { recursive: true });
 const want = new Set(process.argv.slice(2));
 const all = want.size === 0;
 if (all || want.has('scenes')) genScenes();
+if (want.has('presets')) genPresets();
 if (all || want.has('intersect')) genIntersect();
 if (all || want.has('closest')) genClosest();
 if (all || want.has('samples')) genSamples();

@@ -18,7 +18,7 @@ const OUT = path.resolve(__dirname, '../../tests/golden');
 const SEED = 12345, W = 160, H = 120;
 const PROC = { 0: { 0: 1, 8: 2 }, 1: { 0: 5 }, 2: { 0: 3 }, 3: { 0: 4 } };
 
-for (const preset of [2, 3, 0]) {
+for (const preset of [2, 3, 0, 1]) {
   const L = loadRayJs({ seed: SEED, subSample: 1 });
   const ex = L.ex;
   const scene = new ex.Scene({ width: W, height: H });
@@ -38,6 +38,8 @@ for (const preset of [2, 3, 0]) {
     params: { maxTraceDist: ex.MAX_TRACE_DIST, maxDepth: ex.MAX_DEPTH },
   };
   fs.writeFileSync(path.join(OUT, `scene_rayjs${preset}_flat.json`), JSON.stringify(flat));
+  fs.mkdirSync(path.resolve(__dirname, '../../raytracer_amd/presets'), { recursive: true });
+  fs.writeFileSync(path.resolve(__dirname, `../../raytracer_amd/presets/rayjs_${preset}.json`), JSON.stringify(flat));   // for the host's loadPreset
 
   const img = new Float64Array(W * H * 4), draws = new Int32Array(W * H);
   let errors = 0;

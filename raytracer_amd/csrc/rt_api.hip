@@ -57,7 +57,7 @@ void rt_default_params(rt_params *p) {
   p->num_photons_diffuse = 20000; p->num_photons_caustic = 50000;
   p->diffuse_radius = 0.40; p->caustic_radius = 0.15; p->standard_lamp_area = 100;
   p->seed = 12345; p->use_direct_light = 1; p->use_photon_maps = 1;
-  p->precision = RT_PRECISION_F32; p->mode = RT_MODE_PHOTON; p->shadow_bias = 0; p->epsilon_f32 = 1e-4; p->max_bounces = 64;
+  p->precision = RT_PRECISION_F32; p->mode = RT_MODE_PHOTON; p->shadow_bias = 0; p->epsilon_f32 = 1e-4; p->max_bounces = 4096;
 }
 
 int rt_init(const int *device_ids, int n, rt_ctx **out) {

@@ -111,7 +111,7 @@ static int trace_tile_mode(rt_scene *sc, const rt_params *p, DevMap md, DevMap m
   C.caustic_radius = p->caustic_radius; C.standard_lamp_area = p->standard_lamp_area;
   C.shadow_bias = p->shadow_bias > 0 ? p->shadow_bias : C.epsilon;
   C.max_depth = p->max_depth; C.sub_sample = p->sub_sample; C.use_direct_light = p->use_direct_light;
-  C.use_photon_maps = p->use_photon_maps; C.max_bounces = p->max_bounces > 0 ? p->max_bounces : 64;
+  C.use_photon_maps = p->use_photon_maps; C.max_bounces = p->max_bounces > 0 ? p->max_bounces : 4096;
   C.seed = p->seed; C.x0 = x0; C.y0 = y0; C.w = w; C.h = h; C.n_paths = (uint32_t)n_paths;
   C.magic_w = (uint32_t)(0x100000000ull / (uint64_t)w); C.magic_ss = (uint32_t)(0x100000000ull / (uint64_t)(p->sub_sample * p->sub_sample));
   C.magic_s = (uint32_t)(0x100000000ull / (uint64_t)p->sub_sample);

@@ -153,10 +153,18 @@ class Scene {
     this._device = null;
   }
 
+  // Presets 0, 2, 4, 7, 10 are built with this host's constructors (presets.js); the others come from the flat scene
+  // files of raytracer_amd/presets (all 13 scenes of rayphoton.js:731-1305 are there, the RNG-built ones as one instance).
   loadPreset(def) {
     const build = presets[String(def)];
-    if (!build) { console.log('No such scene!'); }                           // rayphoton.js:1306
-    else build(this, S);
+    const file = path.join(__dirname, '..', 'presets', `preset_${def}.json`);
+    if (build) build(this, S);
+    else if (require('fs').existsSync(file)) {
+      const src = JSON.parse(require('fs').readFileSync(file, 'utf8'));
+      this.lights = src.lights.map((l) => l.shape);
+      this.flatten = () => S.flattenFromJSON(src, this.canvasWidth, this.canvasHeight);
+      this.initLights = () => { this._device = null; };
+    } else { console.log('No such scene!'); }                                // rayphoton.js:1306
     this.initLights();
     this.emitManyPhotons();
   }
@@ -256,6 +264,11 @@ class WhittedScene extends FlatFileScene {
   }
   flatten() { return this._fromFile ? super.flatten() : S.flatten(this); }
   emitManyPhotons() { /* ray.js has no photon pass */ }
+  // the four scenes of ray.js:560-766
+  loadPreset(def) {
+    this._flatSource = JSON.parse(require('fs').readFileSync(path.join(__dirname, '..', 'presets', `rayjs_${def}.json`), 'utf8'));
+    this._fromFile = true; this._device = null;
+  }
 }
 
 // Binary PPM (P6) of an rgba8 frame as render() returns it; alpha is dropped.

@@ -7,7 +7,7 @@ boundaries."""
 import numpy as np
 import pytest
 
-from golden_io import RAYJS_PARAMS, load_bundle, load_rayjs_scene, load_scene
+from golden_io import ALL_PRESETS, RAYJS_PARAMS, load_bundle, load_packaged_preset, load_rayjs_scene, load_scene
 from oracle import oracle as ora
 
 pytestmark = pytest.mark.gpu
@@ -371,7 +371,7 @@ def test_sharded_protocol_on_gpu_equals_emit_many(c1_emit):
 
 
 # ------------------------------------------------------------------ mode A: the older tracer (ray.js)
-@pytest.mark.parametrize("preset,rays", [(2, 52993), (3, 59233), (0, 58604)])
+@pytest.mark.parametrize("preset,rays", [(2, 52993), (3, 59233), (0, 58604), (1, 90165)])
 def test_image_mode_a_f64_matches_reference(rt, preset, rays, monkeypatch):
     capi, ctx = rt
     g = load_bundle(f"image_rayjs{preset}")
@@ -569,3 +569,32 @@ def test_hierarchy_frames_equal_all_primitive_frames(rt, monkeypatch):
             assert same_px(x["pre"], y["pre"]).mean() > 0.995
         assert x["stats"]["rays"] == y["stats"]["rays"] or prec == capi.PRECISION_F32
         assert x["stats"]["prim_tests"] * 20 < y["stats"]["prim_tests"]       # > 95 % of the tests avoided
+
+
+# ------------------------------------------------------------------ every preset of the reference
+@pytest.mark.parametrize("name", ALL_PRESETS)
+def test_every_preset_emits_and_renders_like_the_oracle(rt, name):
+    """all 13 scenes of rayphoton.js, fp64, full pipeline (emission, both kd-trees, direct light, gathers) at a small
+    size against the CPU oracle (which is pinned to the reference on the default scene)"""
+    capi, ctx = rt
+    W, H, ND, NC = 96, 64, 1500, 1500
+    flat = load_packaged_preset(name, W, H)
+    sc = ctx.upload(flat)
+    # (max_bounces: the reference has no bounce cap -- paths caught between glass surfaces go on until maxDist is used up)
+    p = capi.default_params(precision=capi.PRECISION_F64, num_photons_diffuse=ND, num_photons_caustic=NC, seed=SEED, max_bounces=1000000)
+    e = sc.emit_many(p, strict=False)
+    osc = ora.Scene(flat)
+    op = ora.params(seed=SEED, num_photons_diffuse=ND, num_photons_caustic=NC)
+    oe = ora.emit_many(osc, op)
+    assert same(e["diffuse"], oe["diffuse"]) and same(e["caustic"], oe["caustic"])
+    assert e["stats"]["attempts_phase1"] == oe["attempts1"] and e["stats"]["attempts_phase2"] == oe["attempts2"]
+    md = ctx.photon_map(e["diffuse"]) if len(e["diffuse"]) else None
+    mc = ctx.photon_map(e["caustic"]) if len(e["caustic"]) else None
+    out = sc.trace_tile(p, md, mc)
+    maps = ora.Maps(oe["diffuse"], oe["caustic"])
+    pre, post, rays, _ = ora.render(osc, op, maps, 0, 0, W, H)
+    err = np.abs(out["pre"][..., :3] - pre[..., :3]) / np.maximum(1.0, np.abs(pre[..., :3]))
+    bad = ~((err <= 1e-9) | (np.isnan(out["pre"][..., :3]) & np.isnan(pre[..., :3]))).all(axis=-1)
+    # photon positions are fp32 in the device tree: a photon within rounding of a search-ball boundary may flip
+    assert bad.sum() <= 6, (name, int(bad.sum()))
+    assert out["stats"]["rays"] == rays

@@ -143,7 +143,7 @@ def test_image_c1_mode_b(c1_emission):
     assert rays > W * H
 
 
-@pytest.mark.parametrize("preset,rays", [(2, 52993), (3, 59233), (0, 58604)])
+@pytest.mark.parametrize("preset,rays", [(2, 52993), (3, 59233), (0, 58604), (1, 90165)])
 def test_image_mode_a_whitted(preset, rays):
     """the older tracer (ray.js:801-993): every pixel of three presets, bit for bit"""
     g = load_bundle(f"image_rayjs{preset}")
