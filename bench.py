@@ -106,11 +106,17 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # RT355_BENCH_REHEARSAL=1: all ranks share GPU 0 and talk over gloo -- a dry run of the N > 1 control flow on a
+    # one-GPU box (the numbers mean nothing); the real thing is one GPU per rank over RCCL
+    rehearsal = os.environ.get("RT355_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group("gloo" if rehearsal else "nccl", rank=rank, world_size=world)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    cdev = torch.device("cpu") if rehearsal else dev          # where the tensors of the collectives live
 
     from raytracer_amd import capi, synth
     from raytracer_amd.scene import FlatScene
@@ -158,15 +164,16 @@ def main():
     tail_ms = tail_ms / max(1, tail_launches) * args.steps
     ctx.profile_enable(False)
 
-    tot = torch.tensor([float(rays), dt], dtype=torch.float64, device=dev)
+    tot = torch.tensor([float(rays), dt], dtype=torch.float64, device=cdev)
     if world > 1:
         rays_all = tot[0:1].clone()
         dist.all_reduce(rays_all, op=dist.ReduceOp.SUM)
         tmax = tot[1:2].clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         rays_total, t_total = float(rays_all.item()), float(tmax.item())
-        frames = [torch.empty_like(frame) for _ in range(world)] if rank == 0 else None
-        dist.gather(frame, frames, dst=0)                                  # tiles/frames to rank 0 (outside the timed region)
+        fr = frame.to(cdev)
+        frames = [torch.empty_like(fr) for _ in range(world)] if rank == 0 else None
+        dist.gather(fr, frames, dst=0)                                     # tiles/frames to rank 0 (outside the timed region)
     else:
         rays_total, t_total = float(rays), dt
 
@@ -198,7 +205,7 @@ def main():
         fb_ms, fb_launches = ctx.profile_get("gather_knn_heap_fallback")
         ctx.profile_enable(False)
         gathers = hits.shape[0] * gsteps
-        gps = torch.tensor([gathers / gdt], dtype=torch.float64, device=dev)
+        gps = torch.tensor([gathers / gdt], dtype=torch.float64, device=cdev)
         if world > 1:
             dist.all_reduce(gps, op=dist.ReduceOp.SUM)
         g_achieved = hits.shape[0] * BYTES_PER_GATHER / (g_ms / g_launches * 1e-3) / 1e9
