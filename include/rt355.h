@@ -83,7 +83,9 @@ typedef struct rt_params {
                                    fp32 resolution at scene scale, so on-surface origins would re-hit their surface */
   int32_t max_bounces;          /* hard cap on path segments (0 = 4096); the reference has none: a path caught between
                                    glass surfaces goes on until max_trace_dist is used up (hundreds of segments) */
-  int32_t reserved;
+  int32_t super_sample_block;   /* SUPER_SAMPLE_BASE ** superSampleScale (rayphoton.js:1574-1596, :1911): rt_trace_tile traces one
+                                   jittered sample per block of this many pixels squared and its outputs hold one value per
+                                   block, ceil(h / block) rows of ceil(w / block); 0 or 1 = every pixel */
 } rt_params;
 
 typedef struct rt_trace_stats {

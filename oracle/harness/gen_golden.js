@@ -280,7 +280,7 @@ function treeArrays(tree) {                            // nodes[pos] -> (input i
   return { perm, dim };
 }
 
-function genC1(withImage) {
+function genC1(withImage, withScaled) {
   const ND = 10000, NC = 10000;
   const { L, scene, px } = buildScene(10, { numDiffuse: ND, numCaustic: NC });
   const ex = L.ex;
@@ -351,10 +351,33 @@ function genC1(withImage) {
   writeBundle(path.join(OUT, 'queries_c1'), qOut, { K, radii: { diffuse: 0.40, caustic: 0.15, diffuse_wide: 1.0 },
     note: 'radius results are photon indices in the reference pre-order (kdtree.js:64-80) as CSR; knn = brute force ordered by (d2, index)' });
 
-  if (!withImage) return;
+  if (!withImage && !withScaled) return;
   // image: the scene's own trees (built on the unrounded lists, as the reference does)
   scene.photonKdTDiffuse = new ex.KdTree(scene.photonListDiffuse);
   scene.photonKdTCaustic = new ex.KdTree(scene.photonListCaustic);
+  if (withScaled) {
+    // the progressive preview levels: traceOnCanvas(x, y, scale) traces ONE jittered sample for the block of
+    // SUPER_SAMPLE_BASE ** scale pixels at (x, y) (rayphoton.js:1589-1596, :1911); stream (RENDER, pixel of the block's corner, 0)
+    const outS = {}, metaS = {};
+    for (const scale of [1, 2]) {
+      const sblk = ex.SUPER_SAMPLE_BASE ** scale, nbx = Math.ceil(W / sblk), nby = Math.ceil(H / sblk);
+      const postS = new Float64Array(nby * nbx * 4), drawsS = new Int32Array(nby * nbx);
+      for (let by = 0; by < nby; by++) for (let bx = 0; bx < nbx; bx++) {
+        const x = bx * sblk, y = by * sblk, pi = y * W + x;
+        L.rng.setStream(PH.DOMAIN_RENDER, pi, 0);
+        scene.traceOnCanvas(x, y, scale);
+        drawsS[by * nbx + bx] = L.rng.draw;
+        for (let c = 0; c < 4; c++) postS[(by * nbx + bx) * 4 + c] = px[pi * 4 + c];
+      }
+      outS[`post_block${sblk}`] = { data: postS, shape: [nby, nbx, 4] };
+      outS[`draws_block${sblk}`] = { data: drawsS, shape: [nby, nbx] };
+      metaS[`block${sblk}`] = [nby, nbx];
+      console.log(`scaled preview, block ${sblk}: ${nbx}x${nby} samples`);
+    }
+    writeBundle(path.join(OUT, 'image_c1_scaled'), outS, { seed: SEED, W, H, ND, NC, preset: 10, blocks: metaS,
+      note: 'what putPixel received from traceOnCanvas(x, y, scale) for every block corner (x, y) of the C1 frame, scale 1 and 2' });
+  }
+  if (!withImage) return;
   const pre = new Float64Array(W * H * 4), post = new Float64Array(W * H * 4), draws = new Int32Array(W * H);
   t0 = Date.now();
   for (let y = 0; y < H; y++) {
@@ -388,4 +411,4 @@ if (want.has('presets')) genPresets();
 if (all || want.has('intersect')) genIntersect();
 if (all || want.has('closest')) genClosest();
 if (all || want.has('samples')) genSamples();
-if (all || want.has('c1') || want.has('c1image')) genC1(all || want.has('c1image'));
+if (all || want.has('c1') || want.has('c1image') || want.has('c1scaled')) genC1(all || want.has('c1image'), all || want.has('c1scaled'));

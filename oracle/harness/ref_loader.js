@@ -45,7 +45,7 @@ function loadRayphoton(opts) {
          ' Box, Prism, Cuboctahedron, Ball, Can, Tube, Halfball, Bowl, Spotlight,' +
          ' matTransparent, matRefrIndex, matReflectance, matSpecular,' +
          ' NUM_PHOTONS_DIFFUSE, NUM_PHOTONS_CAUSTIC, SUB_SAMPLE, MAX_TRACE_DIST, MAX_DEPTH,' +
-         ' EPSILON, DIFFUSE_RADIUS, CAUSTIC_RADIUS, COL_WHITE, MAT_AIR});';
+         ' EPSILON, DIFFUSE_RADIUS, CAUSTIC_RADIUS, COL_WHITE, MAT_AIR, SUPER_SAMPLE_BASE});';
   const log = [];
   const ctx = makeContext(rng, log);
   const ex = vm.runInContext(src, ctx, { filename: 'reference:rayphoton+kdtree' });

@@ -25,7 +25,8 @@ class OraParams(C.Structure):
                 ("sub_sample", C.c_int32), ("num_photons_diffuse", C.c_uint32),
                 ("num_photons_caustic", C.c_uint32), ("diffuse_radius", C.c_double),
                 ("caustic_radius", C.c_double), ("standard_lamp_area", C.c_double), ("seed", C.c_uint64),
-                ("use_direct_light", C.c_int32), ("use_photon_maps", C.c_int32)]
+                ("use_direct_light", C.c_int32), ("use_photon_maps", C.c_int32),
+                ("super_sample_block", C.c_int32), ("pad_", C.c_int32)]
 
 
 def lib():
@@ -216,8 +217,9 @@ def render_whitted(scene: Scene, p: OraParams, x0, y0, w, h):
 
 
 def render(scene: Scene, p: OraParams, maps: Maps | None, x0, y0, w, h):
-    pre = np.zeros((h, w, 4), np.float64)
-    post = np.zeros((h, w, 4), np.float64)
+    b = max(1, p.super_sample_block)
+    pre = np.zeros((-(-h // b), -(-w // b), 4), np.float64)
+    post = np.zeros((-(-h // b), -(-w // b), 4), np.float64)
     rays, tests = C.c_uint64(), C.c_uint64()
     lib().ora_render(C.byref(scene.c), C.byref(p), C.c_void_p(maps.h if maps else None), C.c_int(x0), C.c_int(y0),
                      C.c_int(w), C.c_int(h), _p(pre), _p(post), C.byref(rays), C.byref(tests))

@@ -61,7 +61,7 @@ void ora_default_params(ora_params *p) {
   p->epsilon = 1e-6; p->max_trace_dist = 20; p->max_depth = 5; p->sub_sample = 1;
   p->num_photons_diffuse = 20000; p->num_photons_caustic = 50000;
   p->diffuse_radius = 0.40; p->caustic_radius = 0.15; p->standard_lamp_area = 100;
-  p->seed = 12345; p->use_direct_light = 1; p->use_photon_maps = 1;
+  p->seed = 12345; p->use_direct_light = 1; p->use_photon_maps = 1; p->super_sample_block = 0; p->pad_ = 0;
 }
 
 /* ------------------------------------------------------------------ vectors (rayphoton.js:104-112) */
@@ -756,16 +756,21 @@ void ora_render(const ora_scene *s, const ora_params *P, const ora_maps *m,
   const double *cam = s->camera;
   v3 co = ld(cam), cu = ld(cam + 3), cv = ld(cam + 6), cw = ld(cam + 9);
   const int S = P->sub_sample;
-  for (int yy = 0; yy < h; yy++)
-    for (int xx = 0; xx < w; xx++) {
-      int X = x0 + xx, Y = y0 + yy;
+  const int B = P->super_sample_block > 1 ? P->super_sample_block : 1;      /* block side: SUPER_SAMPLE_BASE ** scale */
+  const int wb = (w + B - 1) / B, hb = (h + B - 1) / B;
+  w = wb;                                                                   /* (outputs are indexed by block) */
+  for (int yy = 0; yy < hb; yy++)
+    for (int xx = 0; xx < wb; xx++) {
+      int X = x0 + xx * B, Y = y0 + yy * B;
       uint32_t pixel = (uint32_t)(Y * (int)s->width + X);
       double tot[4] = { 0, 0, 0, 0 }; col_t last = { 0, 0, 0, 0 };
       for (int sy = 0; sy < S; sy++)
-        for (int sx = 0; sx < S; sx++) {                       /* rayphoton.js:1589-1616, superSampleScale = 0 */
+        for (int sx = 0; sx < S; sx++) {                       /* rayphoton.js:1589-1616 */
           rng_set(&g, P->seed, ORA_DOMAIN_RENDER, pixel, (uint32_t)(sy * S + sx));
-          double u = ((X + (sx + rng_next(&g)) / S) * 2 / s->width) - 1;
-          double v = -(((Y + (sy + rng_next(&g)) / S) * 2 / s->height) - 1);
+          double ssx = X, ssy = Y;
+          if (B > 1) { ssx += B * rng_next(&g); ssy += B * rng_next(&g); }    /* :1593-1596 */
+          double u = ((ssx + (sx + rng_next(&g)) / S) * 2 / s->width) - 1;
+          double v = -(((ssy + (sy + rng_next(&g)) / S) * 2 / s->height) - 1);
           u *= cam[12]; v *= cam[13];
           v3 xyz = plus(plus(plus(co, scal(u, cu)), scal(v, cv)), scal(-1, cw));   /* Camera.toXYZ :712 */
           mstack st; st.len = 1; st.m[0] = 0;

@@ -49,6 +49,9 @@ typedef struct ora_params {
   uint64_t seed;
   int32_t use_direct_light;    /* 0 disables directLight (config "primary + reflect/refract only") */
   int32_t use_photon_maps;     /* 0 disables both radius gathers */
+  int32_t super_sample_block;  /* SUPER_SAMPLE_BASE ** superSampleScale (rayphoton.js:1589-1596): one jittered sample per
+                                  block of this many pixels squared; 0 or 1 = every pixel */
+  int32_t pad_;
 } ora_params;
 
 /* photon record: origin3 dir3 power r g b a  (11 doubles), as rayphoton.js:647-654 */
@@ -100,7 +103,8 @@ void ora_knn_brute(const double *pos, uint32_t n, const double x[3], uint32_t k,
 typedef struct ora_maps ora_maps;
 ora_maps *ora_maps_create(const double *diffuse, uint32_t nd, const double *caustic, uint32_t nc);
 void ora_maps_destroy(ora_maps *m);
-/* renders pixels [x0,x0+w) x [y0,y0+h); pre = raw traceRay sums (rgba per sub-sample averaged is NOT
+/* renders pixels [x0,x0+w) x [y0,y0+h) -- with super_sample_block b > 1 one sample per b x b block, outputs sized
+ * ceil(h/b) x ceil(w/b); pre = raw traceRay sums (rgba per sub-sample averaged is NOT
  * applied: with sub_sample==1 pre is the single traceRay result), post = what putPixel receives. */
 void ora_render(const ora_scene *s, const ora_params *p, const ora_maps *m,
                 int x0, int y0, int w, int h, double *pre_rgba, double *post_rgba,

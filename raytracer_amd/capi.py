@@ -48,7 +48,7 @@ class Params(C.Structure):
                 ("caustic_radius", C.c_double), ("standard_lamp_area", C.c_double), ("seed", C.c_uint64),
                 ("use_direct_light", C.c_int32), ("use_photon_maps", C.c_int32), ("precision", C.c_int32),
                 ("mode", C.c_int32), ("shadow_bias", C.c_double), ("epsilon_f32", C.c_double), ("max_bounces", C.c_int32),
-                ("reserved", C.c_int32)]
+                ("super_sample_block", C.c_int32)]
 
 
 class TraceStats(C.Structure):
@@ -234,9 +234,11 @@ class Scene:
         (numpy arrays or device tensors), in which case nothing is allocated for that output."""
         w = self.flat.width if w is None else w
         h = self.flat.height if h is None else h
-        pre = out_pre if out_pre is not None else (np.empty((h, w, 4), np.float64) if "pre" in want else None)
-        post = out_post if out_post is not None else (np.empty((h, w, 4), np.float64) if "post" in want else None)
-        rgba8 = out_rgba8 if out_rgba8 is not None else (np.empty((h, w, 4), np.uint8) if "rgba8" in want else None)
+        b = max(1, params.super_sample_block)
+        wo, ho = -(-w // b), -(-h // b)                       # one output value per block
+        pre = out_pre if out_pre is not None else (np.empty((ho, wo, 4), np.float64) if "pre" in want else None)
+        post = out_post if out_post is not None else (np.empty((ho, wo, 4), np.float64) if "post" in want else None)
+        rgba8 = out_rgba8 if out_rgba8 is not None else (np.empty((ho, wo, 4), np.uint8) if "rgba8" in want else None)
         st = TraceStats()
         self.ctx.check(self.ctx.lib.rt_trace_tile(
             self.h, C.byref(params), C.c_void_p(diffuse.h.value if diffuse else None),

@@ -57,7 +57,7 @@ void rt_default_params(rt_params *p) {
   p->num_photons_diffuse = 20000; p->num_photons_caustic = 50000;
   p->diffuse_radius = 0.40; p->caustic_radius = 0.15; p->standard_lamp_area = 100;
   p->seed = 12345; p->use_direct_light = 1; p->use_photon_maps = 1;
-  p->precision = RT_PRECISION_F32; p->mode = RT_MODE_PHOTON; p->shadow_bias = 0; p->epsilon_f32 = 1e-4; p->max_bounces = 4096;
+  p->precision = RT_PRECISION_F32; p->mode = RT_MODE_PHOTON; p->shadow_bias = 0; p->epsilon_f32 = 1e-4; p->max_bounces = 4096; p->super_sample_block = 0;
 }
 
 int rt_init(const int *device_ids, int n, rt_ctx **out) {
@@ -425,7 +425,9 @@ int rt_trace_tile(rt_scene *sc, const rt_params *p, rt_photon_map *diffuse, rt_p
   if (p->mode != RT_MODE_PHOTON && p->mode != RT_MODE_WHITTED) return rt_fail(ctx, RT_ERR_INVALID, "unknown mode %d", p->mode);
   if ((diffuse && diffuse->ctx != ctx) || (caustic && caustic->ctx != ctx)) return rt_fail(ctx, RT_ERR_INVALID, "photon map belongs to another context");
   RT_HIP(ctx, hipSetDevice(ctx->device));
-  const size_t npx = (size_t)w * h;
+  if (p->super_sample_block < 0 || p->super_sample_block > 65536) return rt_fail(ctx, RT_ERR_INVALID, "super_sample_block must be in 0..65536");
+  const int blk = p->super_sample_block > 1 ? p->super_sample_block : 1;
+  const size_t npx = (size_t)((w + blk - 1) / blk) * (size_t)((h + blk - 1) / blk);      // outputs hold one value per block
   DevMem t1, t2, t3; void *pre, *post, *r8;
   RT_TRY(rt_stage_out_begin(ctx, pre_rgba, npx * 32, t1, &pre));
   RT_TRY(rt_stage_out_begin(ctx, post_rgba, npx * 32, t2, &post));

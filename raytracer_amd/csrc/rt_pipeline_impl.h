@@ -94,7 +94,9 @@ static int trace_tile_mode(rt_scene *sc, const rt_params *p, DevMap md, DevMap m
                            double *pre, double *post, uint8_t *rgba8, rt_trace_stats *stats) {
   rt_ctx *ctx = sc->ctx;
   DevScene<T> &S = SceneOf<T>::get(sc);
-  const size_t n_pixels = (size_t)w * h;
+  const int blk = p->super_sample_block > 1 ? p->super_sample_block : 1;       // one traced sample per blk x blk pixels
+  const int wb = (w + blk - 1) / blk, hb = (h + blk - 1) / blk;
+  const size_t n_pixels = (size_t)wb * hb;
   const size_t n_paths = n_pixels * p->sub_sample * p->sub_sample;
   if (n_paths == 0) return RT_OK;
   if (n_paths > 0x7FFFFFFFull) return rt_fail(ctx, RT_ERR_TOO_LARGE, "tile has too many paths (%zu)", n_paths);
@@ -112,8 +114,8 @@ static int trace_tile_mode(rt_scene *sc, const rt_params *p, DevMap md, DevMap m
   C.shadow_bias = p->shadow_bias > 0 ? p->shadow_bias : C.epsilon;
   C.max_depth = p->max_depth; C.sub_sample = p->sub_sample; C.use_direct_light = p->use_direct_light;
   C.use_photon_maps = p->use_photon_maps; C.max_bounces = p->max_bounces > 0 ? p->max_bounces : 4096;
-  C.seed = p->seed; C.x0 = x0; C.y0 = y0; C.w = w; C.h = h; C.n_paths = (uint32_t)n_paths;
-  C.magic_w = (uint32_t)(0x100000000ull / (uint64_t)w); C.magic_ss = (uint32_t)(0x100000000ull / (uint64_t)(p->sub_sample * p->sub_sample));
+  C.seed = p->seed; C.x0 = x0; C.y0 = y0; C.w = wb; C.h = hb; C.block = blk; C.n_paths = (uint32_t)n_paths;
+  C.magic_w = (uint32_t)(0x100000000ull / (uint64_t)wb); C.magic_ss = (uint32_t)(0x100000000ull / (uint64_t)(p->sub_sample * p->sub_sample));
   C.magic_s = (uint32_t)(0x100000000ull / (uint64_t)p->sub_sample);
   C.fuse_resolve = (!WHITTED && p->sub_sample == 1) ? 1 : 0; C.pre = pre; C.post = post; C.rgba8 = rgba8;
   if (!p->use_photon_maps) { md.n = 0; mc.n = 0; }

@@ -51,7 +51,8 @@ struct TraceCfg {
   double epsilon, max_trace_dist, diffuse_radius, caustic_radius, standard_lamp_area, shadow_bias;
   int32_t max_depth, sub_sample, use_direct_light, use_photon_maps, max_bounces;
   uint64_t seed;
-  int32_t x0, y0, w, h;
+  int32_t x0, y0, w, h;               // tile origin (canvas pixels); columns and rows of traced samples
+  int32_t block;                      // canvas pixels per traced sample along each axis (1 = every pixel)
   uint32_t n_paths;                   // w * h * sub_sample^2
   uint32_t magic_w, magic_ss, magic_s; // floor(2^32 / d) for d = w, sub_sample^2, sub_sample (see div_by)
   // with one sub-sample per pixel a finished path is the finished pixel: the shading kernels write the tile's outputs
@@ -104,7 +105,7 @@ RT_D void path_pixel(const TraceCfg &C, uint32_t p, int &X, int &Y, uint32_t &su
   uint32_t col;
   const uint32_t pix = div_by(p, (uint32_t)(C.sub_sample * C.sub_sample), C.magic_ss, sub);
   const uint32_t row = div_by(pix, (uint32_t)C.w, C.magic_w, col);
-  X = C.x0 + (int)col; Y = C.y0 + (int)row;
+  X = C.x0 + (int)col * C.block; Y = C.y0 + (int)row * C.block;
 }
 
 // traceOnCanvas ray set-up (rayphoton.js:1589-1609, superSampleScale 0) for path p: the initial path state
@@ -115,8 +116,10 @@ RT_D PathState<T> raygen_path(const DevScene<T> &S, const TraceCfg &C, uint32_t 
   path_pixel(C, p, X, Y, sub);
   const int sy = (int)div_by(sub, (uint32_t)C.sub_sample, C.magic_s, sxu), sx = (int)sxu;
   RngStream rng; rng.init(C.seed, RT_DOMAIN_RENDER, (uint32_t)(Y * (int)S.width + X), sub);
-  T u = ((T(X) + (T(sx) + rng.next<T>()) / T(C.sub_sample)) * T(2) / T(S.width)) - T(1);
-  T v = -(((T(Y) + (T(sy) + rng.next<T>()) / T(C.sub_sample)) * T(2) / T(S.height)) - T(1));
+  T ssx = T(X), ssy = T(Y);
+  if (C.block > 1) { ssx += T(C.block) * rng.next<T>(); ssy += T(C.block) * rng.next<T>(); }    // one point for the block, :1593-1596
+  T u = ((ssx + (T(sx) + rng.next<T>()) / T(C.sub_sample)) * T(2) / T(S.width)) - T(1);
+  T v = -(((ssy + (T(sy) + rng.next<T>()) / T(C.sub_sample)) * T(2) / T(S.height)) - T(1));
   u *= S.camera[12]; v *= S.camera[13];
   V3<T> co = ld3(S.camera), cu = ld3(S.camera + 3), cv = ld3(S.camera + 6), cw = ld3(S.camera + 9);
   V3<T> xyz = ((co + u * cu) + v * cv) + T(-1) * cw;                    // Camera.toXYZ, rayphoton.js:712

@@ -30,6 +30,7 @@ const PRECISION = { F32: 0, F64: 1 };
 const DEFAULTS = {
   epsilon: 1e-6, maxTraceDist: 20, maxDepth: 5, subSample: 6, numPhotonsDiffuse: 20000, numPhotonsCaustic: 50000,
   causticRadius: 0.15, diffuseRadius: 0.40, standardLampArea: 100, seed: 12345, precision: PRECISION.F32,
+  superSampleBase: 3, superSampleLevels: 10,                  // rayphoton.js:14-15
 };
 
 class Ray {
@@ -211,21 +212,93 @@ class Scene {
   // traceTile / traceOnCanvas (rayphoton.js:1573-1624) at superSampleScale 0: one launch per tile,
   // then the same fillStyle / fillRect calls per pixel that putPixel makes (:1910-1919)
   traceTile(tile, tileSize, superSampleScale) {
-    if (superSampleScale) throw new Error('traceTile: progressive super-sample levels (scale > 0) are a presentation feature of the browser UI and are not offered');
     const x0 = tile[0], y0 = tile[1];
     const w = Math.min(tileSize, this.canvasWidth - x0), h = Math.min(tileSize, this.canvasHeight - y0);
     if (w <= 0 || h <= 0) return;
-    const out = this.render(x0, y0, w, h);
+    // scale > 0: one jittered sample stands for a block of base ** scale pixels (rayphoton.js:1574-1596), drawn as one
+    // filled square (:1911)
+    const s = superSampleScale ? this.params.superSampleBase ** superSampleScale : 1;
+    const out = this.render(x0, y0, w, h, s > 1 ? { superSampleBlock: s } : undefined);
     if (this.ctx && typeof this.ctx.fillRect === 'function') {
-      for (let y = 0; y < h; y++) for (let x = 0; x < w; x++) {
-        const o = (y * w + x) * 4, p = out.post;
+      const wb = Math.ceil(w / s), hb = Math.ceil(h / s);
+      for (let y = 0; y < hb; y++) for (let x = 0; x < wb; x++) {
+        const o = (y * wb + x) * 4, p = out.post;
         this.ctx.fillStyle = 'rgba(' + p[o] + ',' + p[o + 1] + ',' + p[o + 2] + ',' + p[o + 3] + ')';
-        this.ctx.fillRect(x0 + x, y0 + y, 1, 1);
+        this.ctx.fillRect(x0 + x * s, y0 + y * s, s, s);
       }
     }
     return out;
   }
   traceOnCanvas(canvasX, canvasY, superSampleScale) { return this.traceTile([canvasX, canvasY], 1, superSampleScale); }
+
+  // The order in which the reference's superSampleTiles (rayphoton.js:2108-2244) draws: coarse preview levels first,
+  // and inside a level the tiles where the photon density changes most (shadow edges, caustics), never a tile before
+  // the larger tile that covers it.  Returns [{region: [x, y], size, scale, photonDiff}] in drawing order.  (The
+  // reference breaks ties with an engine-dependent random shuffle; here ties keep row-major order.)
+  progressiveTiles() {
+    const B = this.params.superSampleBase, L = this.params.superSampleLevels;
+    const tileSize = Math.max(1, Math.floor(50 / this.params.subSample));
+    const tx = Math.floor(this.canvasWidth / tileSize) + 1, ty = Math.floor(this.canvasHeight / tileSize) + 1;
+    const count = new Float64Array(tx * ty);
+    for (const rec of [this._recD, this._recC]) {
+      if (!rec) continue;
+      for (let i = 0; i < rec.length; i += 11) {
+        const pr = this.projectToCanvas([rec[i], rec[i + 1], rec[i + 2]]);
+        if (!pr) continue;
+        const x = Math.floor(pr.x / tileSize), y = Math.floor(pr.y / tileSize);
+        if (x >= 0 && x < tx && y >= 0 && y < ty) count[y * tx + x]++;
+      }
+    }
+    const tiles = [];
+    for (let scale = 0; scale <= L; scale++) {
+      const step = B ** scale;
+      if (step > Math.max(tx, ty) * B) break;                 // (levels coarser than the canvas repeat the same single tile)
+      for (let y = 0; y < ty; y += step) for (let x = 0; x < tx; x += step) {
+        let diff = 0;
+        for (let j = -2; j <= 2; j++) for (let i = -2; i <= 2; i++) {
+          if ((i || j) && y + j >= 0 && y + j < ty && x + i >= 0 && x + i < tx) diff += (count[y * tx + x] - count[(y + j) * tx + (x + i)]) ** 2 / (i * i + j * j);
+        }
+        tiles.push({ region: [x * tileSize, y * tileSize], size: tileSize * step, scale, photonDiff: diff, _gx: x, _gy: y });
+      }
+      // fold this level's counts into the corner tile of every group of the next level
+      const next = step * B;
+      for (let y = 0; y < ty; y += next) for (let x = 0; x < tx; x += next) {
+        for (let bj = 0; bj < B; bj++) for (let bi = 0; bi < B; bi++) {
+          const i = bi * step, j = bj * step;
+          if ((i || j) && x + i < tx && y + j < ty) count[y * tx + x] += count[(y + j) * tx + (x + i)];
+        }
+      }
+    }
+    // drawing order: a tile is ready once the tile covering it one level up has been drawn; the ready tile with the
+    // largest scale, then the largest photonDiff, goes next
+    const key = (t) => `${t.scale}:${t._gx}:${t._gy}`;
+    const byKey = new Map(tiles.map((t) => [key(t), t]));
+    const top = Math.max(...tiles.map((t) => t.scale));
+    const children = new Map();
+    let ready = [];
+    for (const t of tiles) {
+      if (t.scale === top) { ready.push(t); continue; }
+      const up = B ** (t.scale + 1);
+      const parent = byKey.get(`${t.scale + 1}:${Math.floor(t._gx / up) * up}:${Math.floor(t._gy / up) * up}`);
+      if (!parent) { ready.push(t); continue; }
+      if (!children.has(parent)) children.set(parent, []);
+      children.get(parent).push(t);
+    }
+    const order = [];
+    const better = (a, b) => (a.scale !== b.scale ? a.scale > b.scale : a.photonDiff > b.photonDiff);
+    while (ready.length) {
+      let bi = 0;
+      for (let i = 1; i < ready.length; i++) if (better(ready[i], ready[bi])) bi = i;
+      const t = ready.splice(bi, 1)[0];
+      order.push(t);
+      for (const c of children.get(t) || []) ready.push(c);
+    }
+    return order.map(({ region, size, scale, photonDiff }) => ({ region, size, scale, photonDiff }));
+  }
+  // draws the whole canvas in that order; onTile(tile, result) after each tile
+  renderProgressive(onTile) {
+    for (const t of this.progressiveTiles()) { const r = this.traceTile(t.region, t.size, t.scale); if (onTile) onTile(t, r); }
+  }
 
   projectToCanvas(xyz) {                                                      // rayphoton.js:1559-1571
     const uvw = this.camera.toUVW(xyz);

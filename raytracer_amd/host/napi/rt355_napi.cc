@@ -80,6 +80,7 @@ static void read_params(napi_env env, napi_value o, rt_params *p) {
   p->shadow_bias = prop_num(env, o, "shadowBias", p->shadow_bias);
   p->epsilon_f32 = prop_num(env, o, "epsilonF32", p->epsilon_f32);
   p->max_bounces = (int32_t)prop_num(env, o, "maxBounces", p->max_bounces);
+  p->super_sample_block = (int32_t)prop_num(env, o, "superSampleBlock", p->super_sample_block);
 }
 
 static void set_num(napi_env env, napi_value obj, const char *name, double v) { napi_value n; napi_create_double(env, v, &n); napi_set_named_property(env, obj, name, n); }
@@ -301,7 +302,8 @@ static napi_value TraceTile(napi_env env, napi_callback_info info) {
   MapBox *md = a.ext<MapBox>(2), *mc = a.ext<MapBox>(3);
   int x0 = (int)a.num(4), y0 = (int)a.num(5), w = (int)a.num(6), h = (int)a.num(7);
   if (w <= 0 || h <= 0) { napi_throw_range_error(env, nullptr, "traceTile: empty tile"); return nullptr; }
-  size_t npx = (size_t)w * h;
+  const int blk = p.super_sample_block > 1 ? p.super_sample_block : 1;
+  size_t npx = (size_t)((w + blk - 1) / blk) * (size_t)((h + blk - 1) / blk);      // one value per block
   napi_value ab1, ab2, ab3, pre, post, r8, out, stats; void *d1, *d2, *d3;
   NAPI_OK(napi_create_arraybuffer(env, npx * 32, &d1, &ab1)); NAPI_OK(napi_create_typedarray(env, napi_float64_array, npx * 4, ab1, 0, &pre));
   NAPI_OK(napi_create_arraybuffer(env, npx * 32, &d2, &ab2)); NAPI_OK(napi_create_typedarray(env, napi_float64_array, npx * 4, ab2, 0, &post));

@@ -92,6 +92,28 @@ for (let y = 64; y < 128; y++) for (let x = 96; x < 160; x++) for (let c = 0; c 
 for (let c = 0; c < 4; c++) if (!same(filled[(7 * W + 5) * 4 + c], img.post_floor[(7 * W + 5) * 4 + c])) tileBad++;
 check('Scene.traceTile / traceOnCanvas -> fillRect', tileBad <= 2, `${tileBad} pixels differ`);
 
+// preview levels and the progressive order: every pixel gets covered, coarse tiles before the tiles they contain
+{
+  const gs = loadBundle('image_c1_scaled');
+  filled.fill(NaN);
+  scene.traceTile([0, 0], 9 * 36, 2);                       // the whole frame as 9x9 blocks
+  let sbad = 0;
+  for (let by = 0; by < 27; by++) for (let bx = 0; bx < 36; bx++) {
+    for (let c = 0; c < 4; c++) if (!same(filled[((by * 9) * W + bx * 9) * 4 + c], gs.post_block9[(by * 36 + bx) * 4 + c])) { sbad++; break; }
+  }
+  check('Scene.traceTile(scale 2) -> fillRect', sbad <= 1, `${sbad} blocks differ`);
+  const order = scene.progressiveTiles();
+  const seen = new Uint8Array(W * H); let orderOk = true;
+  for (const t of order) {
+    for (let y = t.region[1]; y < Math.min(H, t.region[1] + t.size); y++) for (let x = t.region[0]; x < Math.min(W, t.region[0] + t.size); x++) {
+      if (t.scale < seen[y * W + x] - 1 && false) orderOk = false;
+      if (seen[y * W + x] && seen[y * W + x] - 1 < t.scale) orderOk = false;   // a coarser tile after a finer one over the same pixel
+      seen[y * W + x] = t.scale + 1;
+    }
+  }
+  check('Scene.progressiveTiles order', orderOk && seen.every((v) => v === 1), `${order.length} tiles`);
+}
+
 // the older tracer (ray.js) from its flat scene file, fp64: every pixel of the reference's frame
 {
   const path = require('path');

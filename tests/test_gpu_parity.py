@@ -598,3 +598,25 @@ def test_every_preset_emits_and_renders_like_the_oracle(rt, name):
     # photon positions are fp32 in the device tree: a photon within rounding of a search-ball boundary may flip
     assert bad.sum() <= 6, (name, int(bad.sum()))
     assert out["stats"]["rays"] == rays
+
+
+def test_preview_levels_match_reference(rt):
+    """super_sample_block = 3 and 9: the reference's traceOnCanvas(x, y, 1) and (x, y, 2) for every block of the C1 frame"""
+    capi, ctx = rt
+    g = load_bundle("image_c1_scaled")
+    ph = load_bundle("photons_c1")
+    W, H = g.meta["W"], g.meta["H"]
+    sc = ctx.upload(load_scene(10, W, H))
+    md, mc = ctx.photon_map(ph["diffuse"]), ctx.photon_map(ph["caustic"])
+    for b in (3, 9):
+        p = capi.default_params(precision=capi.PRECISION_F64, num_photons_diffuse=10000, num_photons_caustic=10000, seed=g.meta["seed"],
+                                super_sample_block=b)
+        out = sc.trace_tile(p, md, mc)
+        want = g[f"post_block{b}"]
+        assert out["post"].shape == want.shape
+        assert (~same_px(out["post"], want)).sum() <= 2           # (fp32 photon positions in the device tree, as for the full frame)
+        # a tile whose size is not a multiple of the block: the blocks that start inside it
+        part = sc.trace_tile(p, md, mc, x0=b * 5, y0=b * 3, w=50, h=31)
+        nb_x, nb_y = -(-50 // b), -(-31 // b)
+        assert part["post"].shape == (nb_y, nb_x, 4)
+        assert (~same_px(part["post"], want[3:3 + nb_y, 5:5 + nb_x])).sum() <= 1

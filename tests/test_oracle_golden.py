@@ -152,3 +152,16 @@ def test_image_mode_a_whitted(preset, rays):
     raw, post, n = ora.render_whitted(osc, op, 0, 0, g.meta["W"], g.meta["H"])
     assert same(raw, g["rgba"]) and n == rays
     assert same(post, g["rgba"])                 # one sub-sample: putPixel gets floor(colour / 1)
+
+
+def test_image_c1_preview_levels(c1_emission):
+    """traceOnCanvas(x, y, scale > 0) (rayphoton.js:1589-1596): one jittered sample per 3x3 and per 9x9 block"""
+    g = load_bundle("image_c1_scaled")
+    ph = load_bundle("photons_c1")
+    W, H = g.meta["W"], g.meta["H"]
+    osc = ora.Scene(load_scene(10, W, H))
+    maps = ora.Maps(ph["diffuse"], ph["caustic"])
+    for b in (3, 9):
+        op = ora.params(seed=g.meta["seed"], num_photons_diffuse=10000, num_photons_caustic=10000, super_sample_block=b)
+        _, post, _, _ = ora.render(osc, op, maps, 0, 0, W, H)
+        assert same(post, g[f"post_block{b}"])
