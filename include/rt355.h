@@ -179,6 +179,13 @@ int rt_kd_knn(rt_photon_map *map, const float *queries, uint32_t nq, uint32_t k,
  * distance (k > 0).  hits: nq x 9 fp32 = pos3 normal3 albedo3; rgb_out: nq x 3 fp32. */
 int rt_gather_radiance(rt_photon_map *map, const float *hits, uint32_t nq, double r, uint32_t k, float *rgb_out);
 
+/* The adaptive-radius search sketched in the reference's commented block (rayphoton.js:1766-1778, :1789-1801): start at
+ * r0 and, up to max_attempts times (10 there), multiply the radius by `grow` (3) while fewer than min_count (10) photons
+ * are inside; fewer than min_keep (3) photons in the end give no contribution.  rgb as rt_gather_radiance with the area of
+ * the radius that was used; r_used_out (nq floats, may be NULL) returns that radius. */
+int rt_gather_radiance_adaptive(rt_photon_map *map, const float *hits, uint32_t nq, double r0, double grow, uint32_t min_count,
+                                uint32_t min_keep, uint32_t max_attempts, float *rgb_out, float *r_used_out);
+
 /* ---- renderer: `traceTile` / `traceOnCanvas` / `traceRay` / `directLight`
  *      (rayphoton.js:1573-1880; ray.js:801-993 for RT_MODE_WHITTED) ----
  * Renders pixels [x0,x0+w) x [y0,y0+h) of the scene's canvas with superSampleScale 0.

@@ -24,7 +24,7 @@ EXPORTS = [
     "rt_profile_enable", "rt_profile_select", "rt_profile_reset", "rt_profile_get", "rt_scene_upload", "rt_scene_free",
     "rt_intersect_pairs", "rt_intersect", "rt_emit_photons", "rt_emit_many", "rt_photon_map_build",
     "rt_photon_map_free", "rt_photon_map_size", "rt_photon_map_nodes", "rt_kd_build", "rt_find_median",
-    "rt_kd_radius", "rt_kd_knn", "rt_gather_radiance", "rt_trace_tile",
+    "rt_kd_radius", "rt_kd_knn", "rt_gather_radiance", "rt_gather_radiance_adaptive", "rt_trace_tile",
 ]
 
 
@@ -316,6 +316,15 @@ class PhotonMap:
         d2 = out_d2 if out_d2 is not None else np.empty((nq, k), np.float64)
         self.ctx.check(self.ctx.lib.rt_kd_knn(self.h, _ptr(q), C.c_uint32(nq), C.c_uint32(k), _ptr(idx), _ptr(d2)))
         return idx, d2
+
+    def gather_adaptive(self, hits, r0, grow=3.0, min_count=10, min_keep=3, max_attempts=10):
+        h = _c(hits, np.float32) if isinstance(hits, np.ndarray) else hits
+        nq = h.shape[0]
+        rgb, r_used = np.empty((nq, 3), np.float32), np.empty(nq, np.float32)
+        self.ctx.check(self.ctx.lib.rt_gather_radiance_adaptive(self.h, _ptr(h), C.c_uint32(nq), C.c_double(r0), C.c_double(grow),
+                                                                C.c_uint32(min_count), C.c_uint32(min_keep), C.c_uint32(max_attempts),
+                                                                _ptr(rgb), _ptr(r_used)))
+        return rgb, r_used
 
     def gather(self, hits, r=0.0, k=0, out=None):
         h = _c(hits, np.float32) if isinstance(hits, np.ndarray) else hits

@@ -815,3 +815,55 @@ extern "C" int rt_gather_radiance(rt_photon_map *m, const float *hits, uint32_t 
   RT_TRY(rt_stage_out_end(ctx, rgb_out, (size_t)nq * 12, to));
   return RT_OK;
 }
+
+// ------------------------------------------------------------------ adaptive-radius gather
+// The search the reference sketches in a commented block (rayphoton.js:1766-1778, :1789-1801): start at r0 and, up to
+// `max_attempts` times, triple the radius while fewer than `min_count` photons are inside; a result with fewer than
+// `min_keep` photons is dropped.  The estimate is normalised by the area of the radius that was used (:1808, commented).
+// One lane per query; every attempt is the reference's radius walk.
+__global__ void __launch_bounds__(256) k_gather_adaptive(DevMap M, const float *hits, uint32_t nq, double r0, double grow, uint32_t min_count,
+                                                         uint32_t min_keep, uint32_t max_attempts, float *rgb, float *r_used) {
+  uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= nq) return;
+  const float *h = hits + (size_t)q * 9;
+  const double x0 = h[0], x1 = h[1], x2 = h[2];
+  const float nx = h[3], ny = h[4], nz = h[5];
+  double r = r0, r_last = r0;
+  float sr = 0, sg = 0, sb = 0; uint32_t c = 0;
+  for (uint32_t attempt = 0; attempt < max_attempts; attempt++) {
+    const double r2 = r * r;
+    sr = sg = sb = 0; c = 0; r_last = r;
+    kd_radius_walk(M, x0, x1, x2, r, [&](uint32_t slot, float4 nd) {
+      if (sq_dist(x0, x1, x2, (double)nd.x, (double)nd.y, (double)nd.z) < r2) {
+        const float *pp = M.pay + (size_t)slot * 6;
+        float w = fmaxf(0.0f, pp[0] * nx + pp[1] * ny + pp[2] * nz);
+        sr += pp[3] * w; sg += pp[4] * w; sb += pp[5] * w; c++;
+      }
+    });
+    if (c < min_count) r *= grow; else break;
+  }
+  if (c < min_keep) { sr = sg = sb = 0; }
+  const float inv_area = (float)(1.0 / (3.141592653589793 * r_last * r_last));
+  rgb[(size_t)q * 3] = sr * (h[6] / 255.0f) * inv_area;
+  rgb[(size_t)q * 3 + 1] = sg * (h[7] / 255.0f) * inv_area;
+  rgb[(size_t)q * 3 + 2] = sb * (h[8] / 255.0f) * inv_area;
+  if (r_used) r_used[q] = (float)r_last;
+}
+
+extern "C" int rt_gather_radiance_adaptive(rt_photon_map *m, const float *hits, uint32_t nq, double r0, double grow, uint32_t min_count,
+                                           uint32_t min_keep, uint32_t max_attempts, float *rgb_out, float *r_used_out) {
+  if (!m) return RT_ERR_INVALID;
+  rt_ctx *ctx = m->ctx;
+  if (!(r0 > 0) || !(grow > 1) || max_attempts == 0 || max_attempts > 64) return rt_fail(ctx, RT_ERR_INVALID, "adaptive gather: need r0 > 0, grow > 1, 1 <= max_attempts <= 64");
+  if (nq == 0) return RT_OK;
+  RT_HIP(ctx, hipSetDevice(ctx->device));
+  DevMem th, to, tr; const void *dh; void *dout, *dr;
+  RT_TRY(rt_stage_in(ctx, hits, (size_t)nq * 36, th, &dh));
+  RT_TRY(rt_stage_out_begin(ctx, rgb_out, (size_t)nq * 12, to, &dout));
+  RT_TRY(rt_stage_out_begin(ctx, r_used_out, (size_t)nq * 4, tr, &dr));
+  RT_LAUNCH(ctx, "gather_adaptive", k_gather_adaptive, div_up(nq, 256), 256, m->view(), (const float *)dh, nq, r0, grow, min_count, min_keep,
+            max_attempts, (float *)dout, (float *)dr);
+  RT_TRY(rt_stage_out_end(ctx, rgb_out, (size_t)nq * 12, to));
+  RT_TRY(rt_stage_out_end(ctx, r_used_out, (size_t)nq * 4, tr));
+  return RT_OK;
+}

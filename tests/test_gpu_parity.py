@@ -620,3 +620,38 @@ def test_preview_levels_match_reference(rt):
         nb_x, nb_y = -(-50 // b), -(-31 // b)
         assert part["post"].shape == (nb_y, nb_x, 4)
         assert (~same_px(part["post"], want[3:3 + nb_y, 5:5 + nb_x])).sum() <= 1
+
+
+def test_adaptive_radius_gather(rt):
+    """the reference's commented-out search (rayphoton.js:1766-1778): triple r until 10 photons, drop results under 3"""
+    capi, ctx = rt
+    ph, q = load_bundle("photons_c1"), load_bundle("queries_c1")
+    rec = ph["caustic"]
+    m = ctx.photon_map(rec)
+    nq = 400
+    rng = np.random.default_rng(2)
+    nrm = rng.normal(size=(nq, 3))
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    hits = np.concatenate([q["queries"][:nq], nrm, rng.uniform(0, 255, (nq, 3))], axis=1).astype(np.float32)
+    got, r_used = m.gather_adaptive(hits, 0.05)
+    pos = rec[:, :3].astype(np.float32).astype(np.float64)
+    exp, r_exp = np.zeros((nq, 3)), np.zeros(nq)
+    for i in range(nq):
+        x = hits[i, :3].astype(np.float64)
+        d2 = ((x - pos) ** 2).sum(axis=1)             # (same value as the device's sum order up to the last bit: see the margin below)
+        r = 0.05
+        for attempt in range(10):
+            inside = d2 < r * r
+            r_exp[i] = r
+            if inside.sum() < 10:
+                r *= 3
+            else:
+                break
+        if inside.sum() >= 3:
+            w = np.maximum(0.0, rec[inside, 3:6] @ hits[i, 3:6].astype(np.float64))
+            exp[i] = (rec[inside, 7:10] * rec[inside, 6:7] * w[:, None]).sum(axis=0) * hits[i, 6:9] / 255 / (np.pi * r_exp[i] ** 2)
+    assert np.allclose(r_used, r_exp, rtol=1e-6)
+    assert np.allclose(got, exp, rtol=2e-5, atol=1e-6 * max(1.0, np.abs(exp).max()))
+    assert len(np.unique(r_used)) >= 3               # several radii were in use
+    with pytest.raises(capi.RtError):
+        m.gather_adaptive(hits, 0.0)
