@@ -371,6 +371,21 @@ int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *d, rt_scene **out) {
   }
   bool has_bvh = false;
   if ((rc = rt_build_bvh(ctx, d, order, sc, has_bvh))) { delete sc; return rc; }
+  {   // bounding spheres of the sorted primitives for the primary pass's per-workgroup culling (fp32 build)
+    std::vector<float> bs((size_t)n * 4);
+    for (uint32_t s = 0; s < n; s++) {
+      const uint32_t i = order[s];
+      double lo[3], hi[3];
+      float *o4 = &bs[(size_t)s * 4];
+      if (rt_prim_box(d->shape_meta[4 * i], d->shape_meta[4 * i + 2], d->shape_geom + (size_t)i * 12, lo, hi)) {
+        double r2 = 0;
+        for (int k = 0; k < 3; k++) { o4[k] = (float)(0.5 * (lo[k] + hi[k])); r2 += 0.25 * (hi[k] - lo[k]) * (hi[k] - lo[k]); }
+        o4[3] = (float)(sqrt(r2) * 1.001 + 1e-3);
+      } else { o4[0] = o4[1] = o4[2] = 0; o4[3] = INFINITY; }
+    }
+    if ((rc = up(sc->sbound, bs.data(), bs.size() * 4))) { delete sc; return rc; }
+    sc->d32.sbound = getenv("RT355_NO_CULL") ? nullptr : sc->sbound.as<float4>();
+  }
   memcpy(sc->d32.seg, seg, sizeof seg); memcpy(sc->d64.seg, seg, sizeof seg);
   *out = sc;
   return RT_OK;

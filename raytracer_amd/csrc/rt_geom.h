@@ -42,6 +42,7 @@ template <typename T> struct DevScene {
   const uint32_t *bvh_prims;  // leaf entries: sorted slot | type << 28
   const uint32_t *unbounded;  // entries of the same form for planes and infinite cylinders: always tested
   uint32_t n_bvh_nodes, n_unbounded;
+  const float4 *sbound;       // per sorted slot: bounding sphere (centre, radius; +inf = unbounded), fp32 build only, or nullptr
 };
 
 // A miss is reported as -1 (every accepted distance is > epsilon > 0).
@@ -269,9 +270,14 @@ template <int TYPE> RT_D float isect_fast(const float *f, const float *ot, V3<fl
 template <typename T> struct ScanSrc { const T *geom; const uint32_t *orig; const uint32_t *flags; const T *ot; };
 
 // LDS bytes needed to stage n primitives
+// (fp32: + origin terms, + the list of primitives a workgroup's primary rays can reach: 9 segment bounds, n slots,
+// n flag bytes)
 template <typename T> constexpr size_t scan_lds_bytes(uint32_t n) {
-  return (size_t)n * (RT_GEOM_STRIDE * sizeof(T) + 8 + (sizeof(T) == 4 ? RT_OT_STRIDE * 4 : 0));
+  return (size_t)n * (RT_GEOM_STRIDE * sizeof(T) + 8 + (sizeof(T) == 4 ? RT_OT_STRIDE * 4 + 3 : 0)) + (sizeof(T) == 4 ? 64 : 0);
 }
+// where that list lives in a workgroup's staging area
+RT_D uint32_t *scan_lds_vseg(uint32_t n, void *lds) { return (uint32_t *)((char *)lds + (size_t)n * (RT_GEOM_STRIDE * 4 + 8 + RT_OT_STRIDE * 4)); }
+RT_D uint16_t *scan_lds_vis(uint32_t n, void *lds) { return (uint16_t *)(scan_lds_vseg(n, lds) + 16); }
 
 // Cooperative, coalesced copy of the type-sorted scene into LDS (all threads of the block must call it).
 // With `origin` (fp32 only) the origin terms of every primitive are staged behind it.
@@ -326,6 +332,26 @@ template <int MODE, bool OT> RT_D int scan_fast(const DevScene<float> &S, const 
   RT_FAST_LOOP(RT_TRIANGLE) RT_FAST_LOOP(RT_SQUARE) RT_FAST_LOOP(RT_DISC) RT_FAST_LOOP(RT_ANNULUS)
 #undef RT_FAST_LOOP
   if (MODE == 2) { t_out = 0.0f; return occluded ? 1 : 0; }
+  t_out = best;
+  return best_s >= 0 ? (int)G.orig[best_s] : -1;
+}
+
+// The same closest-hit scan over a subset: vis[vseg[t] .. vseg[t+1]) are the sorted slots of type t that the rays of
+// this workgroup can reach (see cull_primitives in rt_trace.h).  Origin terms are the staged ones.
+template <int MODE> RT_D int scan_fast_visible(const ScanSrc<float> &G, const uint16_t *vis, const uint32_t *vseg, V3<float> d, float eps, float &t_out) {
+  float best = __builtin_huge_valf(); int best_s = -1;
+#define RT_VIS_LOOP(TYPE)                                                                               \
+  RT_SCAN_UNROLL_PRAGMA                                                                                 \
+  for (uint32_t k = vseg[TYPE]; k < vseg[TYPE + 1]; k++) {                                              \
+    const uint32_t s = vis[k];                                                                          \
+    const float *f = G.geom + (size_t)s * RT_GEOM_STRIDE;                                               \
+    const int flags = (TYPE == RT_CYLINDER) ? (int)G.flags[s] : 0;                                      \
+    const float t = isect_fast<TYPE>(f, G.ot + (size_t)s * RT_OT_STRIDE, d, eps, flags);                \
+    const bool upd = t > eps && t < best; best = upd ? t : best; best_s = upd ? (int)s : best_s;        \
+  }
+  RT_VIS_LOOP(RT_PLANE) RT_VIS_LOOP(RT_SPHERE) RT_VIS_LOOP(RT_HEMISPHERE) RT_VIS_LOOP(RT_CYLINDER)
+  RT_VIS_LOOP(RT_TRIANGLE) RT_VIS_LOOP(RT_SQUARE) RT_VIS_LOOP(RT_DISC) RT_VIS_LOOP(RT_ANNULUS)
+#undef RT_VIS_LOOP
   t_out = best;
   return best_s >= 0 ? (int)G.orig[best_s] : -1;
 }

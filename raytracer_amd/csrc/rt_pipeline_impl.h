@@ -219,7 +219,9 @@ static int trace_tile_mode(rt_scene *sc, const rt_params *p, DevMap md, DevMap m
     uint64_t tests = 0;
     for (int k = 0; k < RT_CTR_SLOTS; k++) tests += hc.prim_tests[k * 16];
     // without a hierarchy every segment is tested against every primitive (shadow rays stop at the first occluder)
-    stats->prim_tests = S.bvh ? tests : stats->rays * (uint64_t)S.n_shapes;
+    // the fp32 primary pass scans only the primitives each workgroup's rays can reach and counts them
+    const bool culled = !whole_frame && lds && sizeof(T) == 4 && S.sbound != nullptr;
+    stats->prim_tests = S.bvh ? tests : (culled ? tests + (stats->rays - n_paths) * (uint64_t)S.n_shapes : stats->rays * (uint64_t)S.n_shapes);
     stats->prims_per_ray_brute_force = S.n_shapes;
   }
   return RT_OK;

@@ -65,7 +65,7 @@ struct TraceCfg {
 #define RT_CTR_SLOTS 64
 struct TraceCounters {
   unsigned long long shadow_rays, gathers, stack_overflows, tail_rays[RT_CTR_SLOTS];
-  unsigned long long prim_tests[RT_CTR_SLOTS * 16];   // ray-primitive tests counted by the hierarchy scans; slot s at [16 s]
+  unsigned long long prim_tests[RT_CTR_SLOTS * 16];   // ray-primitive tests counted by the scans that skip primitives; slot s at [16 s]
   uint32_t max_iter[RT_CTR_SLOTS];          // iterations the longest-lived workgroup of k_tail ran
   uint32_t counts[RT_MAX_WAVE_BOUNCES + 2];
 #ifdef RT_TAIL_PROBE
@@ -435,6 +435,57 @@ RT_D bool shade_step(const DevScene<T> &S, const ScanSrc<T> &G, const PathSoA<T>
   return alive;
 }
 
+// Which primitives can the primary rays of this workgroup reach?  Its paths are consecutive, so their pixels span a
+// few columns of one row (or whole rows); the rays through that rectangle lie inside a four-sided pyramid with its
+// apex at the camera, and a primitive whose bounding sphere lies outside one of the four planes cannot be hit by any
+// of them.  Wave 0 tests the primitives, 64 at a time and type by type, and compacts the survivors into vis[] / vseg[].
+// Conservative (padded spheres, the rectangle widened by a pixel), so the scan over the list finds the same hits.
+RT_D void cull_primitives(const DevScene<float> &S, const TraceCfg &C, uint16_t *vis, uint32_t *vseg) {
+  if (threadIdx.x < 64) {                                       // wave 0 does it all; the others wait at the barrier below
+    const int lane = threadIdx.x;
+    const uint32_t p0 = blockIdx.x * blockDim.x, p1 = min(p0 + blockDim.x, C.n_paths) - 1;
+    uint32_t r_, c0, c1;
+    const uint32_t ss = (uint32_t)(C.sub_sample * C.sub_sample);
+    const uint32_t pix0 = div_by(p0, ss, C.magic_ss, r_), pix1 = div_by(p1, ss, C.magic_ss, r_);
+    const uint32_t row0 = div_by(pix0, (uint32_t)C.w, C.magic_w, c0), row1 = div_by(pix1, (uint32_t)C.w, C.magic_w, c1);
+    if (row0 != row1) { c0 = 0; c1 = (uint32_t)C.w - 1; }
+    const float jit = (C.block > 1 ? (float)C.block : 0.0f) + 1.0f;        // block jitter + sub-sample jitter, in pixels
+    const float xa = (float)(C.x0 + (int)c0 * C.block) - 1.0f, xb = (float)(C.x0 + (int)c1 * C.block) + jit + 1.0f;
+    const float ya = (float)(C.y0 + (int)row0 * C.block) - 1.0f, yb = (float)(C.y0 + (int)row1 * C.block) + jit + 1.0f;
+    const float ua = (xa * 2.0f / (float)S.width - 1.0f) * S.camera[12], ub = (xb * 2.0f / (float)S.width - 1.0f) * S.camera[12];
+    const float vb = -(ya * 2.0f / (float)S.height - 1.0f) * S.camera[13], va = -(yb * 2.0f / (float)S.height - 1.0f) * S.camera[13];
+    const V3<float> o = ld3(S.camera), cu = ld3(S.camera + 3), cv = ld3(S.camera + 6), cw = ld3(S.camera + 9);
+    auto dir = [&](float u, float v) { return (u * cu + v * cv) + (-1.0f) * cw; };
+    const V3<float> d00 = dir(ua, va), d10 = dir(ub, va), d01 = dir(ua, vb), d11 = dir(ub, vb), dc = dir(0.5f * (ua + ub), 0.5f * (va + vb));
+    auto plane = [&](V3<float> a, V3<float> b) {                 // unit normal of the plane through the apex, a and b, facing the pyramid's axis
+      V3<float> nn = cross(a, b);
+      const float l = rt_sqrt(sqlen(nn));
+      const float sgn = dot(nn, dc) < 0.0f ? -1.0f : 1.0f;
+      return (l > 0.0f ? sgn / l : 0.0f) * nn;                    // (degenerate: zero normal, never culls)
+    };
+    const V3<float> nl = plane(d00, d01), nr = plane(d10, d11), nb = plane(d00, d10), nt = plane(d01, d11);
+    uint32_t total = 0;
+    for (int t = 0; t < RT_NUM_TYPES; t++) {
+      if (lane == 0) vseg[t] = total;
+      for (uint32_t base = S.seg[t]; base < S.seg[t + 1]; base += 64) {
+        const uint32_t i = base + lane;
+        bool keep = false;
+        if (i < S.seg[t + 1]) {
+          const float4 bs = S.sbound[i];
+          const V3<float> c = mk<float>(bs.x, bs.y, bs.z) - o;
+          const float R = bs.w;                                    // +inf (or NaN): never culled
+          keep = !(dot(nl, c) < -R || dot(nr, c) < -R || dot(nb, c) < -R || dot(nt, c) < -R);
+        }
+        const unsigned long long m = __ballot(keep);
+        if (keep) vis[total + (uint32_t)__popcll(m & (((unsigned long long)1 << lane) - 1))] = (uint16_t)i;
+        total += (uint32_t)__popcll(m);
+      }
+    }
+    if (lane == 0) vseg[RT_NUM_TYPES] = total;
+  }
+  __syncthreads();
+}
+
 // First pass of a frame, fused: camera ray, closest hit and shade of every path with the path state in
 // registers; only paths that go on are written to the path arrays.  Survivors are recorded as one keep-mask
 // per wave plus one count per workgroup; k_scan_blocks and k_queue_scatter then build the next queue in order.
@@ -449,16 +500,35 @@ __global__ void __launch_bounds__(256) k_primary(DevScene<T> S, PathSoA<T> P, Tr
   if (blockIdx.x == 0 && threadIdx.x == 0) *count_ptr = count;          // the queue length the later passes read
   const V3<T> cam_o = ld3(S.camera);
   const ScanSrc<T> G = LDS ? stage_scene_lds<T>(S, rt_lds, OT ? &cam_o : nullptr) : global_scan_src<T>(S);
+  // fp32: only the primitives this workgroup's rays can reach are scanned (the hierarchy, when present, does that job)
+  bool culled = false; uint16_t *vis = nullptr; uint32_t *vseg = nullptr;
+  if constexpr (OT) {
+    if (S.sbound && !S.bvh) {
+      vseg = scan_lds_vseg(S.n_shapes, rt_lds); vis = scan_lds_vis(S.n_shapes, rt_lds);
+      cull_primitives(S, C, vis, vseg);
+      culled = true;
+    }
+  }
   const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
   bool alive = false;
   ShadeTally tally;
+  PathState<T> st;
   if (p < count) {
     queue[p] = p;                                                        // identity queue for the compaction
-    PathState<T> st = raygen_path<T>(S, C, p);
-    T t;
-    const int idx = scan_scene<T, WHITTED ? 3 : 0, OT>(S, G, st.o, st.d, T(C.epsilon), T(0), t, &tally.tests);
+    st = raygen_path<T>(S, C, p);
+    T t; int idx;
+    if constexpr (OT) {
+      if (culled) idx = scan_fast_visible<WHITTED ? 3 : 0>(G, vis, vseg, st.d, (float)C.epsilon, t);
+      else idx = scan_scene<T, WHITTED ? 3 : 0, OT>(S, G, st.o, st.d, T(C.epsilon), T(0), t, &tally.tests);
+    } else {
+      idx = scan_scene<T, WHITTED ? 3 : 0, OT>(S, G, st.o, st.d, T(C.epsilon), T(0), t, &tally.tests);
+    }
     alive = shade_step<T, WHITTED, FULL>(S, G, P, C, Md, Mc, levels, p, st, t, idx, 0, tally);
-    if (alive) store_path<T>(P, p, st);
+  }
+  if (alive) store_path<T>(P, p, st);
+  if constexpr (OT) {
+    // tests executed by this workgroup's primary rays (workgroup-uniform list length): one atomic per workgroup
+    if (culled && threadIdx.x == 0) atomicAdd(&ctr->prim_tests[(blockIdx.x % RT_CTR_SLOTS) * 16], (unsigned long long)vseg[RT_NUM_TYPES] * (min(blockIdx.x * blockDim.x + blockDim.x, count) - blockIdx.x * blockDim.x));
   }
   block_publish_masks(alive, wave_mask, block_count);
   flush_tally(tally, ctr);
