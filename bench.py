@@ -135,25 +135,25 @@ def main():
     p = capi.default_params(precision=capi.PRECISION_F32, use_direct_light=0, use_photon_maps=0, seed=seed, sub_sample=1)
     frame = torch.empty((H, W, 4), dtype=torch.uint8, device=dev)          # output stays in HBM
 
-    def step():
-        return sc.trace_tile(p, out_rgba8=frame, want=())["stats"]
+    def step(stats=True):
+        return sc.trace_tile(p, out_rgba8=frame, want=(), stats=stats)["stats"]
 
     ctx.profile_enable(os.environ.get("RT355_BENCH_NO_EVENTS") is None)
     ctx.profile_select(None if os.environ.get("RT355_BENCH_ALL_EVENTS") else "primary")   # time the roofline kernel only: every event pair costs ~8 us of stream time
     for _ in range(max(args.warmup, 1)):
-        step()
+        st = step()                         # every step renders the same frame (same seed): its ray count is this one's
     ctx.profile_reset()                     # (the warm-up's timing events go back to the library's pool)
     barrier()
     t0 = time.perf_counter()
-    rays = 0
-    bounces = 0
+    # the timed frames are queued back to back on the library's stream (no statistics read back in between: that
+    # would put a host round trip after every frame) and the clock stops after the stream has drained
     for _ in range(args.steps):
-        st = step()
-        rays += st["rays"]
-        bounces += st["bounces"]
+        step(stats=False)
     ctx.synchronize()
     barrier()
     dt = time.perf_counter() - t0
+    rays = st["rays"] * args.steps
+    bounces = st["bounces"] * args.steps
     k_ms, k_launches = ctx.profile_get("primary")        # the fused first pass: the roofline kernel
     # the tail kernel's duration, for the report only: a few extra steps outside the timed region
     ctx.profile_select("tail")

@@ -194,7 +194,10 @@ int rt_gather_radiance_adaptive(rt_photon_map *map, const float *hits, uint32_t 
  *               clamping (with sub_sample == 1: the pixel's radiance), alpha NaN-able
  *   post_rgba : w*h*4 doubles, what putPixel receives (rayphoton.js:1618-1623)
  *   rgba8     : w*h*4 bytes, post_rgba as 8-bit RGBA (alpha*255)
- * any of the three may be NULL. diffuse/caustic may be NULL (no map). */
+ * any of the three may be NULL. diffuse/caustic may be NULL (no map).
+ * With `stats` the call returns when the frame is finished.  With stats == NULL and every output in device
+ * memory it only queues the frame on rt_stream(): the outputs are complete after rt_synchronize() (or any later
+ * call that synchronises), and consecutive frames run back to back without a host round trip in between. */
 int rt_trace_tile(rt_scene *scene, const rt_params *p, rt_photon_map *diffuse, rt_photon_map *caustic,
                   int x0, int y0, int w, int h, double *pre_rgba, double *post_rgba, uint8_t *rgba8,
                   rt_trace_stats *stats);

@@ -229,9 +229,11 @@ class Scene:
         return t, idx
 
     def trace_tile(self, params, diffuse=None, caustic=None, x0=0, y0=0, w=None, h=None, want=("pre", "post"),
-                   out_pre=None, out_post=None, out_rgba8=None):
+                   out_pre=None, out_post=None, out_rgba8=None, stats=True):
         """Renders a tile.  `want` selects host outputs to allocate; out_* accept caller buffers
-        (numpy arrays or device tensors), in which case nothing is allocated for that output."""
+        (numpy arrays or device tensors), in which case nothing is allocated for that output.
+        stats=False with device outputs only queues the frame on the context's stream (see rt_trace_tile):
+        call Context.synchronize() before reading the outputs."""
         w = self.flat.width if w is None else w
         h = self.flat.height if h is None else h
         b = max(1, params.super_sample_block)
@@ -243,8 +245,8 @@ class Scene:
         self.ctx.check(self.ctx.lib.rt_trace_tile(
             self.h, C.byref(params), C.c_void_p(diffuse.h.value if diffuse else None),
             C.c_void_p(caustic.h.value if caustic else None), C.c_int(x0), C.c_int(y0), C.c_int(w), C.c_int(h),
-            _ptr(pre), _ptr(post), _ptr(rgba8), C.byref(st)))
-        return dict(pre=pre, post=post, rgba8=rgba8, stats={k: getattr(st, k) for k, _ in TraceStats._fields_})
+            _ptr(pre), _ptr(post), _ptr(rgba8), C.byref(st) if stats else None))
+        return dict(pre=pre, post=post, rgba8=rgba8, stats={k: getattr(st, k) for k, _ in TraceStats._fields_} if stats else None)
 
     def emit_photons(self, params, phase, a0, a1):
         cap = max(a1 - a0, 1)

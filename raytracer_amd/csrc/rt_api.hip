@@ -454,6 +454,7 @@ int rt_trace_tile(rt_scene *sc, const rt_params *p, rt_photon_map *diffuse, rt_p
     RT_TRY(pl_trace_tile<double>(sc, p, md, mc, x0, y0, w, h, (double *)pre, (double *)post, (uint8_t *)r8, stats));
   else
     RT_TRY(pl_trace_tile<float>(sc, p, md, mc, x0, y0, w, h, (double *)pre, (double *)post, (uint8_t *)r8, stats));
+  if (!stats && !t1.p && !t2.p && !t3.p) return RT_OK;       // queued only: nothing to copy back, the caller synchronises
   RT_TRY(rt_stage_out_end(ctx, pre_rgba, npx * 32, t1));
   RT_TRY(rt_stage_out_end(ctx, post_rgba, npx * 32, t2));
   return rt_stage_out_end(ctx, rgba8, npx * 4, t3);

@@ -193,6 +193,13 @@ static int trace_tile_mode(rt_scene *sc, const rt_params *p, DevMap md, DevMap m
               (int)p->sub_sample, pre, post, rgba8);
   else if (!C.fuse_resolve)
     RT_LAUNCH(ctx, "resolve", k_resolve<T>, div_up(n_pixels, 256), 256, P, (int)n_pixels, (int)p->sub_sample, pre, post, rgba8);
+  bool readback = stats != nullptr;
+#ifdef RT_TAIL_PROBE
+  readback = true;
+#endif
+  // without `stats` nothing has to come back: the frame stays queued on the stream and the caller synchronises when
+  // it wants the pixels (frames of a sequence then run back to back, with no host round trip between them)
+  if (!readback) { RT_HIP(ctx, hipGetLastError()); return RT_OK; }
   TraceCounters hc;
   const uint32_t *hcounts = hc.counts;
   RT_HIP(ctx, hipMemcpyAsync(&hc, ctr, sizeof(hc), hipMemcpyDeviceToHost, ctx->stream));

@@ -655,3 +655,23 @@ def test_adaptive_radius_gather(rt):
     assert len(np.unique(r_used)) >= 3               # several radii were in use
     with pytest.raises(capi.RtError):
         m.gather_adaptive(hits, 0.0)
+
+
+def test_queued_frames_equal_finished_frames(rt):
+    """rt_trace_tile without statistics and with device outputs only queues the frame: several frames queued back to
+    back (different seeds, one shared workspace) must come out as the same frames rendered one at a time"""
+    import torch
+    capi, ctx = rt
+    W, H = 320, 200
+    sc = ctx.upload(load_scene(10, W, H))
+    for prec, sub in ((capi.PRECISION_F32, 1), (capi.PRECISION_F64, 2)):
+        ps = [capi.default_params(precision=prec, use_photon_maps=0, seed=s, sub_sample=sub) for s in (3, 4, 5)]
+        want = [sc.trace_tile(p, want=("post", "rgba8")) for p in ps]
+        post = [torch.full((H, W, 4), -1.0, dtype=torch.float64, device="cuda") for _ in ps]
+        rgba = [torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda") for _ in ps]
+        torch.cuda.synchronize()
+        for p, a, b in zip(ps, post, rgba):
+            assert sc.trace_tile(p, want=(), out_post=a, out_rgba8=b, stats=False)["stats"] is None
+        ctx.synchronize()
+        for w, a, b in zip(want, post, rgba):
+            assert same(a.cpu().numpy(), w["post"]) and np.array_equal(b.cpu().numpy(), w["rgba8"])
