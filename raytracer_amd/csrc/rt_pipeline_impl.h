@@ -137,6 +137,8 @@ static int trace_tile_mode(rt_scene *sc, const rt_params *p, DevMap md, DevMap m
   uint32_t *counts = ctr->counts;                           // counts[b] = queue length of pass b (device side)
   const bool lds = !S.bvh && scene_fits_lds<T>(S.n_shapes);       // hierarchy scans read the primitives they reach from global memory
   const size_t smem = lds ? scan_lds_bytes<T>(S.n_shapes) : 0;
+  // k_tail (fp32) also keeps its workgroup's path states in LDS: it stages the scene only while both fit in 64 KB
+  const bool lds_tail = lds && (sizeof(T) == 8 || smem + (size_t)(RT_LSTATE_WORDS + 3) * 4 * RT_TAIL_THREADS + 256 <= 64 * 1024);
   constexpr bool SHADE_SCANS = FULL && !WHITTED;            // only directLight's shadow rays scan primitives while shading
   // The first pass (k_primary) is fused.  Wide later bounces run as wavefront passes (intersect_closest, shade,
   // ordered compaction of the survivors); once at most tail_threshold paths are left, one k_tail launch follows
@@ -153,7 +155,7 @@ static int trace_tile_mode(rt_scene *sc, const rt_params *p, DevMap md, DevMap m
   uint32_t wave_bounces = 0;
   if (whole_frame) {
     const uint32_t tblocks = div_up(n_paths, RT_TAIL_THREADS);
-    if (lds) RT_LAUNCH_SMEM(ctx, "trace", (k_tail<T, true, WHITTED, FULL, RT_TAIL_PRIMARY>), tblocks, RT_TAIL_THREADS, smem, S, P, C, md, mc, levels, (const uint32_t *)nullptr, (const uint32_t *)nullptr, ctr, 0);
+    if (lds_tail) RT_LAUNCH_SMEM(ctx, "trace", (k_tail<T, true, WHITTED, FULL, RT_TAIL_PRIMARY>), tblocks, RT_TAIL_THREADS, smem, S, P, C, md, mc, levels, (const uint32_t *)nullptr, (const uint32_t *)nullptr, ctr, 0);
     else RT_LAUNCH_SMEM(ctx, "trace", (k_tail<T, false, WHITTED, FULL, RT_TAIL_PRIMARY>), tblocks, RT_TAIL_THREADS, 0, S, P, C, md, mc, levels, (const uint32_t *)nullptr, (const uint32_t *)nullptr, ctr, 0);
   } else
   for (;;) {
@@ -161,7 +163,7 @@ static int trace_tile_mode(rt_scene *sc, const rt_params *p, DevMap md, DevMap m
     uint32_t *cnt = counts + wave_bounces;
     if ((wave_bounces > 0 && ub <= tail_threshold) || wave_bounces >= RT_MAX_WAVE_BOUNCES) {
       const uint32_t tblocks = div_up(ub, RT_TAIL_THREADS);
-      if (lds) RT_LAUNCH_SMEM(ctx, "tail", (k_tail<T, true, WHITTED, FULL, RT_TAIL_QUEUE>), tblocks, RT_TAIL_THREADS, smem, S, P, C, md, mc, levels, q_cur, cnt, ctr, (int)wave_bounces);
+      if (lds_tail) RT_LAUNCH_SMEM(ctx, "tail", (k_tail<T, true, WHITTED, FULL, RT_TAIL_QUEUE>), tblocks, RT_TAIL_THREADS, smem, S, P, C, md, mc, levels, q_cur, cnt, ctr, (int)wave_bounces);
       else RT_LAUNCH_SMEM(ctx, "tail", (k_tail<T, false, WHITTED, FULL, RT_TAIL_QUEUE>), tblocks, RT_TAIL_THREADS, 0, S, P, C, md, mc, levels, q_cur, cnt, ctr, (int)wave_bounces);
       break;
     }

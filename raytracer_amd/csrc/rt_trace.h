@@ -47,6 +47,25 @@ template <typename T> RT_D void store_path(const PathSoA<T> &P, uint32_t p, cons
   P.draw[p] = st.draw; P.depth[p] = st.depth; P.stack[p] = st.stack;
 }
 
+// The same for a workgroup's own copy in LDS (fp32 builds): 15 words per path, field f of slot s at L[f * n + s].
+#define RT_LSTATE_WORDS 15
+RT_D PathState<float> load_path_lds(const uint32_t *L, uint32_t n, uint32_t s) {
+  PathState<float> st;
+  auto f = [&](int k) { return __uint_as_float(L[k * n + s]); };
+  st.o = mk<float>(f(0), f(1), f(2)); st.d = mk<float>(f(3), f(4), f(5));
+  st.max_dist = f(6); st.importance = f(7); st.acc = mk<float>(f(8), f(9), f(10));
+  st.draw = L[11 * n + s]; st.depth = (int32_t)L[12 * n + s];
+  st.stack = (uint64_t)L[13 * n + s] | ((uint64_t)L[14 * n + s] << 32); st.blk_idx = 0xFFFFFFFFu;
+  return st;
+}
+RT_D void store_path_lds(uint32_t *L, uint32_t n, uint32_t s, const PathState<float> &st) {
+  auto f = [&](int k, float v) { L[k * n + s] = __float_as_uint(v); };
+  f(0, st.o.x); f(1, st.o.y); f(2, st.o.z); f(3, st.d.x); f(4, st.d.y); f(5, st.d.z);
+  f(6, st.max_dist); f(7, st.importance); f(8, st.acc.x); f(9, st.acc.y); f(10, st.acc.z);
+  L[11 * n + s] = st.draw; L[12 * n + s] = (uint32_t)st.depth;
+  L[13 * n + s] = (uint32_t)st.stack; L[14 * n + s] = (uint32_t)(st.stack >> 32);
+}
+
 struct TraceCfg {
   double epsilon, max_trace_dist, diffuse_radius, caustic_radius, standard_lamp_area, shadow_bias;
   int32_t max_depth, sub_sample, use_direct_light, use_photon_maps, max_bounces;
@@ -560,8 +579,10 @@ __global__ void __launch_bounds__(256) k_shade(DevScene<T> S, PathSoA<T> P, Trac
 }
 
 // One launch that follows paths to their end.  A workgroup of RT_TAIL_THREADS lanes takes that many paths;
-// after every bounce the survivors' path indices are compacted to the front of an LDS queue (the path state
-// itself goes through the SoA arrays, so only the index moves), and waves that are left without a path retire.
+// after every bounce the survivors are compacted to the front of an LDS queue, and waves that are left without a
+// path retire.  Only a handle moves in that queue: the path index, with the state going through the SoA arrays
+// (fp64), or -- fp32 -- the slot of the workgroup's own LDS copy of the state, which a path keeps from its first
+// iteration here to its end: no global round trip per bounce, and the barriers wait for no global store.
 // The loop is bounded by max_bounces.
 //   PRIMARY = false: the tail of a wavefront frame -- the paths are those of `queue`, already under way.
 //   PRIMARY = true:  the whole frame -- the workgroup's paths are blockIdx.x * RT_TAIL_THREADS + lane and the
@@ -571,7 +592,7 @@ __global__ void __launch_bounds__(256) k_shade(DevScene<T> S, PathSoA<T> P, Trac
 // Segments traced here are counted in ctr->tail_rays[], the longest path in ctr->max_iter[] (spread over
 // RT_CTR_SLOTS addresses: same-address atomics from thousands of workgroups serialise).
 #ifndef RT_TAIL_THREADS
-#define RT_TAIL_THREADS 512
+#define RT_TAIL_THREADS 256
 #endif
 #ifndef RT_TAIL_MIN_WAVES
 #define RT_TAIL_MIN_WAVES 1
@@ -583,6 +604,9 @@ __global__ void __launch_bounds__(RT_TAIL_THREADS, RT_TAIL_MIN_WAVES) k_tail(Dev
   extern __shared__ __align__(16) unsigned char rt_lds[];
   __shared__ uint32_t live[2][RT_TAIL_THREADS];
   __shared__ uint32_t wave_cnt[RT_TAIL_THREADS / 64];
+  constexpr bool LST = sizeof(T) == 4;                      // path states in LDS
+  constexpr uint32_t N = RT_TAIL_THREADS;
+  __shared__ uint32_t lstate[LST ? (RT_LSTATE_WORDS + 1) * N : 1];      // [RT_LSTATE_WORDS][N] state words, then [N] path indices
   constexpr bool PRIMARY = SRC == RT_TAIL_PRIMARY;
   constexpr bool OT = PRIMARY && LDS && sizeof(T) == 4;
   const uint32_t count = (SRC == RT_TAIL_QUEUE) ? min(*count_ptr, C.n_paths) : C.n_paths;
@@ -593,7 +617,11 @@ __global__ void __launch_bounds__(RT_TAIL_THREADS, RT_TAIL_MIN_WAVES) k_tail(Dev
   const V3<T> cam_o = ld3(S.camera);
   const ScanSrc<T> G = LDS ? stage_scene_lds<T>(S, rt_lds, OT ? &cam_o : nullptr) : global_scan_src<T>(S);
   if (SRC == RT_TAIL_QUEUE) {
-    if (threadIdx.x < n_live) live[0][threadIdx.x] = queue[first_path + threadIdx.x];
+    if (threadIdx.x < n_live) {
+      const uint32_t q = queue[first_path + threadIdx.x];
+      if (LST) { lstate[RT_LSTATE_WORDS * N + threadIdx.x] = q; live[0][threadIdx.x] = threadIdx.x; }
+      else live[0][threadIdx.x] = q;
+    }
     __syncthreads();
   }
   if (SRC != RT_TAIL_PRIMARY && (uint32_t)(wv * 64) >= n_live) return;     // waves without a path (no barrier waits for an ended wave)
@@ -613,9 +641,15 @@ __global__ void __launch_bounds__(RT_TAIL_THREADS, RT_TAIL_MIN_WAVES) k_tail(Dev
     // waves 0 .. nw-1 are still running this iteration; the others have retired and their wave_cnt slots are stale
     const int nw = (int)((n_live + 63u) / 64u);
     const bool first = PRIMARY && b == bounce0;             // workgroup-uniform
-    bool alive = false; uint32_t p = 0;
+    const bool fresh = b == bounce0;                        // this iteration's states are where the previous kernel left them
+    bool alive = false; uint32_t p = 0, hd = 0;             // hd: the path's handle in the live queue
     if (threadIdx.x < n_live) {
-      p = first ? first_path + threadIdx.x : live[cur][threadIdx.x];
+      if (LST) {
+        hd = first ? threadIdx.x : min(live[cur][threadIdx.x], N - 1);
+        p = PRIMARY ? first_path + hd : lstate[RT_LSTATE_WORDS * N + hd];
+      } else {
+        hd = p = first ? first_path + threadIdx.x : live[cur][threadIdx.x];
+      }
       if (p < C.n_paths) {                                  // (always true; guards the indexed accesses below)
         PathState<T> st;
         T t; int idx;
@@ -623,7 +657,8 @@ __global__ void __launch_bounds__(RT_TAIL_THREADS, RT_TAIL_MIN_WAVES) k_tail(Dev
           st = raygen_path<T>(S, C, p);
           idx = scan_scene<T, WHITTED ? 3 : 0, OT>(S, G, st.o, st.d, T(C.epsilon), T(0), t, &tally.tests);
         } else {
-          st = load_path<T>(P, p);
+          if constexpr (LST) { if (fresh) st = load_path<T>(P, p); else st = load_path_lds(lstate, N, hd); }
+          else st = load_path<T>(P, p);
 #ifdef RT_TAIL_PROBE
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
@@ -632,7 +667,9 @@ __global__ void __launch_bounds__(RT_TAIL_THREADS, RT_TAIL_MIN_WAVES) k_tail(Dev
         }
         RT_PROBE(1)
         alive = shade_step<T, WHITTED, FULL>(S, G, P, C, Md, Mc, levels, p, st, t, idx, b, tally);
-        if (alive) store_path<T>(P, p, st);
+        if (alive) {
+          if constexpr (LST) store_path_lds(lstate, N, hd, st); else store_path<T>(P, p, st);
+        }
         RT_PROBE(2)
       } else {
         tally.overflows++;
@@ -645,7 +682,7 @@ __global__ void __launch_bounds__(RT_TAIL_THREADS, RT_TAIL_MIN_WAVES) k_tail(Dev
     uint32_t base = 0, total = 0;
     for (int w = 0; w < nw; w++) { uint32_t c = wave_cnt[w]; if (w < wv) base += c; total += c; }
     const uint32_t slot = base + (uint32_t)__popcll(mask & (((unsigned long long)1 << lane) - 1));
-    if (alive && slot < RT_TAIL_THREADS) live[cur ^ 1][slot] = p;
+    if (alive && slot < RT_TAIL_THREADS) live[cur ^ 1][slot] = hd;
     __syncthreads();
     cur ^= 1; n_live = min(total, (uint32_t)RT_TAIL_THREADS);
     RT_PROBE(3)

@@ -1,6 +1,6 @@
+# bench (frame leg only) for each named variant library under gpurun_variants/, then for the in-tree build
 set -e
-export RT355_BENCH_NO_EVENTS=1
-for v in 512_5 256_5 256_8; do
-  RT355_LIB=$PWD/gpurun_variants/librt355_$v.so timeout -k 10 120 python bench.py --no-cpu-baseline --no-gather > gpurun_out/exp_v$v.json
+for v in "$@"; do
+  RT355_LIB=$PWD/gpurun_variants/librt355_$v.so timeout -k 10 120 python bench.py --no-cpu-baseline --no-gather --no-other-configs > gpurun_out/exp_v$v.json
 done
-timeout -k 10 120 python bench.py --no-cpu-baseline --no-gather > gpurun_out/exp_vbase.json
+timeout -k 10 120 python bench.py --no-cpu-baseline --no-gather --no-other-configs > gpurun_out/exp_vbase.json
