@@ -281,19 +281,35 @@ RT_D uint16_t *scan_lds_vis(uint32_t n, void *lds) { return (uint16_t *)(scan_ld
 
 // Cooperative, coalesced copy of the type-sorted scene into LDS (all threads of the block must call it).
 // With `origin` (fp32 only) the origin terms of every primitive are staged behind it.
+// Every thread issues all its loads of a round (16-byte pieces of the records, four per thread, then the index and
+// flag words) before it stores any of them: a small scene costs the workgroup ONE global round trip, not one per
+// element.  The origin terms are then computed from the LDS copy.
 template <typename T> RT_D ScanSrc<T> stage_scene_lds(const DevScene<T> &S, void *lds, const V3<T> *origin = nullptr) {
   T *lg = (T *)lds;
   uint32_t *lo = (uint32_t *)(lg + (size_t)S.n_shapes * RT_GEOM_STRIDE), *lf = lo + S.n_shapes;
-  for (uint32_t i = threadIdx.x; i < S.n_shapes * RT_GEOM_STRIDE; i += blockDim.x) lg[i] = S.sgeom[i];
-  for (uint32_t i = threadIdx.x; i < S.n_shapes; i += blockDim.x) { lo[i] = S.sorig[i]; lf[i] = S.sflags32[i]; }
+  const uint32_t n = S.n_shapes, tid = threadIdx.x, nt = blockDim.x;
+  const uint32_t n16 = n * (uint32_t)(RT_GEOM_STRIDE * sizeof(T) / 16);           // the records as 16-byte pieces
+  const uint4 *src = (const uint4 *)S.sgeom;
+  uint4 *dst = (uint4 *)lg;
+  const uint32_t o0 = S.sorig[tid < n ? tid : 0], f0 = S.sflags32[tid < n ? tid : 0];     // (first round of the words: in flight with the pieces)
+  for (uint32_t base = 0; base < n16; base += 4 * nt) {
+    uint4 v[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) { const uint32_t i = base + (uint32_t)k * nt + tid; v[k] = src[i < n16 ? i : 0]; }
+#pragma unroll
+    for (int k = 0; k < 4; k++) { const uint32_t i = base + (uint32_t)k * nt + tid; if (i < n16) dst[i] = v[k]; }
+  }
+  if (tid < n) { lo[tid] = o0; lf[tid] = f0; }
+  for (uint32_t i = tid + nt; i < n; i += nt) { lo[i] = S.sorig[i]; lf[i] = S.sflags32[i]; }
   ScanSrc<T> G; G.geom = lg; G.orig = lo; G.flags = lf; G.ot = nullptr;
   if constexpr (sizeof(T) == 4) {
     if (origin) {
-      float *lt = (float *)(lf + S.n_shapes);
-      for (uint32_t i = threadIdx.x; i < S.n_shapes; i += blockDim.x) {
+      __syncthreads();
+      float *lt = (float *)(lf + n);
+      for (uint32_t i = tid; i < n; i += nt) {
         int type = 0;
         while (type < RT_NUM_TYPES - 1 && i >= S.seg[type + 1]) type++;
-        origin_terms_any(type, S.sgeom + (size_t)i * RT_GEOM_STRIDE, *origin, lt + (size_t)i * RT_OT_STRIDE);
+        origin_terms_any(type, lg + (size_t)i * RT_GEOM_STRIDE, *origin, lt + (size_t)i * RT_OT_STRIDE);
       }
       G.ot = lt;
     }

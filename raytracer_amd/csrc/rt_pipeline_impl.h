@@ -103,10 +103,13 @@ static int trace_tile_mode(rt_scene *sc, const rt_params *p, DevMap md, DevMap m
   size_t path_bytes = 0;
   carve_paths<T>(nullptr, n_paths, &path_bytes);
   RT_HIP(ctx, sc->ws_paths.reserve(path_bytes));
-  RT_HIP(ctx, sc->ws_queue.reserve(n_paths * 8));
+  // two queues of n_paths entries, or the sub-queues between the first pass and the tail kernel
+  const uint32_t subq_cap_all = div_up(div_up((uint32_t)n_paths, 256), RT_SUBQ) * 256;
+  const size_t queue_len = std::max<size_t>(n_paths, (size_t)RT_SUBQ * subq_cap_all);
+  RT_HIP(ctx, sc->ws_queue.reserve(queue_len * 8));
   RT_HIP(ctx, sc->ws_ctr.reserve(sizeof(TraceCounters)));
   PathSoA<T> P = carve_paths<T>(sc->ws_paths.p, n_paths);
-  uint32_t *q_cur = sc->ws_queue.as<uint32_t>(), *q_nxt = q_cur + n_paths;
+  uint32_t *q_cur = sc->ws_queue.as<uint32_t>(), *q_nxt = q_cur + queue_len;
   TraceCounters *ctr = sc->ws_ctr.as<TraceCounters>();
   TraceCfg C;
   C.epsilon = working_eps<T>(p); C.max_trace_dist = p->max_trace_dist; C.diffuse_radius = p->diffuse_radius;
@@ -135,7 +138,8 @@ static int trace_tile_mode(rt_scene *sc, const rt_params *p, DevMap md, DevMap m
   unsigned long long *wave_mask = sc->ws_masks.as<unsigned long long>();
   uint32_t *block_count = sc->ws_blocks.as<uint32_t>();
   uint32_t *counts = ctr->counts;                           // counts[b] = queue length of pass b (device side)
-  const bool lds = !S.bvh && scene_fits_lds<T>(S.n_shapes);       // hierarchy scans read the primitives they reach from global memory
+  bool lds = !S.bvh && scene_fits_lds<T>(S.n_shapes);       // hierarchy scans read the primitives they reach from global memory
+  if (const char *e = getenv("RT355_NO_LDS")) if (atoi(e)) lds = false;      // (experiments: wave-uniform scalar loads instead)
   const size_t smem = lds ? scan_lds_bytes<T>(S.n_shapes) : 0;
   // k_tail (fp32) also keeps its workgroup's path states in LDS: it stages the scene only while both fit in 64 KB
   const bool lds_tail = lds && (sizeof(T) == 8 || smem + (size_t)(RT_LSTATE_WORDS + 3) * 4 * RT_TAIL_THREADS + 256 <= 64 * 1024);
@@ -153,18 +157,41 @@ static int trace_tile_mode(rt_scene *sc, const rt_params *p, DevMap md, DevMap m
   if (const char *e = getenv("RT355_WHOLE_FRAME")) whole_frame = atoi(e) != 0;
   uint32_t ub = (uint32_t)n_paths;                          // upper bound of the current queue length
   uint32_t wave_bounces = 0;
+  // when the tail kernel follows the first pass directly, the survivors go to it through sub-queues (their order
+  // does not matter to it) and no scan / scatter launches are needed
+  const bool direct = !whole_frame && ub <= tail_threshold && RT_MAX_WAVE_BOUNCES >= 1;
+  C.subq_cap = direct ? subq_cap_all : 0;
+  // ... optionally (RT355_BOUNCE_PASSES=1|2) after single-bounce passes at the first pass's occupancy (k_bounce).
+  // Off by default: on the 1080p frames measured, a pass costs more (state through global memory, another append)
+  // than the iteration of k_tail it replaces.
+  uint32_t bounce_passes = 0;
+  if (const char *e = getenv("RT355_BOUNCE_PASSES")) bounce_passes = direct ? std::min<uint32_t>((uint32_t)atoi(e), RT_MAX_BOUNCE_PASSES) : 0;
+  if ((int)bounce_passes > C.max_bounces - 1) bounce_passes = (uint32_t)std::max(C.max_bounces - 1, 0);    // pass j traces segment j
+  C.iter_base = bounce_passes;
   if (whole_frame) {
     const uint32_t tblocks = div_up(n_paths, RT_TAIL_THREADS);
-    if (lds_tail) RT_LAUNCH_SMEM(ctx, "trace", (k_tail<T, true, WHITTED, FULL, RT_TAIL_PRIMARY>), tblocks, RT_TAIL_THREADS, smem, S, P, C, md, mc, levels, (const uint32_t *)nullptr, (const uint32_t *)nullptr, ctr, 0);
-    else RT_LAUNCH_SMEM(ctx, "trace", (k_tail<T, false, WHITTED, FULL, RT_TAIL_PRIMARY>), tblocks, RT_TAIL_THREADS, 0, S, P, C, md, mc, levels, (const uint32_t *)nullptr, (const uint32_t *)nullptr, ctr, 0);
+    if (lds_tail) RT_LAUNCH_SMEM(ctx, "trace", (k_tail<T, true, WHITTED, FULL, RT_TAIL_PRIMARY>), tblocks, RT_TAIL_THREADS, smem, S, P, C, md, mc, levels, (const uint32_t *)nullptr, (const uint32_t *)nullptr, 0u, 0u, ctr, 0);
+    else RT_LAUNCH_SMEM(ctx, "trace", (k_tail<T, false, WHITTED, FULL, RT_TAIL_PRIMARY>), tblocks, RT_TAIL_THREADS, 0, S, P, C, md, mc, levels, (const uint32_t *)nullptr, (const uint32_t *)nullptr, 0u, 0u, ctr, 0);
   } else
   for (;;) {
     const uint32_t blocks = div_up(ub, 256);
     uint32_t *cnt = counts + wave_bounces;
     if ((wave_bounces > 0 && ub <= tail_threshold) || wave_bounces >= RT_MAX_WAVE_BOUNCES) {
-      const uint32_t tblocks = div_up(ub, RT_TAIL_THREADS);
-      if (lds_tail) RT_LAUNCH_SMEM(ctx, "tail", (k_tail<T, true, WHITTED, FULL, RT_TAIL_QUEUE>), tblocks, RT_TAIL_THREADS, smem, S, P, C, md, mc, levels, q_cur, cnt, ctr, (int)wave_bounces);
-      else RT_LAUNCH_SMEM(ctx, "tail", (k_tail<T, false, WHITTED, FULL, RT_TAIL_QUEUE>), tblocks, RT_TAIL_THREADS, 0, S, P, C, md, mc, levels, q_cur, cnt, ctr, (int)wave_bounces);
+      // (the grid is an upper bound on the chunks: every sub-queue may end with a partly filled one)
+      const uint32_t n_subq = direct ? RT_SUBQ : 1u, cap = direct ? C.subq_cap : (uint32_t)n_paths;
+      if (direct) {
+        for (uint32_t j = 1; j <= bounce_passes; j++) {
+          const uint32_t bblocks = div_up(ub, 256) + RT_SUBQ;
+          if (lds) RT_LAUNCH_SMEM(ctx, "bounce", (k_bounce<T, true, WHITTED, FULL>), bblocks, 256, smem, S, P, C, md, mc, levels, (const uint32_t *)q_cur, (const uint32_t *)ctr->subq_count[j - 1], q_nxt, ctr->subq_count[j], ctr, (int)j);
+          else RT_LAUNCH_SMEM(ctx, "bounce", (k_bounce<T, false, WHITTED, FULL>), bblocks, 256, 0, S, P, C, md, mc, levels, (const uint32_t *)q_cur, (const uint32_t *)ctr->subq_count[j - 1], q_nxt, ctr->subq_count[j], ctr, (int)j);
+          std::swap(q_cur, q_nxt);
+          wave_bounces++;
+        }
+      }
+      const uint32_t *lens = direct ? ctr->subq_count[bounce_passes] : cnt;
+      const uint32_t tblocks = div_up(ub, RT_TAIL_THREADS) + (direct ? RT_SUBQ : 0);
+      if (lds_tail) RT_LAUNCH_SMEM(ctx, "tail", (k_tail<T, true, WHITTED, FULL, RT_TAIL_QUEUE>), tblocks, RT_TAIL_THREADS, smem, S, P, C, md, mc, levels, (const uint32_t *)q_cur, lens, n_subq, cap, ctr, (int)wave_bounces);
+      else RT_LAUNCH_SMEM(ctx, "tail", (k_tail<T, false, WHITTED, FULL, RT_TAIL_QUEUE>), tblocks, RT_TAIL_THREADS, 0, S, P, C, md, mc, levels, (const uint32_t *)q_cur, lens, n_subq, cap, ctr, (int)wave_bounces);
       break;
     }
     if (wave_bounces == 0) {
@@ -178,9 +205,10 @@ static int trace_tile_mode(rt_scene *sc, const rt_params *p, DevMap md, DevMap m
       else
         RT_LAUNCH_SMEM(ctx, "shade", (k_shade<T, false, WHITTED, FULL>), blocks, 256, 0, S, P, C, md, mc, levels, q_cur, cnt, wave_mask, block_count, ctr, (int)wave_bounces);
     }
-    RT_LAUNCH(ctx, "queue_scan", k_scan_blocks, 1, 1024, block_count, blocks, counts + wave_bounces + 1, cnt);
-    RT_LAUNCH(ctx, "queue_scatter", k_queue_scatter, blocks, 256, q_cur, cnt, wave_mask, block_count, q_nxt);
     wave_bounces++;
+    if (direct) continue;                                   // the survivors are in the sub-queues of q_cur already
+    RT_LAUNCH(ctx, "queue_scan", k_scan_blocks, 1, 1024, block_count, blocks, counts + wave_bounces, cnt);
+    RT_LAUNCH(ctx, "queue_scatter", k_queue_scatter, blocks, 256, q_cur, cnt, wave_mask, block_count, q_nxt);
     std::swap(q_cur, q_nxt);
     // the first pass of a large frame is followed blind; after that a length is worth a round trip
     if (ub > tail_threshold && wave_bounces >= 2) {
@@ -219,9 +247,9 @@ static int trace_tile_mode(rt_scene *sc, const rt_params *p, DevMap md, DevMap m
 #endif
   if (stats) {
     uint64_t rays = 0, tail = 0; uint32_t iters = 0;
-    for (uint32_t b = 0; b < wave_bounces; b++) rays += hcounts[b];
+    for (uint32_t b = 0; b < (direct ? 1u : wave_bounces); b++) rays += hcounts[b];
     for (int k = 0; k < RT_CTR_SLOTS; k++) { tail += hc.tail_rays[k]; iters = hc.max_iter[k] > iters ? hc.max_iter[k] : iters; }
-    stats->rays = rays + tail; stats->bounces = wave_bounces + iters;
+    stats->rays = rays + tail; stats->bounces = (direct ? 1u : wave_bounces) + iters;
     stats->shadow_rays = hc.shadow_rays; stats->gathers = hc.gathers;
     stats->stack_overflows = hc.stack_overflows;
     stats->tail_rays = whole_frame ? tail - n_paths : tail;       // segments after the first pass that k_tail traced

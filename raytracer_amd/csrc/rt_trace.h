@@ -77,15 +77,21 @@ struct TraceCfg {
   // with one sub-sample per pixel a finished path is the finished pixel: the shading kernels write the tile's outputs
   // themselves (any of the three may be null) and no resolve pass runs
   int32_t fuse_resolve; double *pre, *post; uint8_t *rgba8;
+  // > 0: the first pass hands its survivors to k_tail through sub-queues of this capacity (block_append_subqueue)
+  uint32_t subq_cap;
+  uint32_t iter_base;                 // bounce passes (k_bounce) that ran between the first pass and k_tail
 };
 
 #define RT_MAX_WAVE_BOUNCES 62
 // device-side bookkeeping of one rt_trace_tile call; counts[b] = queue length of wavefront pass b
 #define RT_CTR_SLOTS 64
+#define RT_MAX_BOUNCE_PASSES 2
 struct TraceCounters {
   unsigned long long shadow_rays, gathers, stack_overflows, tail_rays[RT_CTR_SLOTS];
   unsigned long long prim_tests[RT_CTR_SLOTS * 16];   // ray-primitive tests counted by the scans that skip primitives; slot s at [16 s]
   uint32_t max_iter[RT_CTR_SLOTS];          // iterations the longest-lived workgroup of k_tail ran
+  // lengths of the sub-queues the first pass ([0]) and the bounce passes after it ([1], [2]) leave (s at [16 s])
+  uint32_t subq_count[RT_MAX_BOUNCE_PASSES + 1][RT_SUBQ * 16];
   uint32_t counts[RT_MAX_WAVE_BOUNCES + 2];
 #ifdef RT_TAIL_PROBE
   unsigned long long probe[3][6];           // [first / second / later iterations][phase] cycles seen by lane 0 of each workgroup; [..][5] = iterations
@@ -457,9 +463,11 @@ RT_D bool shade_step(const DevScene<T> &S, const ScanSrc<T> &G, const PathSoA<T>
 // Which primitives can the primary rays of this workgroup reach?  Its paths are consecutive, so their pixels span a
 // few columns of one row (or whole rows); the rays through that rectangle lie inside a four-sided pyramid with its
 // apex at the camera, and a primitive whose bounding sphere lies outside one of the four planes cannot be hit by any
-// of them.  Wave 0 tests the primitives, 64 at a time and type by type, and compacts the survivors into vis[] / vseg[].
+// of them.  Wave 0 tests the primitives, 64 at a time, and compacts the survivors into vis[] / vseg[] (the slots are
+// sorted by type, so one pass in slot order keeps the types together).  first64: the bounding sphere of slot `lane`,
+// which the caller loads before it stages the scene so that the round trip is not paid here.
 // Conservative (padded spheres, the rectangle widened by a pixel), so the scan over the list finds the same hits.
-RT_D void cull_primitives(const DevScene<float> &S, const TraceCfg &C, uint16_t *vis, uint32_t *vseg) {
+RT_D void cull_primitives(const DevScene<float> &S, const TraceCfg &C, uint16_t *vis, uint32_t *vseg, float4 first64) {
   if (threadIdx.x < 64) {                                       // wave 0 does it all; the others wait at the barrier below
     const int lane = threadIdx.x;
     const uint32_t p0 = blockIdx.x * blockDim.x, p1 = min(p0 + blockDim.x, C.n_paths) - 1;
@@ -484,21 +492,29 @@ RT_D void cull_primitives(const DevScene<float> &S, const TraceCfg &C, uint16_t 
     };
     const V3<float> nl = plane(d00, d01), nr = plane(d10, d11), nb = plane(d00, d10), nt = plane(d01, d11);
     uint32_t total = 0;
-    for (int t = 0; t < RT_NUM_TYPES; t++) {
-      if (lane == 0) vseg[t] = total;
-      for (uint32_t base = S.seg[t]; base < S.seg[t + 1]; base += 64) {
-        const uint32_t i = base + lane;
-        bool keep = false;
-        if (i < S.seg[t + 1]) {
-          const float4 bs = S.sbound[i];
-          const V3<float> c = mk<float>(bs.x, bs.y, bs.z) - o;
-          const float R = bs.w;                                    // +inf (or NaN): never culled
-          keep = !(dot(nl, c) < -R || dot(nr, c) < -R || dot(nb, c) < -R || dot(nt, c) < -R);
-        }
-        const unsigned long long m = __ballot(keep);
-        if (keep) vis[total + (uint32_t)__popcll(m & (((unsigned long long)1 << lane) - 1))] = (uint16_t)i;
-        total += (uint32_t)__popcll(m);
+    uint32_t below[RT_NUM_TYPES] = {};                            // kept slots below the first slot of each type
+    for (uint32_t base = 0; base < S.n_shapes; base += 64) {
+      const uint32_t i = base + lane;
+      bool keep = false;
+      if (i < S.n_shapes) {
+        const float4 bs = base == 0 ? first64 : S.sbound[i];
+        const V3<float> c = mk<float>(bs.x, bs.y, bs.z) - o;
+        const float R = bs.w;                                      // +inf (or NaN): never culled
+        keep = !(dot(nl, c) < -R || dot(nr, c) < -R || dot(nb, c) < -R || dot(nt, c) < -R);
       }
+      const unsigned long long m = __ballot(keep);
+      if (keep) vis[total + (uint32_t)__popcll(m & (((unsigned long long)1 << lane) - 1))] = (uint16_t)i;
+      total += (uint32_t)__popcll(m);
+#pragma unroll
+      for (int t = 0; t < RT_NUM_TYPES; t++) {
+        const uint32_t e = S.seg[t];                               // lanes of this round with a slot below e
+        const unsigned long long lt = e <= base ? 0ull : (e - base >= 64 ? ~0ull : (((unsigned long long)1 << (e - base)) - 1));
+        below[t] += (uint32_t)__popcll(m & lt);
+      }
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int t = 0; t < RT_NUM_TYPES; t++) vseg[t] = below[t];
     }
     if (lane == 0) vseg[RT_NUM_TYPES] = total;
   }
@@ -518,14 +534,18 @@ __global__ void __launch_bounds__(256) k_primary(DevScene<T> S, PathSoA<T> P, Tr
   const uint32_t count = C.n_paths;
   if (blockIdx.x == 0 && threadIdx.x == 0) *count_ptr = count;          // the queue length the later passes read
   const V3<T> cam_o = ld3(S.camera);
-  const ScanSrc<T> G = LDS ? stage_scene_lds<T>(S, rt_lds, OT ? &cam_o : nullptr) : global_scan_src<T>(S);
   // fp32: only the primitives this workgroup's rays can reach are scanned (the hierarchy, when present, does that job)
   bool culled = false; uint16_t *vis = nullptr; uint32_t *vseg = nullptr;
+  float4 first64 = make_float4(0.f, 0.f, 0.f, 0.f);
   if constexpr (OT) {
-    if (S.sbound && !S.bvh) {
+    culled = S.sbound && !S.bvh;
+    if (culled && threadIdx.x < 64 && threadIdx.x < S.n_shapes) first64 = S.sbound[threadIdx.x];
+  }
+  const ScanSrc<T> G = LDS ? stage_scene_lds<T>(S, rt_lds, OT ? &cam_o : nullptr) : global_scan_src<T>(S);
+  if constexpr (OT) {
+    if (culled) {
       vseg = scan_lds_vseg(S.n_shapes, rt_lds); vis = scan_lds_vis(S.n_shapes, rt_lds);
-      cull_primitives(S, C, vis, vseg);
-      culled = true;
+      cull_primitives(S, C, vis, vseg, first64);
     }
   }
   const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -533,7 +553,7 @@ __global__ void __launch_bounds__(256) k_primary(DevScene<T> S, PathSoA<T> P, Tr
   ShadeTally tally;
   PathState<T> st;
   if (p < count) {
-    queue[p] = p;                                                        // identity queue for the compaction
+    if (!C.subq_cap) queue[p] = p;                                       // identity queue for the ordered compaction
     st = raygen_path<T>(S, C, p);
     T t; int idx;
     if constexpr (OT) {
@@ -549,7 +569,44 @@ __global__ void __launch_bounds__(256) k_primary(DevScene<T> S, PathSoA<T> P, Tr
     // tests executed by this workgroup's primary rays (workgroup-uniform list length): one atomic per workgroup
     if (culled && threadIdx.x == 0) atomicAdd(&ctr->prim_tests[(blockIdx.x % RT_CTR_SLOTS) * 16], (unsigned long long)vseg[RT_NUM_TYPES] * (min(blockIdx.x * blockDim.x + blockDim.x, count) - blockIdx.x * blockDim.x));
   }
-  block_publish_masks(alive, wave_mask, block_count);
+  if (C.subq_cap) block_append_subqueue(alive, p, queue, C.subq_cap, ctr->subq_count[0], blockIdx.x / (C.subq_cap >> 8));
+  else block_publish_masks(alive, wave_mask, block_count);
+  flush_tally(tally, ctr);
+}
+
+// One more bounce of every path in the sub-queues `qin` (lengths cin[16 s]), in the manner of the first pass: one
+// lane per path, no loop, state from and to the SoA arrays, hence few registers and many waves in flight.  The
+// survivors go to the same sub-queue of `qout` (lengths cout[16 s]).  Used for the first bounces after the first
+// pass, while most paths are still alive; k_tail takes the rest.
+template <typename T, bool LDS, bool WHITTED, bool FULL>
+__global__ void __launch_bounds__(256) k_bounce(DevScene<T> S, PathSoA<T> P, TraceCfg C, DevMap Md, DevMap Mc, T *levels,
+                                                const uint32_t *qin, const uint32_t *cin, uint32_t *qout, uint32_t *cout,
+                                                TraceCounters *ctr, int bounce) {
+  extern __shared__ __align__(16) unsigned char rt_lds[];
+  uint32_t sq, first, n;
+  const uint32_t len_raw = subq_load_len(cin, RT_SUBQ);     // (in flight while the scene is staged)
+  const ScanSrc<T> G = LDS ? stage_scene_lds<T>(S, rt_lds) : global_scan_src<T>(S);
+  if (!subq_find_chunk(len_raw, C.subq_cap, 256u, sq, first, n)) return;      // (workgroup-uniform: the grid is an upper bound)
+  bool alive = false;
+  uint32_t p = 0;
+  ShadeTally tally;
+  if (threadIdx.x < n) {
+    p = qin[first + threadIdx.x];
+    if (p >= C.n_paths) tally.overflows++;                  // (never taken; guards the indexed accesses)
+    else {
+      PathState<T> st = load_path<T>(P, p);
+      T t;
+      const int idx = scan_scene<T, WHITTED ? 3 : 0>(S, G, st.o, st.d, T(C.epsilon), T(0), t, &tally.tests);
+      alive = shade_step<T, WHITTED, FULL>(S, G, P, C, Md, Mc, levels, p, st, t, idx, bounce, tally);
+      if (alive) store_path<T>(P, p, st);
+    }
+  }
+  if (threadIdx.x == 0) {
+    const uint32_t slot = blockIdx.x % RT_CTR_SLOTS;
+    atomicAdd(&ctr->tail_rays[slot], (unsigned long long)n);
+    atomicMax(&ctr->max_iter[slot], (uint32_t)bounce);
+  }
+  block_append_subqueue(alive, p, qout, C.subq_cap, cout, sq);
   flush_tally(tally, ctr);
 }
 
@@ -584,7 +641,9 @@ __global__ void __launch_bounds__(256) k_shade(DevScene<T> S, PathSoA<T> P, Trac
 // (fp64), or -- fp32 -- the slot of the workgroup's own LDS copy of the state, which a path keeps from its first
 // iteration here to its end: no global round trip per bounce, and the barriers wait for no global store.
 // The loop is bounded by max_bounces.
-//   PRIMARY = false: the tail of a wavefront frame -- the paths are those of `queue`, already under way.
+//   PRIMARY = false: the tail of a wavefront frame -- the paths, already under way, are those of n_subq sub-queues
+//                    of capacity cap in `queue` with their lengths at counts[16 s] (n_subq = 1: one ordered queue).
+//                    The grid is an upper bound; a workgroup finds its chunk from the lengths.
 //   PRIMARY = true:  the whole frame -- the workgroup's paths are blockIdx.x * RT_TAIL_THREADS + lane and the
 //                    first iteration is the fused primary pass (camera ray in registers, staged origin terms).
 //                    Workgroups in their latency-bound late bounces share the CUs with workgroups in their
@@ -600,7 +659,8 @@ __global__ void __launch_bounds__(256) k_shade(DevScene<T> S, PathSoA<T> P, Trac
 enum { RT_TAIL_QUEUE = 0, RT_TAIL_PRIMARY = 1 };
 template <typename T, bool LDS, bool WHITTED, bool FULL, int SRC>
 __global__ void __launch_bounds__(RT_TAIL_THREADS, RT_TAIL_MIN_WAVES) k_tail(DevScene<T> S, PathSoA<T> P, TraceCfg C, DevMap Md, DevMap Mc, T *levels,
-                                                          const uint32_t *queue, const uint32_t *count_ptr, TraceCounters *ctr, int bounce0) {
+                                                          const uint32_t *queue, const uint32_t *counts, uint32_t n_subq, uint32_t cap,
+                                                          TraceCounters *ctr, int bounce0) {
   extern __shared__ __align__(16) unsigned char rt_lds[];
   __shared__ uint32_t live[2][RT_TAIL_THREADS];
   __shared__ uint32_t wave_cnt[RT_TAIL_THREADS / 64];
@@ -609,13 +669,20 @@ __global__ void __launch_bounds__(RT_TAIL_THREADS, RT_TAIL_MIN_WAVES) k_tail(Dev
   __shared__ uint32_t lstate[LST ? (RT_LSTATE_WORDS + 1) * N : 1];      // [RT_LSTATE_WORDS][N] state words, then [N] path indices
   constexpr bool PRIMARY = SRC == RT_TAIL_PRIMARY;
   constexpr bool OT = PRIMARY && LDS && sizeof(T) == 4;
-  const uint32_t count = (SRC == RT_TAIL_QUEUE) ? min(*count_ptr, C.n_paths) : C.n_paths;
-  const uint32_t first_path = blockIdx.x * RT_TAIL_THREADS;
-  if (first_path >= count) return;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  uint32_t n_live = min((uint32_t)RT_TAIL_THREADS, count - first_path);
+  uint32_t first_path = blockIdx.x * RT_TAIL_THREADS;      // PRIMARY: first path; else: first entry of this workgroup's chunk in `queue`
+  uint32_t n_live;
+  uint32_t len_raw = 0;
+  if (SRC == RT_TAIL_QUEUE) len_raw = subq_load_len(counts, n_subq);        // (in flight while the scene is staged)
+  else if (first_path >= C.n_paths) return;
   const V3<T> cam_o = ld3(S.camera);
   const ScanSrc<T> G = LDS ? stage_scene_lds<T>(S, rt_lds, OT ? &cam_o : nullptr) : global_scan_src<T>(S);
+  if (SRC == RT_TAIL_QUEUE) {
+    uint32_t sq;
+    if (!subq_find_chunk(len_raw, cap, N, sq, first_path, n_live)) return;   // (workgroup-uniform: the grid is an upper bound)
+  } else {
+    n_live = min(N, C.n_paths - first_path);
+  }
   if (SRC == RT_TAIL_QUEUE) {
     if (threadIdx.x < n_live) {
       const uint32_t q = queue[first_path + threadIdx.x];
@@ -691,7 +758,7 @@ __global__ void __launch_bounds__(RT_TAIL_THREADS, RT_TAIL_MIN_WAVES) k_tail(Dev
   if (threadIdx.x == 0) {                                   // wave 0 is the last to retire: it has seen every iteration
     const uint32_t slot = blockIdx.x % RT_CTR_SLOTS;
     if (rays) atomicAdd(&ctr->tail_rays[slot], rays);
-    atomicMax(&ctr->max_iter[slot], iters);
+    atomicMax(&ctr->max_iter[slot], iters ? iters + C.iter_base : 0u);
 #ifdef RT_TAIL_PROBE
     pr[0][5] = iters > 0; pr[1][5] = iters > 1 ? (iters > 3 ? 2 : iters - 1) : 0; pr[2][5] = iters > 3 ? iters - 3 : 0;
     for (int a = 0; a < 3; a++) for (int k = 0; k < 6; k++) if (pr[a][k]) atomicAdd(&ctr->probe[a][k], pr[a][k]);

@@ -440,6 +440,20 @@ def test_wavefront_and_whole_frame_pipelines_agree(rt, precision, monkeypatch):
             for k in ("rays", "shadow_rays", "gathers"):
                 assert wave["stats"][k] == whole["stats"][k], (k, thr)
         monkeypatch.delenv("RT355_TAIL_THRESHOLD")
+        # single-bounce passes between the first pass and the tail kernel (large frames choose them by themselves)
+        for n in ("0", "1", "2"):
+            monkeypatch.setenv("RT355_BOUNCE_PASSES", n)
+            for mb in (0, 1, 2, 3):
+                p.max_bounces = mb
+                monkeypatch.setenv("RT355_WHOLE_FRAME", "1")
+                ref = whole if mb == 0 else sc.trace_tile(p, md, mc)
+                monkeypatch.delenv("RT355_WHOLE_FRAME")
+                got = sc.trace_tile(p, md, mc)
+                assert same(got["pre"], ref["pre"]) and same(got["post"], ref["post"]), (n, mb)
+                for k in ("rays", "shadow_rays", "gathers", "bounces"):
+                    assert got["stats"][k] == ref["stats"][k], (k, n, mb)
+            p.max_bounces = 0
+        monkeypatch.delenv("RT355_BOUNCE_PASSES")
 
 
 # ------------------------------------------------------------------ wave-cooperative k-nearest gather
