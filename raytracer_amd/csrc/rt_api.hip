@@ -7,6 +7,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <limits>
 #include <vector>
 #include "rt_emit.h"
 #include "rt_pipeline.h"
@@ -285,7 +286,8 @@ static int rt_build_bvh(rt_ctx *ctx, const rt_scene_desc *d, const std::vector<u
 }
 
 template <typename T> static int upload_typed(rt_ctx *ctx, const rt_scene_desc *d, const std::vector<uint32_t> &order, DevMem &geom,
-                                              DevMem &colour, DevMem &sgeom, DevMem &surface, DevScene<T> &S, rt_scene *sc) {
+                                              DevMem &colour, DevMem &sgeom, DevMem &surface, DevMem &hit, DevScene<T> &S, rt_scene *sc,
+                                              const std::vector<uint32_t> &spec_gt) {
   const uint32_t n = d->n_shapes;
   std::vector<T> g((size_t)n * 12), c((size_t)n * 4), sg((size_t)n * 12);
   for (size_t i = 0; i < (size_t)n * 12; i++) g[i] = (T)d->shape_geom[i];
@@ -321,6 +323,27 @@ template <typename T> static int upload_typed(rt_ctx *ctx, const rt_scene_desc *
     RT_HIP(ctx, hipMemcpy(surface.p, sf.data(), sf.size() * sizeof(T), hipMemcpyHostToDevice));
     S.surface = surface.as<T>();
   }
+  // one record per shape with everything shading reads about it (see HitRec)
+  std::vector<HitRec<T>> hr(n);
+  const T nan = std::numeric_limits<T>::quiet_NaN();
+  for (uint32_t i = 0; i < n; i++) {
+    HitRec<T> &h = hr[i];
+    memset(&h, 0, sizeof h);
+    for (int k = 0; k < 12; k++) h.geom[k] = g[(size_t)i * 12 + k];
+    for (int k = 0; k < 4; k++) h.colour[k] = c[(size_t)i * 4 + k];
+    const uint8_t *m = d->shape_meta + 4 * (size_t)i;
+    const bool has_mat = m[1] < 8;
+    const int mi = m[1] & 7;
+    h.transparent = has_mat ? S.mat[0][mi] : nan; h.refr_index = has_mat ? S.mat[1][mi] : nan;
+    h.reflectance = has_mat ? S.mat[2][mi] : nan; h.specular = has_mat ? S.mat[3][mi] : nan;
+    h.refl_k = has_mat ? S.refl_k[mi] : 0u; h.spec_k = has_mat ? S.spec_k[mi] : 0u;
+    h.meta = (uint32_t)m[0] | ((uint32_t)m[1] << 8) | ((uint32_t)m[2] << 16) | ((uint32_t)m[3] << 24);
+    h.spec_gt_k = spec_gt[i];
+    h.surf_refl = d->shape_surface ? (T)d->shape_surface[2 * (size_t)i] : nan;
+  }
+  RT_HIP(ctx, hit.alloc(hr.size() * sizeof(HitRec<T>)));
+  RT_HIP(ctx, hipMemcpy(hit.p, hr.data(), hr.size() * sizeof(HitRec<T>), hipMemcpyHostToDevice));
+  S.hit = hit.as<HitRec<T>>();
   return RT_OK;
 }
 
@@ -365,8 +388,8 @@ int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *d, rt_scene **out) {
   if ((rc = up(sc->meta, d->shape_meta, (size_t)n * 4)) || (rc = up(sc->sorig, order.data(), (size_t)n * 4)) ||
       (rc = up(sc->sflags, sflags.data(), (size_t)n * 4)) ||
       (rc = up(sc->spec_gt, spec_gt.data(), (size_t)n * 4)) ||
-      (rc = upload_typed<float>(ctx, d, order, sc->geom32, sc->colour32, sc->sgeom32, sc->surface32, sc->d32, sc)) ||
-      (rc = upload_typed<double>(ctx, d, order, sc->geom64, sc->colour64, sc->sgeom64, sc->surface64, sc->d64, sc))) {
+      (rc = upload_typed<float>(ctx, d, order, sc->geom32, sc->colour32, sc->sgeom32, sc->surface32, sc->hit32, sc->d32, sc, spec_gt)) ||
+      (rc = upload_typed<double>(ctx, d, order, sc->geom64, sc->colour64, sc->sgeom64, sc->surface64, sc->hit64, sc->d64, sc, spec_gt))) {
     delete sc; return rc;
   }
   bool has_bvh = false;

@@ -17,6 +17,23 @@ struct BvhNode {
   float hi[3]; uint32_t leaf;     // 0 for interior nodes, else first entry in bvh_prims | count << 24
 };
 
+// Everything traceRay needs to know about the shape a ray hit, gathered at upload so that shading fetches it in ONE
+// batch of loads: following meta byte -> material id -> material tables costs a chain of dependent global round
+// trips per bounce, which is what a path's latency is made of once few waves are left to hide it.
+template <typename T> struct alignas(16) HitRec {
+  T geom[RT_GEOM_STRIDE];     // the shape's geometry slots (normals, procedural colours)
+  T colour[4];
+  T transparent, refr_index, reflectance, specular;      // the shape's material; NaN = undefined (all four without a material)
+  uint32_t refl_k, spec_k;    // integer thresholds of `U < reflectance`, `U < specular` (0 without a material)
+  uint32_t meta;              // type | material byte << 8 | flags << 16 | proc << 24
+  uint32_t spec_gt_k;         // ray.js: smallest 24-bit draw k with k * 2^-24 > specular
+  T surf_refl, pad_[3];       // ray.js shape model: per-shape reflectance (NaN without one)
+  RT_D int type() const { return (int)(meta & 255u); }
+  RT_D int mat_byte() const { return (int)((meta >> 8) & 255u); }
+  RT_D int flags() const { return (int)((meta >> 16) & 255u); }
+  RT_D int proc() const { return (int)(meta >> 24); }
+};
+
 // Device view of an uploaded scene.  Shapes are kept twice: in the host's order (for shading:
 // normals, colours, materials by original index) and sorted by primitive type (for the scan
 // loops: one branch-free inner loop per type, wave-uniform primitive loads).
@@ -35,6 +52,7 @@ template <typename T> struct DevScene {
   uint32_t width, height;
   T mat[4][8];                // transparent, refrIndex, reflectance, specular (NaN = undefined)
   uint32_t refl_k[8], spec_k[8];    // integer thresholds of `U < reflectance`, `U < specular`
+  const HitRec<T> *hit;       // n, original order
   const T *surface;           // n x 2 per-shape reflectance, specular (ray.js shape model) or nullptr
   const uint32_t *spec_gt_k;  // per shape: smallest 24-bit draw k with k * 2^-24 > specular
   // bounding-volume hierarchy over the bounded primitives (scenes too large for the all-primitives scan), or nullptr
@@ -478,9 +496,7 @@ template <typename T, int MODE, bool OT = false> RT_D int scan_scene(const DevSc
 }
 
 // shape.normal(p) (rayphoton.js:368-371, :385, :403, :417, :433, :449, :464, :480); not renormalised
-template <typename T> RT_D V3<T> shape_normal(const DevScene<T> &S, int i, V3<T> p) {
-  const T *g = S.geom + (size_t)i * RT_GEOM_STRIDE;
-  const int type = S.meta[4 * i], flags = S.meta[4 * i + 2];
+template <typename T> RT_D V3<T> shape_normal_g(const T *g, int type, int flags, V3<T> p) {
   const T sign = (flags & RT_FLAG_CONVEX) ? T(1) : T(-1);
   switch (type) {
     case RT_TRIANGLE: case RT_SQUARE: return ld3(g + 9);
@@ -494,13 +510,33 @@ template <typename T> RT_D V3<T> shape_normal(const DevScene<T> &S, int i, V3<T>
   }
 }
 
+template <typename T> RT_D V3<T> shape_normal(const DevScene<T> &S, int i, V3<T> p) {
+  return shape_normal_g<T>(S.geom + (size_t)i * RT_GEOM_STRIDE, S.meta[4 * i], S.meta[4 * i + 2], p);
+}
+
+// The hit record of shape i in registers: all of it is requested before any of it is used.
+template <typename T> RT_D HitRec<T> load_hit(const DevScene<T> &S, int i) {
+  HitRec<T> r;
+  const uint4 *src = (const uint4 *)(S.hit + i);
+  uint4 v[sizeof(HitRec<T>) / 16];
+#pragma unroll
+  for (int k = 0; k < (int)(sizeof(HitRec<T>) / 16); k++) v[k] = src[k];
+  __builtin_memcpy(&r, v, sizeof r);
+  return r;
+}
+// entry x (0..7, per lane) of a table of eight wave-uniform values: selects instead of an indexed load
+template <typename T> RT_D T pick8(const T *tab, int x) {
+  T v = tab[0];
+#pragma unroll
+  for (int k = 1; k < 8; k++) v = (x == k) ? tab[k] : v;
+  return v;
+}
+
 // JavaScript ToInt32 of a sum of two floors, as the checker patterns' `& 1` sees it
 template <typename T> RT_D int js_parity(T x) { return (int)((long long)x & 1LL); }
 
 // shape.colour(p): the base colour (rayphoton.js:350) or one of the presets' closures
-template <typename T> RT_D V3<T> shape_colour(const DevScene<T> &S, int i, V3<T> p) {
-  const T *c = S.colour + (size_t)i * 4;
-  const int proc = S.meta[4 * i + 3];
+template <typename T> RT_D V3<T> shape_colour_g(const T *g, const T *c, int proc, V3<T> p) {
   if (proc == RT_PROC_NONE) return mk<T>(c[0], c[1], c[2]);
   const V3<T> WHITE = mk<T>(255, 255, 255), BLACK = mk<T>(0, 0, 0);
   switch (proc) {
@@ -511,7 +547,6 @@ template <typename T> RT_D V3<T> shape_colour(const DevScene<T> &S, int i, V3<T>
       return idx == 1 ? mk<T>(128, 128, 128) : BLACK;
     }
     case RT_PROC_EIGHT_BALL: {                                            // rayphoton.js:756-768
-      const T *g = S.geom + (size_t)i * RT_GEOM_STRIDE;
       V3<T> pc = p - ld3(g); T r = g[6];
       T c1 = dot(pc, normalize<T>(mk<T>(-1, -1, 0), T(1e-6))) / r;
       if (c1 < T(0.905)) return BLACK;
@@ -536,4 +571,7 @@ template <typename T> RT_D V3<T> shape_colour(const DevScene<T> &S, int i, V3<T>
     }
   }
   return mk<T>(c[0], c[1], c[2]);
+}
+template <typename T> RT_D V3<T> shape_colour(const DevScene<T> &S, int i, V3<T> p) {
+  return shape_colour_g<T>(S.geom + (size_t)i * RT_GEOM_STRIDE, S.colour + (size_t)i * 4, S.meta[4 * i + 3], p);
 }

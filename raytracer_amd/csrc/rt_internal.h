@@ -92,7 +92,7 @@ static inline uint32_t div_up(uint64_t a, uint32_t b) { return (uint32_t)((a + b
 // ---- scene ----
 struct rt_scene {
   rt_ctx *ctx = nullptr;
-  DevMem meta, geom32, geom64, colour32, colour64, sgeom32, sgeom64, sorig, sflags, surface32, surface64, spec_gt;
+  DevMem meta, geom32, geom64, colour32, colour64, sgeom32, sgeom64, sorig, sflags, surface32, surface64, spec_gt, hit32, hit64;
   DevMem bvh_nodes, bvh_prims, bvh_unbounded, sbound;
   DevScene<float> d32; DevScene<double> d64;
   // per-scene workspaces (grow-only) so that steady-state calls do not allocate

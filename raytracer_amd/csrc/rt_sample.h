@@ -83,10 +83,11 @@ struct MatStack {
 template <typename T>
 RT_D int fresnel_bounce(const DevScene<T> &S, int mat, V3<T> d, V3<T> n, T cos1, MatStack &st, RngStream &rng,
                         V3<T> &ndir, bool &overflow) {
-  T eta1 = S.mat[1][st.top()];
+  // (the indices differ from lane to lane and the table sits in the kernel arguments: selects, not indexed loads)
+  T eta1 = pick8<T>(S.mat[1], st.top());
   T eta2;
-  if (dot(d, n) < T(0)) eta2 = S.mat[1][mat];
-  else if (st.len() >= 2) eta2 = S.mat[1][st.at(st.len() - 2)];
+  if (dot(d, n) < T(0)) eta2 = pick8<T>(S.mat[1], mat);
+  else if (st.len() >= 2) eta2 = pick8<T>(S.mat[1], st.at(st.len() - 2));
   else return 0;
   if (!(eta2 == eta2)) return 0;
   T ratio = eta1 / eta2;

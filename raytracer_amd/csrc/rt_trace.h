@@ -260,21 +260,21 @@ RT_D bool shade_body(const DevScene<T> &S, const ScanSrc<T> &G, const TraceCfg &
   const V3<T> ZERO = mk<T>(0, 0, 0);
   if (idx < 0 || idx >= (int)S.n_shapes) {
     finish_path<T>(out, st.acc, mk<T>(16, 16, 16), T(1), alpha_fixed);                 // COL_VERY_DARK_GREY :1838
-  } else if (S.meta[4 * idx + 2] & RT_FLAG_LIGHT) {                                    // :1654-1656
+  } else if (const HitRec<T> H = load_hit<T>(S, idx); H.flags() & RT_FLAG_LIGHT) {     // :1654-1656
     int l = 0;
     for (uint32_t k = 0; k < S.n_lights; k++) if ((int)S.light_shape[k] == idx) l = (int)k;
     finish_path<T>(out, st.acc, mk<T>(S.light_data[l][3], S.light_data[l][4], S.light_data[l][5]), S.light_data[l][6], alpha_fixed);
   } else {
     const V3<T> d = st.d;
     const V3<T> hit = st.o + t * d;
-    const V3<T> local = shape_colour<T>(S, idx, hit);
-    const V3<T> n = shape_normal<T>(S, idx, hit);
+    const V3<T> local = shape_colour_g<T>(H.geom, H.colour, H.proc(), hit);
+    const V3<T> n = shape_normal_g<T>(H.geom, H.type(), H.flags(), hit);
     if (t < st.max_dist || depth < C.max_depth) {                                      // :1677 (note: OR)
       const T cos1 = -dot(d, n);
-      const int mat = S.meta[4 * idx + 1] & 7;
-      const bool has_mat = S.meta[4 * idx + 1] < 8;
+      const int mat = H.mat_byte() & 7;
+      const bool has_mat = H.mat_byte() < 8;
       RngStream rng = path_rng<T>(S.width, C, p, st);
-      if (has_mat && S.mat[0][mat] == T(1)) {                                          // transparent :1679
+      if (has_mat && H.transparent == T(1)) {                                          // transparent :1679
         MatStack ms; ms.bits = st.stack;
         V3<T> ndir; bool ovf = false;
         if (!fresnel_bounce<T>(S, mat, d, n, cos1, ms, rng, ndir, ovf)) {
@@ -288,14 +288,14 @@ RT_D bool shade_body(const DevScene<T> &S, const ScanSrc<T> &G, const TraceCfg &
       } else if (cos1 < T(0)) {
         finish_path<T>(out, st.acc, ZERO, T(1), alpha_fixed);                          // inside an opaque object :1736-1747
       } else {
-        const T refl = has_mat ? S.mat[2][mat] : Limits<T>::nan();
+        const T refl = H.reflectance;                                                  // (NaN without a material)
         V3<T> direct = ZERO;
         if (FULL && refl < T(1) && C.use_direct_light) {
           const T bias = T(C.shadow_bias);
           direct = direct_light<T>(S, G, C, hit + bias * n, n, local, rng, tally.shadow_rays, &tally.tests);     // :1750-1752
         }
         bool spec = false;
-        if (rng.next_k() < (has_mat ? S.refl_k[mat] : 0u)) spec = rng.next_k() < S.spec_k[mat];   // :1753, short-circuit
+        if (rng.next_k() < H.refl_k) spec = rng.next_k() < H.spec_k;                  // :1753, short-circuit
         V3<T> acc = st.acc;
         if (FULL) {
           V3<T> diff = ZERO, caus = ZERO;
@@ -370,17 +370,18 @@ RT_D bool shade_body_a(const DevScene<T> &S, const TraceCfg &C, T *levels, uint3
   }
   const V3<T> d = st.d;
   const V3<T> hit = st.o + t * d;
-  const V3<T> sc = shape_colour<T>(S, idx, hit);
-  const V3<T> n = shape_normal<T>(S, idx, hit);
-  const T refl = S.surface ? S.surface[2 * (size_t)idx] : Limits<T>::nan();
+  const HitRec<T> H = load_hit<T>(S, idx);
+  const V3<T> sc = shape_colour_g<T>(H.geom, H.colour, H.proc(), hit);
+  const V3<T> n = shape_normal_g<T>(H.geom, H.type(), H.flags(), hit);
+  const T refl = H.surf_refl;
   T *rec = levels + ((size_t)level * C.n_paths + p) * 4;
   if (t < st.max_dist && level < C.max_depth) {                                  // ray.js:893, depth = max_depth - level
     const T cos1 = -dot(d, n);
-    const int mat = S.meta[4 * idx + 1] & 7;
-    const bool has_mat = S.meta[4 * idx + 1] < 8;
+    const int mat = H.mat_byte() & 7;
+    const bool has_mat = H.mat_byte() < 8;
     RngStream rng = path_rng<T>(S.width, C, p, st);
     V3<T> ndir;
-    if (!(has_mat && S.mat[0][mat] == T(1))) {                                   // MAT_OPAQUE ray.js:895
+    if (!(has_mat && H.transparent == T(1))) {                                   // MAT_OPAQUE ray.js:895
       if (cos1 < T(0)) {                                                         // ray.js:897-907: undefined, or black far away
         const T v = (t < T(1e5)) ? Limits<T>::nan() : T(0);
         out[0] = v; out[1] = v; out[2] = v; out[3] = v; *depth_out = level;
@@ -388,7 +389,7 @@ RT_D bool shade_body_a(const DevScene<T> &S, const TraceCfg &C, T *levels, uint3
       }
       const V3<T> rdir = d + (T(2) * cos1) * n;
       ndir = rdir;
-      if (rng.next_k() >= S.spec_gt_k[idx]) {                                    // Math.random() > specular, ray.js:910-923
+      if (rng.next_k() >= H.spec_gt_k) {                                    // Math.random() > specular, ray.js:910-923
         for (int attempt = 0; attempt < 100; attempt++) {
           ndir = vec_perturb_a<T>(rdir, eps, rng);
           if (dot(ndir, n) > eps) break;
@@ -397,8 +398,8 @@ RT_D bool shade_body_a(const DevScene<T> &S, const TraceCfg &C, T *levels, uint3
       }
     } else {                                                                     // ray.js:925-977, no Fresnel term
       MatStack ms; ms.bits = st.stack;
-      const T eta1 = ms.len() >= 1 ? S.mat[1][ms.top()] : Limits<T>::nan();
-      const T eta2 = (dot(d, n) < T(0)) ? S.mat[1][mat] : (ms.len() >= 2 ? S.mat[1][ms.at(ms.len() - 2)] : Limits<T>::nan());
+      const T eta1 = ms.len() >= 1 ? pick8<T>(S.mat[1], ms.top()) : Limits<T>::nan();
+      const T eta2 = (dot(d, n) < T(0)) ? H.refr_index : (ms.len() >= 2 ? pick8<T>(S.mat[1], ms.at(ms.len() - 2)) : Limits<T>::nan());
       const T ratio = eta1 / eta2;                                               // an undefined index flows on as NaN
       const T c2sq = T(1) - ratio * ratio * (T(1) - cos1 * cos1);
       if (c2sq < T(0)) ndir = d + (T(2) * cos1) * n;
