@@ -30,9 +30,9 @@ BYTES_PER_GATHER = 64 * 36 + 36 + 12
 
 def measured_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed PMC passes of this same command (rocprofv3 cannot run
-    inside the benchmark): profiles/r01_b_traffic.json, written by tools/profile_round.sh + the extraction in DESIGN.md."""
+    inside the benchmark): profiles/r01_c_traffic.json, written by tools/profile_round.sh + tools/make_profiles.py."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_b_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r01_c_traffic.json")) as f:
             return json.load(f)[kernel]["traffic_bytes_per_launch"]
     except (OSError, KeyError, ValueError):
         return None
@@ -264,7 +264,7 @@ def main():
                                    "primary + reflection/refraction segments only (direct light and photon gathers off)",
                        "parallelism": f"{world} independent frame(s), one per GPU", "rays_per_step": rays // args.steps,
                        "longest_path_segments": bounces // args.steps},
-            "roofline": {"kernel": "k_primary<float> (camera ray + closest-hit scan of all primitives + shade, one lane per primary ray)", "bound": "valu", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS,
+            "roofline": {"kernel": "k_primary<float> (camera ray + closest hit among the primitives its workgroup's rays can reach + shade, one lane per primary ray; algorithmic flops count the all-primitives scan the reference does)", "bound": "valu", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_VALU_TFLOPS, "traffic": measured_traffic("k_primary"),
                          "algorithmic_flop_per_ray_pass": fl, "avg_launch_ms": k_ms / max(1, k_launches),
                          "launches_per_step": k_launches / args.steps, "kernel_ms_per_step": k_ms / args.steps,
