@@ -133,35 +133,42 @@ def main():
     sc = ctx.upload(flat)
     seed = 1 + rank
     p = capi.default_params(precision=capi.PRECISION_F32, use_direct_light=0, use_photon_maps=0, seed=seed, sub_sample=1)
-    frame = torch.empty((H, W, 4), dtype=torch.uint8, device=dev)          # output stays in HBM
+    frames_out = [torch.empty((H, W, 4), dtype=torch.uint8, device=dev) for _ in range(2)]   # outputs stay in HBM
+    frame = frames_out[0]
 
-    def step(stats=True):
-        return sc.trace_tile(p, out_rgba8=frame, want=(), stats=stats)["stats"]
+    def step(stats=True, i=0):
+        return sc.trace_tile(p, out_rgba8=frames_out[i & 1], want=(), stats=stats)["stats"]
 
     ctx.profile_enable(os.environ.get("RT355_BENCH_NO_EVENTS") is None)
     ctx.profile_select(None if os.environ.get("RT355_BENCH_ALL_EVENTS") else "primary")   # time the roofline kernel only: every event pair costs ~8 us of stream time
     for _ in range(max(args.warmup, 1)):
         st = step()                         # every step renders the same frame (same seed): its ray count is this one's
     ctx.profile_reset()                     # (the warm-up's timing events go back to the library's pool)
+    # the timed frames are only queued (no statistics read back in between: that would put a host round trip after
+    # every frame) and the clock stops after the library's streams have drained
+    # Two frames in flight: consecutive frames go to alternate streams, workspaces and output buffers, so the thinly
+    # occupied end of one frame's path tracing overlaps the start of the next.
+    ctx.set_frames_in_flight(1 if os.environ.get("RT355_BENCH_SERIAL_FRAMES") else 2)
     barrier()
     t0 = time.perf_counter()
-    # the timed frames are queued back to back on the library's stream (no statistics read back in between: that
-    # would put a host round trip after every frame) and the clock stops after the stream has drained
-    for _ in range(args.steps):
-        step(stats=False)
+    for i in range(args.steps):
+        step(stats=False, i=i)
     ctx.synchronize()
     barrier()
     dt = time.perf_counter() - t0
+    ctx.set_frames_in_flight(1)
     rays = st["rays"] * args.steps
     bounces = st["bounces"] * args.steps
     k_ms, k_launches = ctx.profile_get("primary")        # the fused first pass: the roofline kernel
-    # the tail kernel's duration, for the report only: a few extra steps outside the timed region
-    ctx.profile_select("tail")
+    # for the report only, a few extra steps outside the timed region, one frame at a time: the tail kernel's duration,
+    # and the first pass's when it has the chip to itself (in the timed region it shares it with the previous frame's tail)
+    ctx.profile_select("primary,tail")
     ctx.profile_reset()
     for _ in range(3):
         step()
     tail_ms, tail_launches = ctx.profile_get("tail")
     tail_ms = tail_ms / max(1, tail_launches) * args.steps
+    kx_ms, kx_launches = ctx.profile_get("primary")
     ctx.profile_enable(False)
 
     tot = torch.tensor([float(rays), dt], dtype=torch.float64, device=cdev)
@@ -269,7 +276,12 @@ def main():
                          "algorithmic_flop_per_ray_pass": fl, "avg_launch_ms": k_ms / max(1, k_launches),
                          "launches_per_step": k_launches / args.steps, "kernel_ms_per_step": k_ms / args.steps,
                          "rays_per_launch": W * H, "tail_kernel_ms_per_step": tail_ms / args.steps,
-                         "tail_rays_per_step": (rays - W * H * args.steps) // args.steps},
+                         "tail_rays_per_step": (rays - W * H * args.steps) // args.steps,
+                         "note": "the timed frames overlap in pairs (two frames in flight), so this kernel's launches share the chip "
+                                 "with the previous frame's tail kernel; `exclusive` is the same kernel over frames run one at a time",
+                         "exclusive": {"avg_launch_ms": kx_ms / max(1, kx_launches),
+                                       "achieved": (W * H) * fl / ((max(kx_ms, 1e-9) / max(1, kx_launches)) * 1e-3) / 1e12,
+                                       "frac": (W * H) * fl / ((max(kx_ms, 1e-9) / max(1, kx_launches)) * 1e-3) / 1e12 / PEAK_FP32_VALU_TFLOPS}},
         }
         if roof_gather:
             line["roofline_gather"] = roof_gather

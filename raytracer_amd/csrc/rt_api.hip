@@ -73,12 +73,14 @@ int rt_init(const int *device_ids, int n, rt_ctx **out) {
   if (dev < 0 || dev >= count) return rt_fail(nullptr, RT_ERR_NO_DEVICE, "device %d out of range (%d visible)", dev, count);
   rt_ctx *ctx = new rt_ctx();
   ctx->device = dev;
-  if (hipSetDevice(dev) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
+  if (hipSetDevice(dev) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream_main, hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithFlags(&ctx->stream_alt, hipStreamNonBlocking) != hipSuccess ||
       hipHostMalloc((void **)&ctx->pinned, 256, hipHostMallocDefault) != hipSuccess) {
     rt_fail(nullptr, RT_ERR_HIP, "context creation failed: %s", hipGetErrorString(hipGetLastError()));
     delete ctx;
     return RT_ERR_HIP;
   }
+  ctx->stream = ctx->stream_main;
   *out = ctx;
   return RT_OK;
 }
@@ -86,19 +88,30 @@ int rt_init(const int *device_ids, int n, rt_ctx **out) {
 void rt_shutdown(rt_ctx *ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
-  (void)hipStreamSynchronize(ctx->stream);
+  (void)hipStreamSynchronize(ctx->stream_main);
+  (void)hipStreamSynchronize(ctx->stream_alt);
   for (auto &kv : ctx->events) for (auto &ev : kv.second) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
   for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
-  (void)hipStreamDestroy(ctx->stream);
+  (void)hipStreamDestroy(ctx->stream_main);
+  (void)hipStreamDestroy(ctx->stream_alt);
   delete ctx;
 }
 
 const char *rt_last_error(rt_ctx *ctx) { return ctx ? ctx->err.c_str() : g_init_error.c_str(); }
-void *rt_stream(rt_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+void *rt_stream(rt_ctx *ctx) { return ctx ? (void *)ctx->stream_main : nullptr; }
 int rt_synchronize(rt_ctx *ctx) {
   if (!ctx) return RT_ERR_INVALID;
-  RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  RT_HIP(ctx, hipStreamSynchronize(ctx->stream_main));
+  if (ctx->alt_used) { RT_HIP(ctx, hipStreamSynchronize(ctx->stream_alt)); ctx->alt_used = false; }
+  return RT_OK;
+}
+
+int rt_set_frames_in_flight(rt_ctx *ctx, int n) {
+  if (!ctx) return RT_ERR_INVALID;
+  if (n != 1 && n != 2) return rt_fail(ctx, RT_ERR_INVALID, "frames in flight must be 1 or 2");
+  RT_TRY(rt_synchronize(ctx));
+  ctx->frames_in_flight = n;
   return RT_OK;
 }
 
@@ -110,14 +123,14 @@ int rt_profile_select(rt_ctx *ctx, const char *kernels) {
 }
 int rt_profile_reset(rt_ctx *ctx) {
   if (!ctx) return RT_ERR_INVALID;
-  RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  RT_TRY(rt_synchronize(ctx));
   for (auto &kv : ctx->events) for (auto &ev : kv.second) { ctx->event_pool.push_back(ev.first); ctx->event_pool.push_back(ev.second); }
   ctx->events.clear();
   return RT_OK;
 }
 int rt_profile_get(rt_ctx *ctx, const char *kernel, double *total_ms, uint64_t *launches) {
   if (!ctx || !kernel) return RT_ERR_INVALID;
-  RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  RT_TRY(rt_synchronize(ctx));
   double tot = 0; uint64_t n = 0;
   auto it = ctx->events.find(kernel);
   if (it != ctx->events.end())
@@ -473,11 +486,20 @@ int rt_trace_tile(rt_scene *sc, const rt_params *p, rt_photon_map *diffuse, rt_p
   DevMap md, mc; memset(&md, 0, sizeof md); memset(&mc, 0, sizeof mc);
   if (diffuse) md = diffuse->view();
   if (caustic) mc = caustic->view();
-  if (p->precision == RT_PRECISION_F64)
-    RT_TRY(pl_trace_tile<double>(sc, p, md, mc, x0, y0, w, h, (double *)pre, (double *)post, (uint8_t *)r8, stats));
-  else
-    RT_TRY(pl_trace_tile<float>(sc, p, md, mc, x0, y0, w, h, (double *)pre, (double *)post, (uint8_t *)r8, stats));
-  if (!stats && !t1.p && !t2.p && !t3.p) return RT_OK;       // queued only: nothing to copy back, the caller synchronises
+  // A frame that is only queued (no statistics, outputs in device memory) may overlap the one queued before it:
+  // with two frames in flight consecutive ones alternate between two streams and two sets of workspaces.  Every
+  // other call first waits for what the second stream still holds.
+  const bool queued = !stats && !t1.p && !t2.p && !t3.p;
+  int slot = 0;
+  if (queued && ctx->frames_in_flight == 2) { slot = sc->next_slot; sc->next_slot ^= 1; }
+  else if (ctx->alt_used) { RT_HIP(ctx, hipStreamSynchronize(ctx->stream_alt)); ctx->alt_used = false; }
+  if (slot) { ctx->stream = ctx->stream_alt; ctx->alt_used = true; }
+  const int rc = p->precision == RT_PRECISION_F64
+      ? pl_trace_tile<double>(sc, slot, p, md, mc, x0, y0, w, h, (double *)pre, (double *)post, (uint8_t *)r8, stats)
+      : pl_trace_tile<float>(sc, slot, p, md, mc, x0, y0, w, h, (double *)pre, (double *)post, (uint8_t *)r8, stats);
+  ctx->stream = ctx->stream_main;
+  if (rc != RT_OK) return rc;
+  if (queued) return RT_OK;                                  // nothing to copy back, the caller synchronises
   RT_TRY(rt_stage_out_end(ctx, pre_rgba, npx * 32, t1));
   RT_TRY(rt_stage_out_end(ctx, post_rgba, npx * 32, t2));
   return rt_stage_out_end(ctx, rgba8, npx * 4, t3);

@@ -15,7 +15,10 @@
 
 struct rt_ctx {
   int device = 0;
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr;          // the stream launches go to: stream_main, except while a queued frame is put on stream_alt
+  hipStream_t stream_main = nullptr, stream_alt = nullptr;
+  int frames_in_flight = 1;              // 2: consecutive queued frames alternate between the two streams (rt_set_frames_in_flight)
+  bool alt_used = false;                 // something was queued on stream_alt since it was last synchronised
   std::string err;
   bool profiling = false;
   std::string profile_only;      // when non-empty: ",name1,name2," -- only launches under these names are timed
@@ -96,7 +99,10 @@ struct rt_scene {
   DevMem bvh_nodes, bvh_prims, bvh_unbounded, sbound;
   DevScene<float> d32; DevScene<double> d64;
   // per-scene workspaces (grow-only) so that steady-state calls do not allocate
-  DevMem ws_paths, ws_queue, ws_ctr, ws_masks, ws_blocks, ws_levels, ws_emit_kind, ws_emit_rec, ws_emit_blocks, ws_misc;
+  // rt_trace_tile's workspaces, one set per frame in flight
+  struct TraceWs { DevMem paths, queue, ctr, masks, blocks, levels; } tws[2];
+  int next_slot = 0;
+  DevMem ws_emit_kind, ws_emit_rec, ws_emit_blocks, ws_misc;
 };
 
 // ---- photon map ----

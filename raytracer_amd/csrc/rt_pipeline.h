@@ -8,7 +8,7 @@ template <typename T> int pl_intersect_pairs(rt_ctx *ctx, const rt_params *p, ui
                                              int normalize_dir, const uint8_t *meta, const double *geom, double *t_out);
 template <typename T> int pl_intersect_scene(rt_scene *sc, const rt_params *p, int mode, uint32_t n, const double *o,
                                              const double *d, const double *source_dist, double *t_out, int32_t *idx_out);
-template <typename T> int pl_trace_tile(rt_scene *sc, const rt_params *p, DevMap md, DevMap mc, int x0, int y0, int w, int h,
+template <typename T> int pl_trace_tile(rt_scene *sc, int slot, const rt_params *p, DevMap md, DevMap mc, int x0, int y0, int w, int h,
                                         double *pre, double *post, uint8_t *rgba8, rt_trace_stats *stats);
 // runs attempts [a0, a0+count) of one phase into the scene's emission workspace
 template <typename T> int pl_emit_batch(rt_scene *sc, const rt_params *p, int phase, uint64_t a0, uint32_t count);

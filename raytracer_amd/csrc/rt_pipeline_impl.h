@@ -90,9 +90,10 @@ template <typename T> static PathSoA<T> carve_paths(void *base, size_t n, size_t
 // WHITTED: the older tracer (ray.js).  FULL: direct light and/or photon gathers are on (otherwise kernels with those
 // terms compiled out run: fewer registers, more waves in flight).
 template <typename T, bool WHITTED, bool FULL>
-static int trace_tile_mode(rt_scene *sc, const rt_params *p, DevMap md, DevMap mc, int x0, int y0, int w, int h,
+static int trace_tile_mode(rt_scene *sc, int slot, const rt_params *p, DevMap md, DevMap mc, int x0, int y0, int w, int h,
                            double *pre, double *post, uint8_t *rgba8, rt_trace_stats *stats) {
   rt_ctx *ctx = sc->ctx;
+  rt_scene::TraceWs &W = sc->tws[slot & 1];
   DevScene<T> &S = SceneOf<T>::get(sc);
   const int blk = p->super_sample_block > 1 ? p->super_sample_block : 1;       // one traced sample per blk x blk pixels
   const int wb = (w + blk - 1) / blk, hb = (h + blk - 1) / blk;
@@ -102,15 +103,15 @@ static int trace_tile_mode(rt_scene *sc, const rt_params *p, DevMap md, DevMap m
   if (n_paths > 0x7FFFFFFFull) return rt_fail(ctx, RT_ERR_TOO_LARGE, "tile has too many paths (%zu)", n_paths);
   size_t path_bytes = 0;
   carve_paths<T>(nullptr, n_paths, &path_bytes);
-  RT_HIP(ctx, sc->ws_paths.reserve(path_bytes));
+  RT_HIP(ctx, W.paths.reserve(path_bytes));
   // two queues of n_paths entries, or the sub-queues between the first pass and the tail kernel
   const uint32_t subq_cap_all = div_up(div_up((uint32_t)n_paths, 256), RT_SUBQ) * 256;
   const size_t queue_len = std::max<size_t>(n_paths, (size_t)RT_SUBQ * subq_cap_all);
-  RT_HIP(ctx, sc->ws_queue.reserve(queue_len * 8));
-  RT_HIP(ctx, sc->ws_ctr.reserve(sizeof(TraceCounters)));
-  PathSoA<T> P = carve_paths<T>(sc->ws_paths.p, n_paths);
-  uint32_t *q_cur = sc->ws_queue.as<uint32_t>(), *q_nxt = q_cur + queue_len;
-  TraceCounters *ctr = sc->ws_ctr.as<TraceCounters>();
+  RT_HIP(ctx, W.queue.reserve(queue_len * 8));
+  RT_HIP(ctx, W.ctr.reserve(sizeof(TraceCounters)));
+  PathSoA<T> P = carve_paths<T>(W.paths.p, n_paths);
+  uint32_t *q_cur = W.queue.as<uint32_t>(), *q_nxt = q_cur + queue_len;
+  TraceCounters *ctr = W.ctr.as<TraceCounters>();
   TraceCfg C;
   C.epsilon = working_eps<T>(p); C.max_trace_dist = p->max_trace_dist; C.diffuse_radius = p->diffuse_radius;
   C.caustic_radius = p->caustic_radius; C.standard_lamp_area = p->standard_lamp_area;
@@ -125,18 +126,18 @@ static int trace_tile_mode(rt_scene *sc, const rt_params *p, DevMap md, DevMap m
   T *levels = nullptr;
   if (WHITTED) {      // one record of 4 values per path and recursion level (levels 0 .. max_depth)
     if (p->max_depth < 0 || p->max_depth > 255) return rt_fail(ctx, RT_ERR_INVALID, "max_depth %d outside [0, 255]", p->max_depth);
-    RT_HIP(ctx, sc->ws_levels.reserve((size_t)(p->max_depth + 1) * n_paths * 4 * sizeof(T)));
-    levels = sc->ws_levels.as<T>();
+    RT_HIP(ctx, W.levels.reserve((size_t)(p->max_depth + 1) * n_paths * 4 * sizeof(T)));
+    levels = W.levels.as<T>();
     C.max_bounces = p->max_depth + 2;                       // every path ends within max_depth + 1 levels
     md.n = 0; mc.n = 0;
   }
 
   RT_HIP(ctx, hipMemsetAsync(ctr, 0, sizeof(TraceCounters), ctx->stream));
   const uint32_t max_blocks = div_up(n_paths, 256);
-  RT_HIP(ctx, sc->ws_masks.reserve((size_t)max_blocks * 4 * 8));
-  RT_HIP(ctx, sc->ws_blocks.reserve(((size_t)max_blocks + 1) * 4));
-  unsigned long long *wave_mask = sc->ws_masks.as<unsigned long long>();
-  uint32_t *block_count = sc->ws_blocks.as<uint32_t>();
+  RT_HIP(ctx, W.masks.reserve((size_t)max_blocks * 4 * 8));
+  RT_HIP(ctx, W.blocks.reserve(((size_t)max_blocks + 1) * 4));
+  unsigned long long *wave_mask = W.masks.as<unsigned long long>();
+  uint32_t *block_count = W.blocks.as<uint32_t>();
   uint32_t *counts = ctr->counts;                           // counts[b] = queue length of pass b (device side)
   bool lds = !S.bvh && scene_fits_lds<T>(S.n_shapes);       // hierarchy scans read the primitives they reach from global memory
   if (const char *e = getenv("RT355_NO_LDS")) if (atoi(e)) lds = false;      // (experiments: wave-uniform scalar loads instead)
@@ -265,16 +266,16 @@ static int trace_tile_mode(rt_scene *sc, const rt_params *p, DevMap md, DevMap m
 }
 
 template <typename T>
-int pl_trace_tile(rt_scene *sc, const rt_params *p, DevMap md, DevMap mc, int x0, int y0, int w, int h,
+int pl_trace_tile(rt_scene *sc, int slot, const rt_params *p, DevMap md, DevMap mc, int x0, int y0, int w, int h,
                   double *pre, double *post, uint8_t *rgba8, rt_trace_stats *stats) {
   if (p->mode == RT_MODE_WHITTED) {
     if (!SceneOf<T>::get(sc).surface)
       return rt_fail(sc->ctx, RT_ERR_INVALID, "RT_MODE_WHITTED needs rt_scene_desc.shape_surface (per-shape reflectance, specular)");
-    return trace_tile_mode<T, true, false>(sc, p, md, mc, x0, y0, w, h, pre, post, rgba8, stats);
+    return trace_tile_mode<T, true, false>(sc, slot, p, md, mc, x0, y0, w, h, pre, post, rgba8, stats);
   }
   const bool full = p->use_direct_light || (p->use_photon_maps && (md.n || mc.n));
-  if (full) return trace_tile_mode<T, false, true>(sc, p, md, mc, x0, y0, w, h, pre, post, rgba8, stats);
-  return trace_tile_mode<T, false, false>(sc, p, md, mc, x0, y0, w, h, pre, post, rgba8, stats);
+  if (full) return trace_tile_mode<T, false, true>(sc, slot, p, md, mc, x0, y0, w, h, pre, post, rgba8, stats);
+  return trace_tile_mode<T, false, false>(sc, slot, p, md, mc, x0, y0, w, h, pre, post, rgba8, stats);
 }
 
 // ------------------------------------------------------------------ emission
@@ -320,7 +321,7 @@ int pl_emit_compact(rt_scene *sc, uint32_t count, int want, uint64_t a0, uint32_
                                      const uint8_t *, const double *, double *);                                       \
   template int pl_intersect_scene<T>(rt_scene *, const rt_params *, int, uint32_t, const double *, const double *,     \
                                      const double *, double *, int32_t *);                                             \
-  template int pl_trace_tile<T>(rt_scene *, const rt_params *, DevMap, DevMap, int, int, int, int, double *, double *, \
+  template int pl_trace_tile<T>(rt_scene *, int, const rt_params *, DevMap, DevMap, int, int, int, int, double *, double *, \
                                 uint8_t *, rt_trace_stats *);                                                          \
   template int pl_emit_batch<T>(rt_scene *, const rt_params *, int, uint64_t, uint32_t);                               \
   template int pl_emit_compact<T>(rt_scene *, uint32_t, int, uint64_t, uint32_t, uint32_t, double *, int64_t *,        \
