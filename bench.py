@@ -133,11 +133,12 @@ def main():
     sc = ctx.upload(flat)
     seed = 1 + rank
     p = capi.default_params(precision=capi.PRECISION_F32, use_direct_light=0, use_photon_maps=0, seed=seed, sub_sample=1)
-    frames_out = [torch.empty((H, W, 4), dtype=torch.uint8, device=dev) for _ in range(2)]   # outputs stay in HBM
+    in_flight = 1 if os.environ.get("RT355_BENCH_SERIAL_FRAMES") else int(os.environ.get("RT355_BENCH_IN_FLIGHT", "2"))
+    frames_out = [torch.empty((H, W, 4), dtype=torch.uint8, device=dev) for _ in range(in_flight)]   # outputs stay in HBM
     frame = frames_out[0]
 
     def step(stats=True, i=0):
-        return sc.trace_tile(p, out_rgba8=frames_out[i & 1], want=(), stats=stats)["stats"]
+        return sc.trace_tile(p, out_rgba8=frames_out[i % in_flight], want=(), stats=stats)["stats"]
 
     ctx.profile_enable(os.environ.get("RT355_BENCH_NO_EVENTS") is None)
     ctx.profile_select(None if os.environ.get("RT355_BENCH_ALL_EVENTS") else "primary")   # time the roofline kernel only: every event pair costs ~8 us of stream time
@@ -148,7 +149,7 @@ def main():
     # every frame) and the clock stops after the library's streams have drained
     # Two frames in flight: consecutive frames go to alternate streams, workspaces and output buffers, so the thinly
     # occupied end of one frame's path tracing overlaps the start of the next.
-    ctx.set_frames_in_flight(1 if os.environ.get("RT355_BENCH_SERIAL_FRAMES") else 2)
+    ctx.set_frames_in_flight(in_flight)
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -269,7 +270,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"reference default scene (preset 10, {flat.n_shapes} primitives) at {W}x{H}, 1 spp, "
                                    "primary + reflection/refraction segments only (direct light and photon gathers off)",
-                       "parallelism": f"{world} independent frame(s), one per GPU", "rays_per_step": rays // args.steps,
+                       "parallelism": f"{world} independent frame(s), one per GPU", "frames_in_flight_per_gpu": in_flight, "rays_per_step": rays // args.steps,
                        "longest_path_segments": bounces // args.steps},
             "roofline": {"kernel": "k_primary<float> (camera ray + closest hit among the primitives its workgroup's rays can reach + shade, one lane per primary ray; algorithmic flops count the all-primitives scan the reference does)", "bound": "valu", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_VALU_TFLOPS, "traffic": measured_traffic("k_primary"),

@@ -116,9 +116,9 @@ void rt_shutdown(rt_ctx *ctx);
 const char *rt_last_error(rt_ctx *ctx);     /* ctx may be NULL: last rt_init failure */
 void *rt_stream(rt_ctx *ctx);               /* the hipStream_t all work is launched on */
 int rt_synchronize(rt_ctx *ctx);            /* waits for everything the context has queued */
-/* n = 2: consecutive frames that rt_trace_tile only queues (see there) may overlap -- the long, thinly occupied
- * end of one frame's path tracing runs beside the start of the next; they must not share output buffers.
- * n = 1 (default): queued frames run one after the other.  No counterpart in the reference (its frames are
+/* n = 2..4: up to n consecutive frames that rt_trace_tile only queues (see there) may overlap -- the long, thinly
+ * occupied end of one frame's path tracing runs beside the start of the next; frames in flight together must not
+ * share output buffers.  n = 1 (default): queued frames run one after the other.  No counterpart in the reference (its frames are
  * serial by construction). */
 int rt_set_frames_in_flight(rt_ctx *ctx, int n);
 /* Per-kernel HIP-event timing (off by default).  rt_profile_get sums the launches of one

@@ -73,14 +73,15 @@ int rt_init(const int *device_ids, int n, rt_ctx **out) {
   if (dev < 0 || dev >= count) return rt_fail(nullptr, RT_ERR_NO_DEVICE, "device %d out of range (%d visible)", dev, count);
   rt_ctx *ctx = new rt_ctx();
   ctx->device = dev;
-  if (hipSetDevice(dev) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream_main, hipStreamNonBlocking) != hipSuccess ||
-      hipStreamCreateWithFlags(&ctx->stream_alt, hipStreamNonBlocking) != hipSuccess ||
+  bool streams_ok = hipSetDevice(dev) == hipSuccess;
+  for (int i = 0; i < RT_MAX_IN_FLIGHT && streams_ok; i++) streams_ok = hipStreamCreateWithFlags(&ctx->streams[i], hipStreamNonBlocking) == hipSuccess;
+  if (!streams_ok ||
       hipHostMalloc((void **)&ctx->pinned, 256, hipHostMallocDefault) != hipSuccess) {
     rt_fail(nullptr, RT_ERR_HIP, "context creation failed: %s", hipGetErrorString(hipGetLastError()));
     delete ctx;
     return RT_ERR_HIP;
   }
-  ctx->stream = ctx->stream_main;
+  ctx->stream = ctx->streams[0];
   *out = ctx;
   return RT_OK;
 }
@@ -88,28 +89,32 @@ int rt_init(const int *device_ids, int n, rt_ctx **out) {
 void rt_shutdown(rt_ctx *ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
-  (void)hipStreamSynchronize(ctx->stream_main);
-  (void)hipStreamSynchronize(ctx->stream_alt);
+  for (int i = 0; i < RT_MAX_IN_FLIGHT; i++) if (ctx->streams[i]) (void)hipStreamSynchronize(ctx->streams[i]);
   for (auto &kv : ctx->events) for (auto &ev : kv.second) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
   for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
-  (void)hipStreamDestroy(ctx->stream_main);
-  (void)hipStreamDestroy(ctx->stream_alt);
+  for (int i = 0; i < RT_MAX_IN_FLIGHT; i++) if (ctx->streams[i]) (void)hipStreamDestroy(ctx->streams[i]);
   delete ctx;
 }
 
 const char *rt_last_error(rt_ctx *ctx) { return ctx ? ctx->err.c_str() : g_init_error.c_str(); }
-void *rt_stream(rt_ctx *ctx) { return ctx ? (void *)ctx->stream_main : nullptr; }
+void *rt_stream(rt_ctx *ctx) { return ctx ? (void *)ctx->streams[0] : nullptr; }
+static int rt_sync_other_streams(rt_ctx *ctx) {
+  if (!ctx->alt_used) return RT_OK;
+  for (int i = 1; i < RT_MAX_IN_FLIGHT; i++) RT_HIP(ctx, hipStreamSynchronize(ctx->streams[i]));
+  ctx->alt_used = false;
+  return RT_OK;
+}
 int rt_synchronize(rt_ctx *ctx) {
   if (!ctx) return RT_ERR_INVALID;
-  RT_HIP(ctx, hipStreamSynchronize(ctx->stream_main));
-  if (ctx->alt_used) { RT_HIP(ctx, hipStreamSynchronize(ctx->stream_alt)); ctx->alt_used = false; }
+  RT_HIP(ctx, hipStreamSynchronize(ctx->streams[0]));
+  RT_TRY(rt_sync_other_streams(ctx));
   return RT_OK;
 }
 
 int rt_set_frames_in_flight(rt_ctx *ctx, int n) {
   if (!ctx) return RT_ERR_INVALID;
-  if (n != 1 && n != 2) return rt_fail(ctx, RT_ERR_INVALID, "frames in flight must be 1 or 2");
+  if (n < 1 || n > RT_MAX_IN_FLIGHT) return rt_fail(ctx, RT_ERR_INVALID, "frames in flight must be in 1..%d", RT_MAX_IN_FLIGHT);
   RT_TRY(rt_synchronize(ctx));
   ctx->frames_in_flight = n;
   return RT_OK;
@@ -491,13 +496,13 @@ int rt_trace_tile(rt_scene *sc, const rt_params *p, rt_photon_map *diffuse, rt_p
   // other call first waits for what the second stream still holds.
   const bool queued = !stats && !t1.p && !t2.p && !t3.p;
   int slot = 0;
-  if (queued && ctx->frames_in_flight == 2) { slot = sc->next_slot; sc->next_slot ^= 1; }
-  else if (ctx->alt_used) { RT_HIP(ctx, hipStreamSynchronize(ctx->stream_alt)); ctx->alt_used = false; }
-  if (slot) { ctx->stream = ctx->stream_alt; ctx->alt_used = true; }
+  if (queued && ctx->frames_in_flight > 1) { slot = sc->next_slot % ctx->frames_in_flight; sc->next_slot = (slot + 1) % ctx->frames_in_flight; }
+  else RT_TRY(rt_sync_other_streams(ctx));
+  if (slot) { ctx->stream = ctx->streams[slot]; ctx->alt_used = true; }
   const int rc = p->precision == RT_PRECISION_F64
       ? pl_trace_tile<double>(sc, slot, p, md, mc, x0, y0, w, h, (double *)pre, (double *)post, (uint8_t *)r8, stats)
       : pl_trace_tile<float>(sc, slot, p, md, mc, x0, y0, w, h, (double *)pre, (double *)post, (uint8_t *)r8, stats);
-  ctx->stream = ctx->stream_main;
+  ctx->stream = ctx->streams[0];
   if (rc != RT_OK) return rc;
   if (queued) return RT_OK;                                  // nothing to copy back, the caller synchronises
   RT_TRY(rt_stage_out_end(ctx, pre_rgba, npx * 32, t1));

@@ -13,12 +13,13 @@
 #include "rt_geom.h"
 #include "rt_kdq.h"
 
+#define RT_MAX_IN_FLIGHT 4
 struct rt_ctx {
   int device = 0;
-  hipStream_t stream = nullptr;          // the stream launches go to: stream_main, except while a queued frame is put on stream_alt
-  hipStream_t stream_main = nullptr, stream_alt = nullptr;
-  int frames_in_flight = 1;              // 2: consecutive queued frames alternate between the two streams (rt_set_frames_in_flight)
-  bool alt_used = false;                 // something was queued on stream_alt since it was last synchronised
+  hipStream_t stream = nullptr;          // the stream launches go to: streams[0], except while a queued frame is put on another
+  hipStream_t streams[RT_MAX_IN_FLIGHT] = {};
+  int frames_in_flight = 1;              // n > 1: consecutive queued frames rotate through n streams (rt_set_frames_in_flight)
+  bool alt_used = false;                 // something was queued on streams[1..] since they were last synchronised
   std::string err;
   bool profiling = false;
   std::string profile_only;      // when non-empty: ",name1,name2," -- only launches under these names are timed
@@ -100,7 +101,7 @@ struct rt_scene {
   DevScene<float> d32; DevScene<double> d64;
   // per-scene workspaces (grow-only) so that steady-state calls do not allocate
   // rt_trace_tile's workspaces, one set per frame in flight
-  struct TraceWs { DevMem paths, queue, ctr, masks, blocks, levels; } tws[2];
+  struct TraceWs { DevMem paths, queue, ctr, masks, blocks, levels; } tws[RT_MAX_IN_FLIGHT];
   int next_slot = 0;
   DevMem ws_emit_kind, ws_emit_rec, ws_emit_blocks, ws_misc;
 };

@@ -93,7 +93,7 @@ template <typename T, bool WHITTED, bool FULL>
 static int trace_tile_mode(rt_scene *sc, int slot, const rt_params *p, DevMap md, DevMap mc, int x0, int y0, int w, int h,
                            double *pre, double *post, uint8_t *rgba8, rt_trace_stats *stats) {
   rt_ctx *ctx = sc->ctx;
-  rt_scene::TraceWs &W = sc->tws[slot & 1];
+  rt_scene::TraceWs &W = sc->tws[(unsigned)slot % RT_MAX_IN_FLIGHT];
   DevScene<T> &S = SceneOf<T>::get(sc);
   const int blk = p->super_sample_block > 1 ? p->super_sample_block : 1;       // one traced sample per blk x blk pixels
   const int wb = (w + blk - 1) / blk, hb = (h + blk - 1) / blk;

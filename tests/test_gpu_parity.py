@@ -715,4 +715,4 @@ def test_two_frames_in_flight_equal_serial_frames(rt):
     for w, b in zip(want, out):
         assert np.array_equal(b.cpu().numpy(), w)
     with pytest.raises(capi.RtError):
-        ctx.set_frames_in_flight(3)
+        ctx.set_frames_in_flight(5)
