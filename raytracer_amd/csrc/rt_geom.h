@@ -248,8 +248,8 @@ template <int TYPE> RT_D float isect_fast(const float *f, const float *ot, V3<fl
     float t0 = -hb - sq, t1 = -hb + sq;
     float dn = dot3(f + 4, d);
     float p0 = ot[4] + t0 * dn, p1 = ot[4] + t1 * dn;
-    bool ok0 = t0 > eps && p0 > f[7] && p0 < f[8];
-    bool ok1 = t1 > eps && p1 > f[7] && p1 < f[8];
+    const bool ok0 = (t0 > eps) & (p0 > f[7]) & (p0 < f[8]);
+    const bool ok1 = (t1 > eps) & (p1 > f[7]) & (p1 < f[8]);
     return ok0 ? t0 : (ok1 ? t1 : MISS);
   } else if (TYPE == RT_CYLINDER) {
     float da = dot3(f + 4, d);
@@ -259,25 +259,25 @@ template <int TYPE> RT_D float isect_fast(const float *f, const float *ot, V3<fl
     float sq = sqrt_fast(hb * hb - a * ot[4]);
     float ia = rcp_fast(a);
     float t0 = (-hb - sq) * ia, t1 = (-hb + sq) * ia;
-    if (flags & RT_FLAG_FIRST_ROOT) return (a == 0.0f || !(t0 > 0.0f)) ? MISS : t0;     // wave-uniform branch
+    if (flags & RT_FLAG_FIRST_ROOT) return ((a == 0.0f) | !(t0 > 0.0f)) ? MISS : t0;      // wave-uniform branch
     float hlim = f[7] - eps;
-    bool ok0 = t0 > eps && fabsf(ot[3] + t0 * da) < hlim;
-    bool ok1 = t1 > eps && fabsf(ot[3] + t1 * da) < hlim;
+    const bool ok0 = (t0 > eps) & (fabsf(ot[3] + t0 * da) < hlim);
+    const bool ok1 = (t1 > eps) & (fabsf(ot[3] + t1 * da) < hlim);
     float t = ok0 ? t0 : (ok1 ? t1 : MISS);
     return a == 0.0f ? MISS : t;
   } else if (TYPE == RT_TRIANGLE || TYPE == RT_SQUARE) {
     float dN = dot3(f, d);
     float t = ot[0] * rcp_fast(dN);
     float u = ot[1] + t * dot3(f + 4, d), v = ot[2] + t * dot3(f + 8, d);
-    bool ok = !(fabsf(dN) < eps) && u >= 0.0f && u <= 1.0f && v >= 0.0f && (TYPE == RT_SQUARE ? v <= 1.0f : u + v <= 1.0f);
+    const bool ok = !(fabsf(dN) < eps) & (u >= 0.0f) & (u <= 1.0f) & (v >= 0.0f) & (TYPE == RT_SQUARE ? v <= 1.0f : u + v <= 1.0f);
     return ok ? t : MISS;
   } else {                                                  // disc, annulus
     float dn = dot3(f, d);
     float t = ot[0] * rcp_fast(dn);
     float hx = ot[1] + t * d.x, hy = ot[2] + t * d.y, hz = ot[3] + t * d.z;
     float rSq = hx * hx + hy * hy + hz * hz;
-    bool ok = !(fabsf(dn) < eps) && rSq + eps < f[7];
-    if (TYPE == RT_ANNULUS) ok = ok && rSq - eps > f[8];
+    bool ok = !(fabsf(dn) < eps) & (rSq + eps < f[7]);
+    if (TYPE == RT_ANNULUS) ok = ok & (rSq - eps > f[8]);
     return ok ? t : MISS;
   }
 }
@@ -285,6 +285,21 @@ template <int TYPE> RT_D float isect_fast(const float *f, const float *ot, V3<fl
 // Where a scan reads the type-sorted primitives from: the scene's global arrays (the primitive index
 // is wave-uniform, so these become scalar loads) or a copy the workgroup staged in LDS.  `ot`: staged
 // origin terms of the fp32 records for the one origin all rays of the workgroup share, or nullptr.
+// A primitive's record and staged origin terms in registers, fetched whole before anything is computed: left to
+// itself the compiler reads the fields where they are first used, inside the tests' conditions, and a wave then
+// pays an LDS round trip per field group instead of one per primitive.
+template <int TYPE> RT_D void load_record(const float *f, float *rec) {
+  constexpr int NV = (TYPE == RT_PLANE || TYPE == RT_SPHERE) ? 1 : (TYPE == RT_CYLINDER ? 2 : 3);     // 16-byte pieces in use
+  const float4 *f4 = (const float4 *)f;
+#pragma unroll
+  for (int k = 0; k < NV; k++) { const float4 v = f4[k]; rec[4 * k] = v.x; rec[4 * k + 1] = v.y; rec[4 * k + 2] = v.z; rec[4 * k + 3] = v.w; }
+}
+template <int TYPE> RT_D void load_origin_terms(const float *ot, float *out) {
+  constexpr int N = (TYPE == RT_PLANE) ? 1 : (TYPE == RT_SPHERE || TYPE == RT_DISC || TYPE == RT_ANNULUS) ? 4 : (TYPE == RT_TRIANGLE || TYPE == RT_SQUARE) ? 3 : 5;
+#pragma unroll
+  for (int k = 0; k < N; k++) out[k] = ot[k];
+}
+
 template <typename T> struct ScanSrc { const T *geom; const uint32_t *orig; const uint32_t *flags; const T *ot; };
 
 // LDS bytes needed to stage n primitives
@@ -352,12 +367,12 @@ template <int MODE, bool OT> RT_D int scan_fast(const DevScene<float> &S, const 
 #define RT_FAST_LOOP(TYPE)                                                                              \
   RT_SCAN_UNROLL_PRAGMA                                                                                 \
   for (uint32_t s = S.seg[TYPE]; s < S.seg[TYPE + 1]; s++) {                                            \
-    const float *f = G.geom + (size_t)s * RT_GEOM_STRIDE;                                               \
+    float f[RT_GEOM_STRIDE], ot[RT_OT_STRIDE];                                                          \
+    load_record<TYPE>(G.geom + (size_t)s * RT_GEOM_STRIDE, f);                                          \
     const int flags = (MODE == 1 || MODE == 2 || TYPE == RT_CYLINDER) ? (int)G.flags[s] : 0;            \
+    if (OT) load_origin_terms<TYPE>(G.ot + (size_t)s * RT_OT_STRIDE, ot);                               \
     if ((MODE == 1 || MODE == 2) && (flags & RT_FLAG_LIGHT)) continue;                                  \
-    float otl[RT_OT_STRIDE];                                                                            \
-    const float *ot = otl;                                                                              \
-    if (OT) ot = G.ot + (size_t)s * RT_OT_STRIDE; else origin_terms<TYPE>(f, o, otl);                   \
+    if (!OT) origin_terms<TYPE>(f, o, ot);                                                              \
     const float t = isect_fast<TYPE>(f, ot, d, eps, flags);                                             \
     if (MODE == 2) occluded = occluded || (t > eps && t < lim);                                         \
     else { const bool upd = t > eps && t < best; best = upd ? t : best; best_s = upd ? (int)s : best_s; } \
@@ -378,9 +393,11 @@ template <int MODE> RT_D int scan_fast_visible(const ScanSrc<float> &G, const ui
   RT_SCAN_UNROLL_PRAGMA                                                                                 \
   for (uint32_t k = vseg[TYPE]; k < vseg[TYPE + 1]; k++) {                                              \
     const uint32_t s = vis[k];                                                                          \
-    const float *f = G.geom + (size_t)s * RT_GEOM_STRIDE;                                               \
+    float f[RT_GEOM_STRIDE], ot[RT_OT_STRIDE];                                                          \
+    load_record<TYPE>(G.geom + (size_t)s * RT_GEOM_STRIDE, f);                                          \
+    load_origin_terms<TYPE>(G.ot + (size_t)s * RT_OT_STRIDE, ot);                                       \
     const int flags = (TYPE == RT_CYLINDER) ? (int)G.flags[s] : 0;                                      \
-    const float t = isect_fast<TYPE>(f, G.ot + (size_t)s * RT_OT_STRIDE, d, eps, flags);                \
+    const float t = isect_fast<TYPE>(f, ot, d, eps, flags);                                             \
     const bool upd = t > eps && t < best; best = upd ? t : best; best_s = upd ? (int)s : best_s;        \
   }
   RT_VIS_LOOP(RT_PLANE) RT_VIS_LOOP(RT_SPHERE) RT_VIS_LOOP(RT_HEMISPHERE) RT_VIS_LOOP(RT_CYLINDER)
