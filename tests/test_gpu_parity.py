@@ -716,3 +716,52 @@ def test_two_frames_in_flight_equal_serial_frames(rt):
         assert np.array_equal(b.cpu().numpy(), w)
     with pytest.raises(capi.RtError):
         ctx.set_frames_in_flight(5)
+
+
+# ------------------------------------------------------------------ the benchmark's sizes, through size-independent properties
+def test_full_size_frame_properties(rt):
+    """1920x1080 frame of the bench workload: tiles compose, queued == finished, the ray statistics add up, and the
+    fp32 build stays within its stated tolerance of the fp64 build (per-pixel radiance within 1e-3*255 on >= 99.5 %)"""
+    import torch
+    capi, ctx = rt
+    W, H = 1920, 1080
+    sc = ctx.upload(load_scene(10, W, H))
+    p32 = capi.default_params(precision=capi.PRECISION_F32, use_direct_light=0, use_photon_maps=0, seed=1)
+    p64 = capi.default_params(precision=capi.PRECISION_F64, use_direct_light=0, use_photon_maps=0, seed=1)
+    whole = sc.trace_tile(p32, want=("pre", "rgba8"))
+    assert whole["stats"]["rays"] == W * H + whole["stats"]["tail_rays"] and whole["stats"]["rays"] > W * H
+    tiles = ((0, 0, 1000, 500), (1000, 0, 920, 500), (0, 500, 1920, 580))
+    parts = [sc.trace_tile(p32, x0=x, y0=y, w=w, h=h, want=("pre",)) for (x, y, w, h) in tiles]
+    for (x, y, w, h), part in zip(tiles, parts):
+        assert same(whole["pre"][y:y + h, x:x + w], part["pre"])
+    assert whole["stats"]["rays"] == sum(q["stats"]["rays"] for q in parts)
+    out = torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda")
+    sc.trace_tile(p32, want=(), out_rgba8=out, stats=False)
+    ctx.synchronize()
+    assert np.array_equal(out.cpu().numpy(), whole["rgba8"])
+    ref = sc.trace_tile(p64, want=("pre",))
+    err = np.abs(whole["pre"][..., :3] - ref["pre"][..., :3]).max(axis=-1)
+    assert (err <= 1e-3 * 255).mean() >= 0.995
+    # the two builds follow the same paths almost everywhere: their segment counts differ by well under a percent
+    assert abs(whole["stats"]["rays"] - ref["stats"]["rays"]) < 0.005 * ref["stats"]["rays"]
+
+
+def test_full_size_knn_gather_properties(rt, monkeypatch):
+    """1 M photons, one k = 64 gather per pixel of a 1920x1080 frame: a sample of the wave kernel's results equals the
+    per-lane heap kernel's, the results do not depend on how the queries are batched, and every result is finite"""
+    capi, ctx = rt
+    from raytracer_amd import synth
+    rec = synth.box_photons(1_000_000, seed=7)
+    hits = synth.box_queries(1920, 1080)
+    m = ctx.photon_map(rec)
+    got = m.gather(hits, k=64)
+    assert got.shape == (hits.shape[0], 3) and np.isfinite(got).all() and (got >= 0).all()
+    rows = np.arange(0, hits.shape[0] - 64 * 40, hits.shape[0] // 37)[:, None] + np.arange(64 * 40)[None, :]     # whole groups of 64
+    rows = rows.reshape(-1)
+    sub = m.gather(hits[rows], k=64)
+    scale = max(1.0, float(np.abs(got).max()))
+    assert np.allclose(sub, got[rows], rtol=2e-5, atol=1e-6 * scale)
+    monkeypatch.setenv("RT355_KNN_HEAP", "1")
+    heap = m.gather(hits[rows[:64 * 64]], k=64)
+    monkeypatch.delenv("RT355_KNN_HEAP")
+    assert np.allclose(got[rows[:64 * 64]], heap, rtol=2e-5, atol=1e-6 * scale)
