@@ -4,7 +4,7 @@ set -e
 name=$1; shift
 cd "$(dirname "$0")/../raytracer_amd/csrc"
 out=../../gpurun_variants; mkdir -p $out/obj_$name
-C="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -I../../include $*"
+C="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-slp-vectorize -Wall -Wno-unused-function -I../../include $*"
 /opt/rocm/bin/hipcc $C -c rt_api.hip -o $out/obj_$name/rt_api.o &
 /opt/rocm/bin/hipcc $C -ffp-contract=off -c rt_kd.hip -o $out/obj_$name/rt_kd.o &
 /opt/rocm/bin/hipcc $C -fno-hip-fp32-correctly-rounded-divide-sqrt -ffp-contract=on -c rt_pipeline_f32.hip -o $out/obj_$name/rt_pipeline_f32.o &
