@@ -355,9 +355,12 @@ template <typename T> RT_D ScanSrc<T> global_scan_src(const DevScene<T> &S) {
   return G;
 }
 
-#ifndef RT_SCAN_UNROLL_PRAGMA
-#define RT_SCAN_UNROLL_PRAGMA _Pragma("unroll 2")
+#ifndef RT_SCAN_UNROLL
+#define RT_SCAN_UNROLL 2
 #endif
+#define RT_PRAGMA_STR_(x) _Pragma(#x)
+#define RT_PRAGMA_(x) RT_PRAGMA_STR_(x)
+#define RT_SCAN_UNROLL_PRAGMA RT_PRAGMA_(unroll RT_SCAN_UNROLL)
 // fp32 scan over the precomputed records; same MODEs as scan_scene below.  Equal distances keep the first
 // primitive in type-sorted order.
 template <int MODE, bool OT> RT_D int scan_fast(const DevScene<float> &S, const ScanSrc<float> &G, V3<float> o, V3<float> d, float eps, float limit, float &t_out) {
