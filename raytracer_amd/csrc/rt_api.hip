@@ -251,11 +251,62 @@ struct BvhBuild {
       nodes[me].skip = (uint32_t)nodes.size();
       return me;
     }
-    const uint32_t mid = b + (e - b) / 2;
-    std::nth_element(order.begin() + b, order.begin() + mid, order.begin() + e, [&](uint32_t x, uint32_t y) {
-      const double cx = lo[3 * x + axis] + hi[3 * x + axis], cy = lo[3 * y + axis] + hi[3 * y + axis];
-      return cx < cy || (cx == cy && x < y);
-    });
+    // Split: surface-area heuristic over 16 centroid bins per axis (cost = area x count of either side); the median
+    // of the widest axis when the bins cannot separate the items.  The boxes only steer the walk, so any split is exact.
+    uint32_t mid = b + (e - b) / 2;
+    {
+      constexpr int NB = 16;
+      double best_cost = INFINITY; int best_axis = -1, best_bin = -1;
+      for (int ax = 0; ax < 3; ax++) {
+        const double c0 = clo[ax], span = chi[ax] - clo[ax];
+        if (!(span > 0)) continue;
+        double blo[NB][3], bhi[NB][3]; uint32_t cnt[NB] = { 0 };
+        for (int i = 0; i < NB; i++) for (int k = 0; k < 3; k++) { blo[i][k] = INFINITY; bhi[i][k] = -INFINITY; }
+        auto bin_of = [&](uint32_t it) {
+          const double c = 0.5 * (lo[3 * it + ax] + hi[3 * it + ax]);
+          int bi = (int)((c - c0) / span * NB);
+          return bi < 0 ? 0 : (bi >= NB ? NB - 1 : bi);
+        };
+        for (uint32_t i = b; i < e; i++) {
+          const uint32_t it = order[i]; const int bi = bin_of(it);
+          cnt[bi]++;
+          for (int k = 0; k < 3; k++) { blo[bi][k] = fmin(blo[bi][k], lo[3 * it + k]); bhi[bi][k] = fmax(bhi[bi][k], hi[3 * it + k]); }
+        }
+        auto area = [](const double *l, const double *h) {
+          const double dx = h[0] - l[0], dy = h[1] - l[1], dz = h[2] - l[2];
+          return (dx >= 0 && dy >= 0 && dz >= 0) ? dx * dy + dy * dz + dz * dx : 0.0;
+        };
+        double right_area[NB]; uint32_t right_cnt[NB];
+        { double l[3] = { INFINITY, INFINITY, INFINITY }, h[3] = { -INFINITY, -INFINITY, -INFINITY }; uint32_t c = 0;
+          for (int i = NB - 1; i > 0; i--) { for (int k = 0; k < 3; k++) { l[k] = fmin(l[k], blo[i][k]); h[k] = fmax(h[k], bhi[i][k]); } c += cnt[i]; right_area[i] = area(l, h); right_cnt[i] = c; } }
+        double l[3] = { INFINITY, INFINITY, INFINITY }, h[3] = { -INFINITY, -INFINITY, -INFINITY }; uint32_t c = 0;
+        for (int i = 0; i < NB - 1; i++) {                    // split between bins i and i + 1
+          for (int k = 0; k < 3; k++) { l[k] = fmin(l[k], blo[i][k]); h[k] = fmax(h[k], bhi[i][k]); }
+          c += cnt[i];
+          if (c == 0 || right_cnt[i + 1] == 0) continue;
+          const double cost = area(l, h) * c + right_area[i + 1] * right_cnt[i + 1];
+          if (cost < best_cost) { best_cost = cost; best_axis = ax; best_bin = i; }
+        }
+      }
+      if (best_axis >= 0) {
+        const int ax = best_axis; const double c0 = clo[ax], span = chi[ax] - clo[ax];
+        auto left = [&](uint32_t it) {
+          const double c = 0.5 * (lo[3 * it + ax] + hi[3 * it + ax]);
+          int bi = (int)((c - c0) / span * 16);
+          bi = bi < 0 ? 0 : (bi >= 16 ? 15 : bi);
+          return bi <= best_bin;
+        };
+        mid = (uint32_t)(std::stable_partition(order.begin() + b, order.begin() + e, left) - order.begin());
+      }
+      const uint32_t smaller = (mid - b < e - mid) ? mid - b : e - mid;
+      if (best_axis < 0 || mid == b || mid == e || (uint64_t)smaller * 16 < (uint64_t)(e - b)) {       // (bounds the depth of the tree)
+        mid = b + (e - b) / 2;
+        std::nth_element(order.begin() + b, order.begin() + mid, order.begin() + e, [&](uint32_t x, uint32_t y) {
+          const double cx = lo[3 * x + axis] + hi[3 * x + axis], cy = lo[3 * y + axis] + hi[3 * y + axis];
+          return cx < cy || (cx == cy && x < y);
+        });
+      }
+    }
     nodes[me].leaf = 0;
     build(b, mid); build(mid, e);
     nodes[me].skip = (uint32_t)nodes.size();
