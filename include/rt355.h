@@ -92,9 +92,9 @@ typedef struct rt_trace_stats {
   uint64_t rays;                /* closest-hit segments traced (one per reference traceRay call that scans) */
   uint64_t shadow_rays;         /* any-hit segments (directLight) */
   uint64_t gathers;             /* photon-map queries (one per map per opaque hit) */
-  uint64_t bounces;             /* wavefront iterations */
+  uint64_t bounces;             /* segments of the longest path */
   uint64_t stack_overflows;     /* paths whose material stack exceeded the fixed capacity */
-  uint64_t tail_rays;           /* of `rays`: segments traced by the per-lane tail kernel instead of a wavefront pass */
+  uint64_t tail_rays;           /* of `rays`: segments traced after the first pass by the kernels that follow paths to their end */
   uint64_t prim_tests;          /* ray-primitive distance tests executed for `rays` (+ shadow rays when a hierarchy is used) */
   uint64_t prims_per_ray_brute_force;   /* primitives in the scene: rays * this = the tests of the reference's loops */
 } rt_trace_stats;
