@@ -287,7 +287,7 @@ def main():
         if roof_gather:
             line["roofline_gather"] = roof_gather
         line["extra"] = extra
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:         # (the CPU baseline is reported with the single-GPU line only)
             line["cpu_baseline"] = cpu_baseline(flat, seed)
             if not args.no_gather:
                 line["cpu_baseline_gather"] = cpu_baseline_gather(rec_host, hits_host, args.knn)
