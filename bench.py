@@ -188,7 +188,7 @@ def main():
     # ---- photon-map leg: 1M-photon kd-tree build + k-NN radiance gather per pixel ----
     extra = {}
     roof_gather = None
-    if not args.no_gather:
+    if not args.no_gather:                        # (every rank runs the report-only legs: they hold barriers)
         rec_host, hits_host = synth.box_photons(args.photons, seed=7), synth.box_queries(W, H)
         rec = torch.from_numpy(rec_host).to(dev)
         hits = torch.from_numpy(hits_host).to(dev)
