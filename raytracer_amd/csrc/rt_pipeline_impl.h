@@ -121,6 +121,8 @@ static int trace_tile_mode(rt_scene *sc, int slot, const rt_params *p, DevMap md
   C.seed = p->seed; C.x0 = x0; C.y0 = y0; C.w = wb; C.h = hb; C.block = blk; C.n_paths = (uint32_t)n_paths;
   C.magic_w = (uint32_t)(0x100000000ull / (uint64_t)wb); C.magic_ss = (uint32_t)(0x100000000ull / (uint64_t)(p->sub_sample * p->sub_sample));
   C.magic_s = (uint32_t)(0x100000000ull / (uint64_t)p->sub_sample);
+  C.tiles_x = (wb % 32 == 0 && hb % 8 == 0 && !getenv("RT355_RASTER_ORDER")) ? (uint32_t)(wb / 32) : 0u;
+  C.magic_tx = C.tiles_x ? (uint32_t)(0x100000000ull / (uint64_t)C.tiles_x) : 0u;
   C.fuse_resolve = (!WHITTED && p->sub_sample == 1) ? 1 : 0; C.pre = pre; C.post = post; C.rgba8 = rgba8;
   if (!p->use_photon_maps) { md.n = 0; mc.n = 0; }
   T *levels = nullptr;
@@ -222,10 +224,10 @@ static int trace_tile_mode(rt_scene *sc, int slot, const rt_params *p, DevMap md
     }
   }
   if (WHITTED)
-    RT_LAUNCH(ctx, "resolve", k_resolve_a<T>, div_up(n_pixels, 256), 256, P, levels, (uint32_t)n_paths, (int)p->max_depth, (int)n_pixels,
+    RT_LAUNCH(ctx, "resolve", k_resolve_a<T>, div_up(n_pixels, 256), 256, P, C, levels, (uint32_t)n_paths, (int)p->max_depth, (int)n_pixels,
               (int)p->sub_sample, pre, post, rgba8);
   else if (!C.fuse_resolve)
-    RT_LAUNCH(ctx, "resolve", k_resolve<T>, div_up(n_pixels, 256), 256, P, (int)n_pixels, (int)p->sub_sample, pre, post, rgba8);
+    RT_LAUNCH(ctx, "resolve", k_resolve<T>, div_up(n_pixels, 256), 256, P, C, (int)n_pixels, (int)p->sub_sample, pre, post, rgba8);
   bool readback = stats != nullptr;
 #ifdef RT_TAIL_PROBE
   readback = true;

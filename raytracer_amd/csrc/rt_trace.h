@@ -80,6 +80,10 @@ struct TraceCfg {
   // > 0: the first pass hands its survivors to k_tail through sub-queues of this capacity (block_append_subqueue)
   uint32_t subq_cap;
   uint32_t iter_base;                 // bounce passes (k_bounce) that ran between the first pass and k_tail
+  // > 0: paths are numbered tile by tile, 32 x 8 samples per tile, tiles_x tiles per row of tiles (w % 32 == 0 and
+  // h % 8 == 0); 0: row by row.  A workgroup of the first pass then covers a compact rectangle: a tighter culling
+  // pyramid, and chunks of survivors that live about equally long.
+  uint32_t tiles_x, magic_tx;
 };
 
 #define RT_MAX_WAVE_BOUNCES 62
@@ -125,11 +129,28 @@ RT_D uint32_t div_by(uint32_t x, uint32_t d, uint32_t m, uint32_t &r) {
   if (r >= d) { q++; r -= d; }
   return q;
 }
+// column and row (in traced samples) of the pp-th pixel in path order
+RT_D void pixel_colrow(const TraceCfg &C, uint32_t pp, uint32_t &col, uint32_t &row) {
+  if (C.tiles_x) {
+    uint32_t tx;
+    const uint32_t ty = div_by(pp >> 8, C.tiles_x, C.magic_tx, tx), in = pp & 255u;
+    col = tx * 32u + (in & 31u); row = ty * 8u + (in >> 5);
+  } else {
+    row = div_by(pp, (uint32_t)C.w, C.magic_w, col);
+  }
+}
+// where the pp-th pixel in path order sits in the tile's (row-major) outputs
+RT_D uint32_t pixel_out_index(const TraceCfg &C, uint32_t pp) {
+  if (!C.tiles_x) return pp;
+  uint32_t col, row;
+  pixel_colrow(C, pp, col, row);
+  return row * (uint32_t)C.w + col;
+}
 // pixel and sub-sample of path p
 RT_D void path_pixel(const TraceCfg &C, uint32_t p, int &X, int &Y, uint32_t &sub) {
-  uint32_t col;
+  uint32_t col, row;
   const uint32_t pix = div_by(p, (uint32_t)(C.sub_sample * C.sub_sample), C.magic_ss, sub);
-  const uint32_t row = div_by(pix, (uint32_t)C.w, C.magic_w, col);
+  pixel_colrow(C, pix, col, row);
   X = C.x0 + (int)col * C.block; Y = C.y0 + (int)row * C.block;
 }
 
@@ -432,7 +453,8 @@ RT_D bool shade_body_a(const DevScene<T> &S, const TraceCfg &C, T *levels, uint3
 RT_D double clamp01(double x, double lo, double hi) { return (x < lo) ? lo : ((x > hi) ? hi : x); }
 
 // what k_resolve does for a pixel with one sub-sample (rayphoton.js:1610-1621): clamp, floor; pre = the unclamped colour
-template <typename T> RT_D void resolve_store(const TraceCfg &C, uint32_t pix, const T *o) {
+template <typename T> RT_D void resolve_store(const TraceCfg &C, uint32_t pp, const T *o) {
+  const uint32_t pix = pixel_out_index(C, pp);
   uint32_t packed = 0;
   for (int c = 0; c < 4; c++) {
     const T last = o[c], hi = (c == 3) ? T(1) : T(255);
@@ -475,8 +497,13 @@ RT_D void cull_primitives(const DevScene<float> &S, const TraceCfg &C, uint16_t 
     uint32_t r_, c0, c1;
     const uint32_t ss = (uint32_t)(C.sub_sample * C.sub_sample);
     const uint32_t pix0 = div_by(p0, ss, C.magic_ss, r_), pix1 = div_by(p1, ss, C.magic_ss, r_);
-    const uint32_t row0 = div_by(pix0, (uint32_t)C.w, C.magic_w, c0), row1 = div_by(pix1, (uint32_t)C.w, C.magic_w, c1);
-    if (row0 != row1) { c0 = 0; c1 = (uint32_t)C.w - 1; }
+    uint32_t row0, row1;
+    pixel_colrow(C, pix0, c0, row0); pixel_colrow(C, pix1, c1, row1);
+    if (C.tiles_x) {
+      // pixels pix0 .. pix1 of one tile are whole rows of it unless they lie in one row; across tiles: no culling
+      if ((pix0 >> 8) != (pix1 >> 8)) { c0 = 0; c1 = (uint32_t)C.w - 1; row0 = 0; row1 = (uint32_t)C.h - 1; }
+      else if (row0 != row1) { c0 &= ~31u; c1 = c0 + 31u; }
+    } else if (row0 != row1) { c0 = 0; c1 = (uint32_t)C.w - 1; }
     const float jit = (C.block > 1 ? (float)C.block : 0.0f) + 1.0f;        // block jitter + sub-sample jitter, in pixels
     const float xa = (float)(C.x0 + (int)c0 * C.block) - 1.0f, xb = (float)(C.x0 + (int)c1 * C.block) + jit + 1.0f;
     const float ya = (float)(C.y0 + (int)row0 * C.block) - 1.0f, yb = (float)(C.y0 + (int)row1 * C.block) + jit + 1.0f;
@@ -771,13 +798,15 @@ __global__ void __launch_bounds__(RT_TAIL_THREADS, RT_TAIL_MIN_WAVES) k_tail(Dev
 // Pixel resolve (rayphoton.js:1610-1623): clamp each sub-sample (`colour()`), sum, floor of the
 // mean.  pre = the last sub-sample's unclamped colour; rgba8 = post as bytes.
 template <typename T>
-__global__ void __launch_bounds__(256) k_resolve(PathSoA<T> P, int n_pixels, int sub_sample, double *pre, double *post, uint8_t *rgba8) {
-  int pix = blockIdx.x * blockDim.x + threadIdx.x;
-  if (pix >= n_pixels) return;
+__global__ void __launch_bounds__(256) k_resolve(PathSoA<T> P, TraceCfg C, int n_pixels, int sub_sample, double *pre, double *post, uint8_t *rgba8) {
+  const int pp = blockIdx.x * blockDim.x + threadIdx.x;    // pixel in path order; `pix` below: in output order
+  if (pp >= n_pixels) return;
+  const int pix = (int)pixel_out_index(C, (uint32_t)pp);
+  if (pix >= n_pixels) return;                             // (never true)
   const int SS = sub_sample * sub_sample;
   double tot[4] = { 0, 0, 0, 0 }, last[4] = { 0, 0, 0, 0 };
   for (int s = 0; s < SS; s++) {
-    const T *o = P.out + ((size_t)pix * SS + s) * 4;
+    const T *o = P.out + ((size_t)pp * SS + s) * 4;
     for (int c = 0; c < 4; c++) { last[c] = (double)o[c]; tot[c] += clamp01(last[c], 0, c == 3 ? 1 : 255); }
   }
   for (int c = 0; c < 4; c++) {
@@ -795,15 +824,17 @@ __global__ void __launch_bounds__(256) k_resolve(PathSoA<T> P, int n_pixels, int
 // colour back up through the path's level records, then average the sub-samples (colour() does not clamp
 // there).  A sub-sample whose trace the reference leaves undefined (ray.js:905) makes the pixel NaN.
 template <typename T>
-__global__ void __launch_bounds__(256) k_resolve_a(PathSoA<T> P, const T *levels, uint32_t n_paths, int max_depth, int n_pixels,
+__global__ void __launch_bounds__(256) k_resolve_a(PathSoA<T> P, TraceCfg C, const T *levels, uint32_t n_paths, int max_depth, int n_pixels,
                                                    int sub_sample, double *pre, double *post, uint8_t *rgba8) {
-  int pix = blockIdx.x * blockDim.x + threadIdx.x;
-  if (pix >= n_pixels) return;
+  const int pp = blockIdx.x * blockDim.x + threadIdx.x;    // pixel in path order; `pix` below: in output order
+  if (pp >= n_pixels) return;
+  const int pix = (int)pixel_out_index(C, (uint32_t)pp);
+  if (pix >= n_pixels) return;                             // (never true)
   const int SS = sub_sample * sub_sample;
   double tot[4] = { 0, 0, 0, 0 }, last[4] = { 0, 0, 0, 0 };
   bool bad = false;
   for (int s = 0; s < SS; s++) {
-    const size_t p = (size_t)pix * SS + s;
+    const size_t p = (size_t)pp * SS + s;
     if (p >= n_paths) break;                                // (never true)
     const T *o = P.out + p * 4;
     T c[3] = { o[0], o[1], o[2] }; T a = o[3];
