@@ -128,6 +128,13 @@ class KdTree {
     for (let i = 0; i < k && res.idx[i] >= 0; i++) out.push({ photon: this.photonAt(res.idx[i]), index: res.idx[i], distSq: res.d2[i] });
     return out;
   }
+  // The adaptive-radius estimate the reference sketches in a commented block (rayphoton.js:1766-1778, :1789-1801):
+  // start at r0, triple the radius (up to 10 times) while fewer than 10 photons are inside, give nothing below 3.
+  // hits = Float32Array(nq*9): position, normal, albedo.  -> {rgb: Float32Array(nq*3), radius: Float32Array(nq)}
+  gatherAdaptive(hits, r0, grow, minCount, minKeep, maxAttempts) {
+    return addon().gatherRadianceAdaptive(this.map, hits, r0, grow === undefined ? 3 : grow, minCount === undefined ? 10 : minCount,
+      minKeep === undefined ? 3 : minKeep, maxAttempts === undefined ? 10 : maxAttempts);
+  }
   // [point, distance] of the nearest photon.  The reference's version (kdtree.js:10-62) never searches
   // the far side of a split and is therefore approximate (and never called); this one is exact.
   nearestNeighbourAndDistance(x, pos) {

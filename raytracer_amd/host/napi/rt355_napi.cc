@@ -293,6 +293,25 @@ static napi_value GatherRadiance(napi_env env, napi_callback_info info) {
   return out;
 }
 
+// gatherRadianceAdaptive(map, hits Float32Array(nq*9), r0, grow, minCount, minKeep, maxAttempts) -> {rgb: Float32Array(nq*3), radius: Float32Array(nq)}
+static napi_value GatherRadianceAdaptive(napi_env env, napi_callback_info info) {
+  Args a(env, info);
+  MapBox *mb = a.ext<MapBox>(0);
+  size_t n9 = 0;
+  const float *h = (const float *)a.typed(1, napi_float32_array, &n9);
+  if (!mb || !h) { napi_throw_type_error(env, nullptr, "gatherRadianceAdaptive(map, hits, r0, grow, minCount, minKeep, maxAttempts)"); return nullptr; }
+  uint32_t nq = (uint32_t)(n9 / 9);
+  napi_value ab, ab2, rgb, rad, out; void *data, *data2;
+  NAPI_OK(napi_create_arraybuffer(env, (size_t)nq * 12, &data, &ab)); NAPI_OK(napi_create_typedarray(env, napi_float32_array, (size_t)nq * 3, ab, 0, &rgb));
+  NAPI_OK(napi_create_arraybuffer(env, (size_t)nq * 4, &data2, &ab2)); NAPI_OK(napi_create_typedarray(env, napi_float32_array, (size_t)nq, ab2, 0, &rad));
+  int rc = rt_gather_radiance_adaptive(mb->map, h, nq, a.num(2, 0.1), a.num(3, 3), (uint32_t)a.num(4, 10), (uint32_t)a.num(5, 3), (uint32_t)a.num(6, 10),
+                                       (float *)data, (float *)data2);
+  if (rc != RT_OK) return fail(env, mb->ctx, rc);
+  NAPI_OK(napi_create_object(env, &out));
+  napi_set_named_property(env, out, "rgb", rgb); napi_set_named_property(env, out, "radius", rad);
+  return out;
+}
+
 // traceTile(scene, params, diffuseMap|null, causticMap|null, x0, y0, w, h) -> {pre, post: Float64Array(w*h*4), rgba8: Uint8Array, stats}
 static napi_value TraceTile(napi_env env, napi_callback_info info) {
   Args a(env, info);
@@ -330,7 +349,7 @@ static napi_value ModuleInit(napi_env env, napi_value exports) {
   const struct { const char *name; napi_callback fn; } fns[] = {
     { "init", Init }, { "shutdown", Shutdown }, { "sceneUpload", SceneUpload }, { "intersectPairs", IntersectPairs }, { "intersect", Intersect },
     { "emitMany", EmitMany }, { "photonMapBuild", PhotonMapBuild }, { "photonMapNodes", PhotonMapNodes },
-    { "kdRadius", KdRadius }, { "kdKnn", KdKnn }, { "gatherRadiance", GatherRadiance }, { "traceTile", TraceTile },
+    { "kdRadius", KdRadius }, { "kdKnn", KdKnn }, { "gatherRadiance", GatherRadiance }, { "gatherRadianceAdaptive", GatherRadianceAdaptive }, { "traceTile", TraceTile },
     { "findMedian", FindMedian },
   };
   for (const auto &f : fns) {

@@ -46,6 +46,28 @@ for (let i = 0; i < 64 && radiusOk; i++) {
   for (let k = 0; k < got.length && radiusOk; k++) radiusOk = got[k] === scene.photonKdTDiffuse.photonAt(q.diffuse_wide_indices[lo + k]);
 }
 check('KdTree.nearestNeighbours order', radiusOk);
+{
+  // adaptive-radius gather: the radius used holds at least 10 photons (or is the last attempt), one step less does not
+  const tree = scene.photonKdTDiffuse, nq = 32;
+  const hits = new Float32Array(nq * 9);
+  for (let i = 0; i < nq; i++) {
+    for (let c = 0; c < 3; c++) hits[i * 9 + c] = q.queries[i * 3 + c];
+    hits[i * 9 + 5] = 1; hits[i * 9 + 6] = 255; hits[i * 9 + 7] = 255; hits[i * 9 + 8] = 255;
+  }
+  const r0 = 0.02, ad = tree.gatherAdaptive(hits, r0);
+  let adOk = ad.rgb.length === nq * 3 && ad.radius.length === nq;
+  for (let i = 0; i < nq && adOk; i++) {
+    const x = [hits[i * 9], hits[i * 9 + 1], hits[i * 9 + 2]];
+    const steps = Math.round(Math.log(ad.radius[i] / r0) / Math.log(3));
+    const radii = [r0];
+    for (let k = 1; k <= steps; k++) radii.push(radii[k - 1] * 3);           // the library's own sequence of radii
+    const r = radii[steps];
+    const inside = tree.nearestNeighbours(x, r).length;
+    adOk = Math.abs(ad.radius[i] - r) <= 1e-5 * r && (inside >= 10 || steps === 9);     // (10 attempts: steps 0 .. 9)
+    if (adOk && steps > 0) adOk = tree.nearestNeighbours(x, radii[steps - 1]).length < 10;
+  }
+  check('KdTree.gatherAdaptive radius', adOk);
+}
 let fmOk = true;
 for (let n = 1; n <= 4096 && fmOk; n++) fmOk = scene.photonKdTDiffuse.findMedian(n) === kd.find_median[n - 1];
 check('KdTree.findMedian', fmOk);
