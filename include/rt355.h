@@ -12,7 +12,10 @@
  *     reference.
  *   - array arguments may be host pointers or device pointers of the context's GPU; the
  *     library detects which.  Host arrays are borrowed for the duration of the call only.
- *   - all kernels of one context run on one HIP stream (rt_stream()).
+ *   - the kernels of one context run on the HIP stream rt_stream() returns, with one exception: after
+ *     rt_set_frames_in_flight(ctx, n > 1), frames that rt_trace_tile only queues rotate through n streams of the
+ *     context.  rt_synchronize() waits for all of them on the host; rt_join() orders rt_stream() behind all of them
+ *     on the device.  A consumer that waits on rt_stream() alone must call rt_join() first.
  *   - nothing here allocates through, or exposes, any framework type: plain pointers/sizes.
  */
 #ifndef RT355_H
@@ -114,8 +117,18 @@ void rt_default_params(rt_params *p);
 int rt_init(const int *device_ids, int n, rt_ctx **out);
 void rt_shutdown(rt_ctx *ctx);
 const char *rt_last_error(rt_ctx *ctx);     /* ctx may be NULL: last rt_init failure */
-void *rt_stream(rt_ctx *ctx);               /* the hipStream_t all work is launched on */
-int rt_synchronize(rt_ctx *ctx);            /* waits for everything the context has queued */
+void *rt_stream(rt_ctx *ctx);               /* the hipStream_t work is launched on (see the conventions above) */
+int rt_synchronize(rt_ctx *ctx);            /* host wait for everything the context has queued, on all its streams */
+/* Device-side join: work put on rt_stream() after this call runs after every frame queued so far, whichever of the
+ * context's streams it went to.  No host wait.  Needed only with rt_set_frames_in_flight(ctx, n > 1) by callers that
+ * order their own work behind rt_stream() (an event, hipStreamWaitEvent, a framework's external-stream wrapper)
+ * instead of calling rt_synchronize().  No counterpart in the reference. */
+int rt_join(rt_ctx *ctx);
+/* Experiment / test switches, by name: tail_threshold, whole_frame, bounce_passes, no_lds, no_cull, raster_order,
+ * bvh (-1 by scene size / 0 / 1; read by rt_scene_upload), knn_heap, knn_r0, knn_verbose, probe.  rt_init reads
+ * RT355_<NAME> from the environment once; this call changes one switch of a live context.  The defaults are the
+ * measured best; results do not depend on any of them (fp32 images: bit for bit).  No counterpart in the reference. */
+int rt_set_option(rt_ctx *ctx, const char *name, double value);
 /* n = 2..4: up to n consecutive frames that rt_trace_tile only queues (see there) may overlap -- the long, thinly
  * occupied end of one frame's path tracing runs beside the start of the next; frames in flight together must not
  * share output buffers.  n = 1 (default): queued frames run one after the other.  No counterpart in the reference (its frames are
@@ -201,8 +214,10 @@ int rt_gather_radiance_adaptive(rt_photon_map *map, const float *hits, uint32_t 
  *   rgba8     : w*h*4 bytes, post_rgba as 8-bit RGBA (alpha*255)
  * any of the three may be NULL. diffuse/caustic may be NULL (no map).
  * With `stats` the call returns when the frame is finished.  With stats == NULL and every output in device
- * memory it only queues the frame on rt_stream(): the outputs are complete after rt_synchronize() (or any later
- * call that synchronises), and consecutive frames run back to back without a host round trip in between. */
+ * memory it only queues the frame -- on rt_stream(), or, after rt_set_frames_in_flight(ctx, n > 1), on one of n streams
+ * of the context in turn: the outputs are complete after rt_synchronize() (or any later call that returns host data),
+ * or, for work the caller puts on rt_stream(), after rt_join(); consecutive frames run back to back without a host
+ * round trip in between. */
 int rt_trace_tile(rt_scene *scene, const rt_params *p, rt_photon_map *diffuse, rt_photon_map *caustic,
                   int x0, int y0, int w, int h, double *pre_rgba, double *post_rgba, uint8_t *rgba8,
                   rt_trace_stats *stats);

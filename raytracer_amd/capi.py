@@ -20,7 +20,7 @@ MODE_PHOTON, MODE_WHITTED = 0, 1
 SCAN_CLOSEST, SCAN_CLOSEST_NOLIGHT, SCAN_ANY = 0, 1, 2
 
 EXPORTS = [
-    "rt_default_params", "rt_init", "rt_shutdown", "rt_last_error", "rt_stream", "rt_synchronize", "rt_set_frames_in_flight",
+    "rt_default_params", "rt_init", "rt_shutdown", "rt_last_error", "rt_stream", "rt_synchronize", "rt_join", "rt_set_option", "rt_set_frames_in_flight",
     "rt_profile_enable", "rt_profile_select", "rt_profile_reset", "rt_profile_get", "rt_scene_upload", "rt_scene_free",
     "rt_intersect_pairs", "rt_intersect", "rt_emit_photons", "rt_emit_many", "rt_photon_map_build",
     "rt_photon_map_free", "rt_photon_map_size", "rt_photon_map_nodes", "rt_kd_build", "rt_find_median",
@@ -142,6 +142,27 @@ class Context:
 
     def synchronize(self):
         self.check(self.lib.rt_synchronize(self.h))
+
+    def join(self):
+        """device-side: work put on stream() from now on runs after every frame queued so far (no host wait)"""
+        self.check(self.lib.rt_join(self.h))
+
+    def set_option(self, name, value):
+        """experiment / test switch of this context (see rt_set_option in include/rt355.h)"""
+        self.check(self.lib.rt_set_option(self.h, name.encode(), C.c_double(float(value))))
+
+    def option(self, name, value, restore):
+        """context manager: switch `name` to `value` inside the block and to `restore` afterwards"""
+        import contextlib
+
+        @contextlib.contextmanager
+        def cm():
+            self.set_option(name, value)
+            try:
+                yield
+            finally:
+                self.set_option(name, restore)
+        return cm()
 
     def set_frames_in_flight(self, n):
         """2: consecutive queued frames (trace_tile(..., stats=False) into device buffers) may overlap; give them

@@ -6,6 +6,7 @@
 #include <stdarg.h>
 #include <stdlib.h>
 #include <string.h>
+#include <ctype.h>
 #include <algorithm>
 #include <limits>
 #include <vector>
@@ -82,7 +83,40 @@ int rt_init(const int *device_ids, int n, rt_ctx **out) {
     return RT_ERR_HIP;
   }
   ctx->stream = ctx->streams[0];
+  for (int i = 1; i < RT_MAX_IN_FLIGHT; i++)
+    if (hipEventCreateWithFlags(&ctx->frame_done[i], hipEventDisableTiming) != hipSuccess) {
+      rt_fail(nullptr, RT_ERR_HIP, "context creation failed: %s", hipGetErrorString(hipGetLastError()));
+      rt_shutdown(ctx);
+      return RT_ERR_HIP;
+    }
+  // the experiment switches: the environment is read here, once per context
+  static const char *names[] = { "tail_threshold", "whole_frame", "bounce_passes", "no_lds", "no_cull", "raster_order", "bvh", "knn_heap",
+                                 "knn_verbose", "probe", "knn_r0" };
+  for (const char *nm : names) {
+    std::string env = "RT355_";
+    for (const char *c = nm; *c; c++) env += (char)toupper((unsigned char)*c);
+    if (const char *e = getenv(env.c_str())) (void)rt_set_option(ctx, nm, atof(e));
+  }
   *out = ctx;
+  return RT_OK;
+}
+
+int rt_set_option(rt_ctx *ctx, const char *name, double value) {
+  if (!ctx || !name) return RT_ERR_INVALID;
+  RtKnobs &K = ctx->knobs;
+  const std::string n = name;
+  if (n == "tail_threshold") K.tail_threshold = (long)value;
+  else if (n == "whole_frame") K.whole_frame = value != 0;
+  else if (n == "bounce_passes") K.bounce_passes = (int)value;
+  else if (n == "no_lds") K.no_lds = value != 0;
+  else if (n == "no_cull") K.no_cull = value != 0;
+  else if (n == "raster_order") K.raster_order = value != 0;
+  else if (n == "bvh") K.bvh = (int)value;
+  else if (n == "knn_heap") K.knn_heap = value != 0;
+  else if (n == "knn_verbose") K.knn_verbose = value != 0;
+  else if (n == "probe") K.probe = value != 0;
+  else if (n == "knn_r0") K.knn_r0 = value;
+  else return rt_fail(ctx, RT_ERR_INVALID, "unknown option '%s'", name);
   return RT_OK;
 }
 
@@ -93,6 +127,7 @@ void rt_shutdown(rt_ctx *ctx) {
   for (auto &kv : ctx->events) for (auto &ev : kv.second) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
   for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+  for (int i = 0; i < RT_MAX_IN_FLIGHT; i++) if (ctx->frame_done[i]) (void)hipEventDestroy(ctx->frame_done[i]);
   for (int i = 0; i < RT_MAX_IN_FLIGHT; i++) if (ctx->streams[i]) (void)hipStreamDestroy(ctx->streams[i]);
   delete ctx;
 }
@@ -101,8 +136,17 @@ const char *rt_last_error(rt_ctx *ctx) { return ctx ? ctx->err.c_str() : g_init_
 void *rt_stream(rt_ctx *ctx) { return ctx ? (void *)ctx->streams[0] : nullptr; }
 static int rt_sync_other_streams(rt_ctx *ctx) {
   if (!ctx->alt_used) return RT_OK;
-  for (int i = 1; i < RT_MAX_IN_FLIGHT; i++) RT_HIP(ctx, hipStreamSynchronize(ctx->streams[i]));
+  for (int i = 1; i < RT_MAX_IN_FLIGHT; i++) { RT_HIP(ctx, hipStreamSynchronize(ctx->streams[i])); ctx->frame_pending[i] = false; }
   ctx->alt_used = false;
+  return RT_OK;
+}
+// Device-side join: everything queued on rt_stream() from now on runs after every frame queued so far, on whichever
+// of the context's streams it was put.  No host wait.
+int rt_join(rt_ctx *ctx) {
+  if (!ctx) return RT_ERR_INVALID;
+  RT_HIP(ctx, hipSetDevice(ctx->device));
+  for (int i = 1; i < RT_MAX_IN_FLIGHT; i++)
+    if (ctx->frame_pending[i]) { RT_HIP(ctx, hipStreamWaitEvent(ctx->streams[0], ctx->frame_done[i], 0)); ctx->frame_pending[i] = false; }
   return RT_OK;
 }
 int rt_synchronize(rt_ctx *ctx) {
@@ -314,13 +358,13 @@ struct BvhBuild {
   }
 };
 
-// Scenes whose type-sorted copy does not fit the scan kernels' LDS budget (or every scene, with RT355_BVH=1, for
+// Scenes whose type-sorted copy does not fit the scan kernels' LDS budget (or every scene, with option bvh = 1, for
 // tests) get a hierarchy; `order` maps sorted slot -> original index.
 static int rt_build_bvh(rt_ctx *ctx, const rt_scene_desc *d, const std::vector<uint32_t> &order, rt_scene *sc, bool &built) {
   built = false;
   const uint32_t n = d->n_shapes;
-  const char *e = getenv("RT355_BVH");
-  const bool want = e ? atoi(e) != 0 : (size_t)n * (RT_GEOM_STRIDE * 4 + 8 + RT_OT_STRIDE * 4) > 56 * 1024;
+  const int knob = ctx->knobs.bvh;
+  const bool want = knob >= 0 ? knob != 0 : (size_t)n * (RT_GEOM_STRIDE * 4 + 8 + RT_OT_STRIDE * 4) > 56 * 1024;
   if (!want || n == 0) return RT_OK;
   if (n >= (1u << 24)) return rt_fail(ctx, RT_ERR_TOO_LARGE, "hierarchy supports up to 2^24 primitives");
   BvhBuild B;
@@ -476,7 +520,7 @@ int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *d, rt_scene **out) {
       } else { o4[0] = o4[1] = o4[2] = 0; o4[3] = INFINITY; }
     }
     if ((rc = up(sc->sbound, bs.data(), bs.size() * 4))) { delete sc; return rc; }
-    sc->d32.sbound = getenv("RT355_NO_CULL") ? nullptr : sc->sbound.as<float4>();
+    sc->d32.sbound = sc->sbound.as<float4>();                 // (option no_cull switches the culling off per frame)
   }
   memcpy(sc->d32.seg, seg, sizeof seg); memcpy(sc->d64.seg, seg, sizeof seg);
   *out = sc;
@@ -496,8 +540,22 @@ int rt_intersect_pairs(rt_ctx *ctx, const rt_params *p, uint32_t n, const double
   RT_TRY(rt_stage_out_begin(ctx, t_out, (size_t)n * 8, tt, &t));
   if (p->precision == RT_PRECISION_F64)
     RT_TRY(pl_intersect_pairs<double>(ctx, p, n, (const double *)o, (const double *)d, normalize_dir, (const uint8_t *)m, (const double *)g, (double *)t));
-  else
-    RT_TRY(pl_intersect_pairs<float>(ctx, p, n, (const double *)o, (const double *)d, normalize_dir, (const uint8_t *)m, (const double *)g, (double *)t));
+  else {
+    // The fp32 product path: every pair goes through the scan record the upload would precompute for the shape
+    // (rt_fast_record) and the distance functions of the fp32 scan kernels.
+    std::vector<uint8_t> hm((size_t)n * 4); std::vector<double> hg((size_t)n * 12); std::vector<float> hr((size_t)n * 12);
+    RT_HIP(ctx, hipMemcpy(hm.data(), shape_meta, hm.size(), hipMemcpyDefault));
+    RT_HIP(ctx, hipMemcpy(hg.data(), shape_geom, hg.size() * 8, hipMemcpyDefault));
+    for (uint32_t i = 0; i < n; i++) {
+      if (hm[4 * (size_t)i] >= RT_NUM_TYPES) return rt_fail(ctx, RT_ERR_UNKNOWN_SHAPE, "I didn't recognize the shape! (%d)", (int)hm[4 * (size_t)i]);
+      rt_fast_record(hm[4 * (size_t)i], hm[4 * (size_t)i + 2], &hg[(size_t)i * 12], &hr[(size_t)i * 12]);
+    }
+    DevMem trec;
+    RT_HIP(ctx, trec.alloc(hr.size() * 4));
+    RT_HIP(ctx, hipMemcpyAsync(trec.p, hr.data(), hr.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    RT_TRY(pl_intersect_pairs_fast(ctx, p, n, (const double *)o, (const double *)d, normalize_dir, (const uint8_t *)m, trec.as<float>(), (double *)t));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));          // (trec and hr go out of scope)
+  }
   return rt_stage_out_end(ctx, t_out, (size_t)n * 8, tt);
 }
 
@@ -555,6 +613,7 @@ int rt_trace_tile(rt_scene *sc, const rt_params *p, rt_photon_map *diffuse, rt_p
       : pl_trace_tile<float>(sc, slot, p, md, mc, x0, y0, w, h, (double *)pre, (double *)post, (uint8_t *)r8, stats);
   ctx->stream = ctx->streams[0];
   if (rc != RT_OK) return rc;
+  if (slot) { RT_HIP(ctx, hipEventRecord(ctx->frame_done[slot], ctx->streams[slot])); ctx->frame_pending[slot] = true; }
   if (queued) return RT_OK;                                  // nothing to copy back, the caller synchronises
   RT_TRY(rt_stage_out_end(ctx, pre_rgba, npx * 32, t1));
   RT_TRY(rt_stage_out_end(ctx, post_rgba, npx * 32, t2));

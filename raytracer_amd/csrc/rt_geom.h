@@ -259,12 +259,15 @@ template <int TYPE> RT_D float isect_fast(const float *f, const float *ot, V3<fl
     float sq = sqrt_fast(hb * hb - a * ot[4]);
     float ia = rcp_fast(a);
     float t0 = (-hb - sq) * ia, t1 = (-hb + sq) * ia;
-    if (flags & RT_FLAG_FIRST_ROOT) return ((a == 0.0f) | !(t0 > 0.0f)) ? MISS : t0;      // wave-uniform branch
+    // a == 0 is the reference's "ray parallel to the axis: miss" (qRoots, rayphoton.js:1884-1889); in fp32 a = 1 - da^2
+    // carries an absolute rounding error of about 1.2e-7, so anything below 4e-7 counts as parallel
+    const bool parallel = fabsf(a) < 4e-7f;
+    if (flags & RT_FLAG_FIRST_ROOT) return (parallel | !(t0 > 0.0f)) ? MISS : t0;      // wave-uniform branch
     float hlim = f[7] - eps;
     const bool ok0 = (t0 > eps) & (fabsf(ot[3] + t0 * da) < hlim);
     const bool ok1 = (t1 > eps) & (fabsf(ot[3] + t1 * da) < hlim);
     float t = ok0 ? t0 : (ok1 ? t1 : MISS);
-    return a == 0.0f ? MISS : t;
+    return parallel ? MISS : t;
   } else if (TYPE == RT_TRIANGLE || TYPE == RT_SQUARE) {
     float dN = dot3(f, d);
     float t = ot[0] * rcp_fast(dN);

@@ -14,6 +14,21 @@
 #include "rt_kdq.h"
 
 #define RT_MAX_IN_FLIGHT 4
+// Experiment / test switches of a context.  Their defaults are the measured best; rt_init reads the RT355_* environment
+// variables ONCE into this struct and rt_set_option changes single entries afterwards, so no frame pays a getenv.
+struct RtKnobs {
+  long tail_threshold = -1;      // paths left at which the tail kernel takes over (< 0: the built-in default)
+  int whole_frame = 0;           // 1: the whole frame in one launch
+  int bounce_passes = 0;         // single-bounce passes between the first pass and the tail kernel
+  int no_lds = 0;                // 1: scans read the primitives through scalar loads instead of the LDS copy
+  int no_cull = 0;               // 1: the first pass scans every primitive (no per-workgroup culling)
+  int raster_order = 0;          // 1: paths numbered row by row even where 32x8 tiles would fit
+  int bvh = -1;                  // hierarchy at upload: -1 by scene size, 0 never, 1 always
+  int knn_heap = 0;              // 1: k-nearest gathers use the per-lane heap kernel only
+  int knn_verbose = 0;
+  int probe = 0;
+  double knn_r0 = 0;             // > 0: first radius of the wave-cooperative k-nearest gather
+};
 struct rt_ctx {
   int device = 0;
   hipStream_t stream = nullptr;          // the stream launches go to: streams[0], except while a queued frame is put on another
@@ -30,6 +45,9 @@ struct rt_ctx {
     hipEvent_t e = nullptr; (void)hipEventCreate(&e); return e;
   }
   uint32_t *pinned = nullptr;    // small pinned scratch for counters read back each bounce
+  RtKnobs knobs;
+  hipEvent_t frame_done[RT_MAX_IN_FLIGHT] = {};   // recorded behind the last frame queued on streams[i], i >= 1
+  bool frame_pending[RT_MAX_IN_FLIGHT] = {};      // ... and not yet joined into streams[0] (rt_join) or synchronised
 };
 
 int rt_fail(rt_ctx *ctx, int code, const char *fmt, ...);

@@ -293,6 +293,7 @@ __global__ void __launch_bounds__(256) k_kd_radius(DevMap M, const float *q3, ui
 extern "C" int rt_kd_radius(rt_photon_map *m, const float *queries, uint32_t nq, double r, uint32_t cap, uint32_t *count, int32_t *idx) {
   if (!m) return RT_ERR_INVALID;
   rt_ctx *ctx = m->ctx;
+  if (!queries || !count || (cap > 0 && !idx)) return rt_fail(ctx, RT_ERR_INVALID, "rt_kd_radius: queries, count and (for cap > 0) idx are required");
   if (nq == 0) return RT_OK;
   RT_HIP(ctx, hipSetDevice(ctx->device));
   DevMem tq, tc, ti; const void *dq; void *dc, *di;
@@ -300,6 +301,7 @@ extern "C" int rt_kd_radius(rt_photon_map *m, const float *queries, uint32_t nq,
   RT_TRY(rt_stage_out_begin(ctx, count, (size_t)nq * 4, tc, &dc));
   RT_TRY(rt_stage_out_begin(ctx, idx, (size_t)nq * cap * 4, ti, &di));
   RT_LAUNCH(ctx, "kd_radius", k_kd_radius, div_up(nq, 256), 256, m->view(), (const float *)dq, nq, r, cap, (uint32_t *)dc, (int32_t *)di);
+  RT_HIP(ctx, hipGetLastError());
   RT_TRY(rt_stage_out_end(ctx, count, (size_t)nq * 4, tc));
   RT_TRY(rt_stage_out_end(ctx, idx, (size_t)nq * cap * 4, ti));
   return RT_OK;
@@ -397,6 +399,7 @@ extern "C" int rt_kd_knn(rt_photon_map *m, const float *queries, uint32_t nq, ui
   if (!m) return RT_ERR_INVALID;
   rt_ctx *ctx = m->ctx;
   if (k == 0 || k > 192) return rt_fail(ctx, RT_ERR_INVALID, "k must be in 1..192 (LDS-resident heap), got %u", k);
+  if (!queries || !idx || !d2) return rt_fail(ctx, RT_ERR_INVALID, "rt_kd_knn: queries, idx and d2 are required");
   if (nq == 0) return RT_OK;
   RT_HIP(ctx, hipSetDevice(ctx->device));
   DevMem tq, ti, td; const void *dq; void *di, *dd;
@@ -409,6 +412,7 @@ extern "C" int rt_kd_knn(rt_photon_map *m, const float *queries, uint32_t nq, ui
     hipLaunchKernelGGL(k_kd_knn, dim3(div_up(nq, KNN_LANES)), dim3(KNN_LANES), knn_lds_bytes(k), ctx->stream, m->view(),
                        (const float *)dq, nq, k, (int32_t *)di, (double *)dd);
   }
+  RT_HIP(ctx, hipGetLastError());
   RT_TRY(rt_stage_out_end(ctx, idx, (size_t)nq * k * 4, ti));
   RT_TRY(rt_stage_out_end(ctx, d2, (size_t)nq * k * 8, td));
   return RT_OK;
@@ -741,10 +745,82 @@ __global__ void __launch_bounds__(256) k_compact_flags(const uint8_t *flags, uin
   if (threadIdx.x == 255) *out_count = base;
 }
 
+// ---- scratch of the k-nearest gather: per query group a fallback flag, the list of flagged groups, the same for the
+// second pass's parts, and two counters.  rt_gather_radiance keeps it in a grow-only buffer of the map.
+#define KNN_SPLIT 64u                                       // parts of a flagged group in the second pass: one query per wave
+static size_t knn_scratch_bytes(uint32_t nq) {
+  const size_t blocks = div_up(nq, KNN_LANES);
+  return (blocks + blocks * KNN_SPLIT) * 5 + 64;
+}
+// The k-nearest gather over device arrays, with its scratch in `ws` (knn_scratch_bytes(nq) bytes of device memory whose
+// old contents do not matter: every word that is read has been written by an earlier kernel of the same call).
+static int gather_knn_run(rt_photon_map *m, const float *dh, uint32_t nq, uint32_t k, float *dout, void *ws) {
+  rt_ctx *ctx = m->ctx;
+  const RtKnobs &K = ctx->knobs;
+  const uint32_t blocks = div_up(nq, KNN_LANES);
+  const bool heap_all = m->n < k || m->n < 2 * KNN2_CAP || K.knn_heap;     // small maps: nothing to gain
+  if (heap_all) {
+    RT_HIP(ctx, hipFuncSetAttribute((const void *)k_gather_knn, hipFuncAttributeMaxDynamicSharedMemorySize, knn_lds_bytes(k)));
+    KernelTimer timer_(ctx, "gather_knn");
+    hipLaunchKernelGGL(k_gather_knn, dim3(blocks), dim3(KNN_LANES), knn_lds_bytes(k), ctx->stream, m->view(),
+                       dh, nq, k, dout, (const uint32_t *)nullptr, (const uint32_t *)nullptr, 1u);
+    RT_HIP(ctx, hipGetLastError());
+    return RT_OK;
+  }
+  // first radius: the k-th neighbour distance if the photons were spread evenly over the faces of their bounding box
+  const double dx = (double)m->bbox[3] - m->bbox[0], dy = (double)m->bbox[4] - m->bbox[1], dz = (double)m->bbox[5] - m->bbox[2];
+  const double area = 2.0 * (dx * dy + dy * dz + dz * dx);
+  double r0 = area > 0 ? 1.2 * sqrt((double)k * area / (3.141592653589793 * (double)m->n)) : (dx + dy + dz) * (double)k / (double)m->n;
+  if (!(r0 > 0)) r0 = 1e-6;
+  if (K.knn_r0 > 0) r0 = K.knn_r0;
+  // pass 1: one wave per 64 consecutive queries.  pass 2: the groups whose queries were too spread out for the LDS
+  // buffers, again with the wave kernel, in KNN_SPLIT parts each.  pass 3: parts still left over, per-lane heaps.
+  const size_t units2_max = (size_t)blocks * KNN_SPLIT;
+  uint32_t *list1 = (uint32_t *)ws, *count1 = list1 + blocks;
+  uint32_t *list2 = count1 + 1, *count2 = list2 + units2_max;
+  uint8_t *flags1 = (uint8_t *)(count2 + 1), *flags2 = flags1 + blocks;
+  RT_LAUNCH(ctx, "gather_knn", k_gather_knn_wave, blocks, 64, m->view(), dh, nq, k, r0, dout, flags1, (const uint32_t *)nullptr, 1u);
+  RT_LAUNCH(ctx, "gather_knn_flags", k_compact_flags, 1, 256, flags1, blocks, list1, count1);
+  RT_HIP(ctx, hipMemcpyAsync(ctx->pinned, count1, 4, hipMemcpyDeviceToHost, ctx->stream));
+  RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  const uint32_t left1 = ctx->pinned[0] <= blocks ? ctx->pinned[0] : blocks;
+  uint32_t left2 = 0;
+  if (left1 > 0) {
+    const uint32_t units2 = left1 * KNN_SPLIT;
+    RT_LAUNCH(ctx, "gather_knn_split", k_gather_knn_wave, units2, 64, m->view(), dh, nq, k, r0, dout, flags2, (const uint32_t *)list1, KNN_SPLIT);
+    RT_LAUNCH(ctx, "gather_knn_flags", k_compact_flags, 1, 256, flags2, units2, list2, count2);
+    RT_HIP(ctx, hipMemcpyAsync(ctx->pinned, count2, 4, hipMemcpyDeviceToHost, ctx->stream));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    left2 = ctx->pinned[0] <= units2 ? ctx->pinned[0] : units2;
+    if (left2 > 0) {
+      RT_HIP(ctx, hipFuncSetAttribute((const void *)k_gather_knn, hipFuncAttributeMaxDynamicSharedMemorySize, knn_lds_bytes(k)));
+      KernelTimer timer_(ctx, "gather_knn_heap_fallback");
+      hipLaunchKernelGGL(k_gather_knn, dim3(left2), dim3(KNN_LANES), knn_lds_bytes(k), ctx->stream, m->view(),
+                         dh, nq, k, dout, (const uint32_t *)list2, (const uint32_t *)list1, KNN_SPLIT);
+    }
+  }
+  RT_HIP(ctx, hipGetLastError());
+#ifdef RT_KNN_PROBE
+  if (K.knn_verbose) {
+    unsigned long long hp[8], zero[8] = { 0 };
+    RT_HIP(ctx, hipMemcpyFromSymbol(hp, HIP_SYMBOL(knn_probe), sizeof hp));
+    RT_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(knn_probe), zero, sizeof zero));
+    const double w = hp[5] ? (double)hp[5] : 1.0;
+    fprintf(stderr, "knn probe per wave: walk %.0f check %.0f search %.0f ties %.0f sum %.0f cycles; passes %.2f candidates %.1f (%llu waves)\n",
+            hp[0] / w, hp[1] / w, hp[2] / w, hp[3] / w, hp[4] / w, hp[6] / w, hp[7] / w, hp[5]);
+  }
+#endif
+  if (K.knn_verbose)
+    fprintf(stderr, "rt_gather_radiance: %u query groups; %u split into %u parts each; %u parts left to the heap kernel\n", blocks, left1, KNN_SPLIT, left2);
+  return RT_OK;
+}
+
 extern "C" int rt_gather_radiance(rt_photon_map *m, const float *hits, uint32_t nq, double r, uint32_t k, float *rgb_out) {
   if (!m) return RT_ERR_INVALID;
   rt_ctx *ctx = m->ctx;
+  if (!rgb_out || !hits) return rt_fail(ctx, RT_ERR_INVALID, "rt_gather_radiance: hits and rgb_out are required");
   if (k > 192) return rt_fail(ctx, RT_ERR_INVALID, "k must be <= 192, got %u", k);
+  if (k == 0 && !(r > 0)) return rt_fail(ctx, RT_ERR_INVALID, "rt_gather_radiance: need k > 0 or r > 0");
   if (nq == 0) return RT_OK;
   RT_HIP(ctx, hipSetDevice(ctx->device));
   DevMem th, to; const void *dh; void *dout;
@@ -752,65 +828,10 @@ extern "C" int rt_gather_radiance(rt_photon_map *m, const float *hits, uint32_t 
   RT_TRY(rt_stage_out_begin(ctx, rgb_out, (size_t)nq * 12, to, &dout));
   if (k == 0) {
     RT_LAUNCH(ctx, "gather_radius", k_gather_radius, div_up(nq, 256), 256, m->view(), (const float *)dh, nq, r, (float *)dout);
+    RT_HIP(ctx, hipGetLastError());
   } else {
-    const uint32_t blocks = div_up(nq, KNN_LANES);
-    bool heap_all = m->n < k || m->n < 2 * KNN2_CAP || getenv("RT355_KNN_HEAP") != nullptr;     // small maps: nothing to gain
-    if (!heap_all) {
-      // first radius: the k-th neighbour distance if the photons were spread evenly over the faces of their bounding box
-      const double dx = (double)m->bbox[3] - m->bbox[0], dy = (double)m->bbox[4] - m->bbox[1], dz = (double)m->bbox[5] - m->bbox[2];
-      const double area = 2.0 * (dx * dy + dy * dz + dz * dx);
-      double r0 = area > 0 ? 1.2 * sqrt((double)k * area / (3.141592653589793 * (double)m->n)) : (dx + dy + dz) * (double)k / (double)m->n;
-      if (!(r0 > 0)) r0 = 1e-6;
-      if (const char *e = getenv("RT355_KNN_R0")) r0 = atof(e);
-      // pass 1: one wave per 64 consecutive queries.  pass 2: the groups whose queries were too spread out for the LDS
-      // buffers, again with the wave kernel, in KNN_SPLIT parts each.  pass 3: parts still left over, per-lane heaps.
-      const uint32_t KNN_SPLIT = 64;                      // one query per wave: its box is a point and always fits
-      const size_t units2_max = (size_t)blocks * KNN_SPLIT;
-      RT_HIP(ctx, m->ws_flags.reserve(((size_t)blocks + units2_max) * 5 + 64));
-      uint32_t *list1 = m->ws_flags.as<uint32_t>(), *count1 = list1 + blocks;
-      uint32_t *list2 = count1 + 1, *count2 = list2 + units2_max;
-      uint8_t *flags1 = (uint8_t *)(count2 + 1), *flags2 = flags1 + blocks;
-      RT_LAUNCH(ctx, "gather_knn", k_gather_knn_wave, blocks, 64, m->view(), (const float *)dh, nq, k, r0, (float *)dout, flags1,
-                (const uint32_t *)nullptr, 1u);
-      RT_LAUNCH(ctx, "gather_knn_flags", k_compact_flags, 1, 256, flags1, blocks, list1, count1);
-      RT_HIP(ctx, hipMemcpyAsync(ctx->pinned, count1, 4, hipMemcpyDeviceToHost, ctx->stream));
-      RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-      const uint32_t left1 = ctx->pinned[0] <= blocks ? ctx->pinned[0] : blocks;
-      uint32_t left2 = 0;
-      if (left1 > 0) {
-        const uint32_t units2 = left1 * KNN_SPLIT;
-        RT_LAUNCH(ctx, "gather_knn_split", k_gather_knn_wave, units2, 64, m->view(), (const float *)dh, nq, k, r0, (float *)dout, flags2,
-                  (const uint32_t *)list1, KNN_SPLIT);
-        RT_LAUNCH(ctx, "gather_knn_flags", k_compact_flags, 1, 256, flags2, units2, list2, count2);
-        RT_HIP(ctx, hipMemcpyAsync(ctx->pinned, count2, 4, hipMemcpyDeviceToHost, ctx->stream));
-        RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        left2 = ctx->pinned[0] <= units2 ? ctx->pinned[0] : units2;
-        if (left2 > 0) {
-          RT_HIP(ctx, hipFuncSetAttribute((const void *)k_gather_knn, hipFuncAttributeMaxDynamicSharedMemorySize, knn_lds_bytes(k)));
-          KernelTimer timer_(ctx, "gather_knn_heap_fallback");
-          hipLaunchKernelGGL(k_gather_knn, dim3(left2), dim3(KNN_LANES), knn_lds_bytes(k), ctx->stream, m->view(),
-                             (const float *)dh, nq, k, (float *)dout, (const uint32_t *)list2, (const uint32_t *)list1, KNN_SPLIT);
-        }
-      }
-#ifdef RT_KNN_PROBE
-      if (getenv("RT355_KNN_VERBOSE")) {
-        unsigned long long hp[8], zero[8] = { 0 };
-        RT_HIP(ctx, hipMemcpyFromSymbol(hp, HIP_SYMBOL(knn_probe), sizeof hp));
-        RT_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(knn_probe), zero, sizeof zero));
-        const double w = hp[5] ? (double)hp[5] : 1.0;
-        fprintf(stderr, "knn probe per wave: walk %.0f check %.0f search %.0f ties %.0f sum %.0f cycles; passes %.2f candidates %.1f (%llu waves)\n",
-                hp[0] / w, hp[1] / w, hp[2] / w, hp[3] / w, hp[4] / w, hp[6] / w, hp[7] / w, hp[5]);
-      }
-#endif
-      if (getenv("RT355_KNN_VERBOSE"))
-        fprintf(stderr, "rt_gather_radiance: %u query groups; %u split into %u parts each; %u parts left to the heap kernel\n", blocks, left1, KNN_SPLIT, left2);
-    }
-    if (heap_all) {
-      RT_HIP(ctx, hipFuncSetAttribute((const void *)k_gather_knn, hipFuncAttributeMaxDynamicSharedMemorySize, knn_lds_bytes(k)));
-      KernelTimer timer_(ctx, "gather_knn");
-      hipLaunchKernelGGL(k_gather_knn, dim3(blocks), dim3(KNN_LANES), knn_lds_bytes(k), ctx->stream, m->view(),
-                         (const float *)dh, nq, k, (float *)dout, (const uint32_t *)nullptr, (const uint32_t *)nullptr, 1u);
-    }
+    RT_HIP(ctx, m->ws_flags.reserve(knn_scratch_bytes(nq)));
+    RT_TRY(gather_knn_run(m, (const float *)dh, nq, k, (float *)dout, m->ws_flags.p));
   }
   RT_TRY(rt_stage_out_end(ctx, rgb_out, (size_t)nq * 12, to));
   return RT_OK;
@@ -855,6 +876,7 @@ extern "C" int rt_gather_radiance_adaptive(rt_photon_map *m, const float *hits, 
   if (!m) return RT_ERR_INVALID;
   rt_ctx *ctx = m->ctx;
   if (!(r0 > 0) || !(grow > 1) || max_attempts == 0 || max_attempts > 64) return rt_fail(ctx, RT_ERR_INVALID, "adaptive gather: need r0 > 0, grow > 1, 1 <= max_attempts <= 64");
+  if (!hits || !rgb_out) return rt_fail(ctx, RT_ERR_INVALID, "adaptive gather: hits and rgb_out are required");
   if (nq == 0) return RT_OK;
   RT_HIP(ctx, hipSetDevice(ctx->device));
   DevMem th, to, tr; const void *dh; void *dout, *dr;
@@ -863,6 +885,7 @@ extern "C" int rt_gather_radiance_adaptive(rt_photon_map *m, const float *hits, 
   RT_TRY(rt_stage_out_begin(ctx, r_used_out, (size_t)nq * 4, tr, &dr));
   RT_LAUNCH(ctx, "gather_adaptive", k_gather_adaptive, div_up(nq, 256), 256, m->view(), (const float *)dh, nq, r0, grow, min_count, min_keep,
             max_attempts, (float *)dout, (float *)dr);
+  RT_HIP(ctx, hipGetLastError());
   RT_TRY(rt_stage_out_end(ctx, rgb_out, (size_t)nq * 12, to));
   RT_TRY(rt_stage_out_end(ctx, r_used_out, (size_t)nq * 4, tr));
   return RT_OK;

@@ -94,7 +94,9 @@ static int trace_tile_mode(rt_scene *sc, int slot, const rt_params *p, DevMap md
                            double *pre, double *post, uint8_t *rgba8, rt_trace_stats *stats) {
   rt_ctx *ctx = sc->ctx;
   rt_scene::TraceWs &W = sc->tws[(unsigned)slot % RT_MAX_IN_FLIGHT];
-  DevScene<T> &S = SceneOf<T>::get(sc);
+  const RtKnobs &K = ctx->knobs;
+  DevScene<T> S = SceneOf<T>::get(sc);                        // (a copy: the kernels take it by value)
+  if constexpr (sizeof(T) == 4) { if (K.no_cull) S.sbound = nullptr; }
   const int blk = p->super_sample_block > 1 ? p->super_sample_block : 1;       // one traced sample per blk x blk pixels
   const int wb = (w + blk - 1) / blk, hb = (h + blk - 1) / blk;
   const size_t n_pixels = (size_t)wb * hb;
@@ -121,7 +123,7 @@ static int trace_tile_mode(rt_scene *sc, int slot, const rt_params *p, DevMap md
   C.seed = p->seed; C.x0 = x0; C.y0 = y0; C.w = wb; C.h = hb; C.block = blk; C.n_paths = (uint32_t)n_paths;
   C.magic_w = (uint32_t)(0x100000000ull / (uint64_t)wb); C.magic_ss = (uint32_t)(0x100000000ull / (uint64_t)(p->sub_sample * p->sub_sample));
   C.magic_s = (uint32_t)(0x100000000ull / (uint64_t)p->sub_sample);
-  C.tiles_x = (wb % 32 == 0 && hb % 8 == 0 && !getenv("RT355_RASTER_ORDER")) ? (uint32_t)(wb / 32) : 0u;
+  C.tiles_x = (wb % 32 == 0 && hb % 8 == 0 && !K.raster_order) ? (uint32_t)(wb / 32) : 0u;
   C.magic_tx = C.tiles_x ? (uint32_t)(0x100000000ull / (uint64_t)C.tiles_x) : 0u;
   C.fuse_resolve = (!WHITTED && p->sub_sample == 1) ? 1 : 0; C.pre = pre; C.post = post; C.rgba8 = rgba8;
   if (!p->use_photon_maps) { md.n = 0; mc.n = 0; }
@@ -142,7 +144,7 @@ static int trace_tile_mode(rt_scene *sc, int slot, const rt_params *p, DevMap md
   uint32_t *block_count = W.blocks.as<uint32_t>();
   uint32_t *counts = ctr->counts;                           // counts[b] = queue length of pass b (device side)
   bool lds = !S.bvh && scene_fits_lds<T>(S.n_shapes);       // hierarchy scans read the primitives they reach from global memory
-  if (const char *e = getenv("RT355_NO_LDS")) if (atoi(e)) lds = false;      // (experiments: wave-uniform scalar loads instead)
+  if (K.no_lds) lds = false;                                // (experiments: wave-uniform scalar loads instead)
   const size_t smem = lds ? scan_lds_bytes<T>(S.n_shapes) : 0;
   // k_tail (fp32) also keeps its workgroup's path states in LDS: it stages the scene only while both fit in 64 KB
   const bool lds_tail = lds && (sizeof(T) == 8 || smem + (size_t)(RT_LSTATE_WORDS + 3) * 4 * RT_TAIL_THREADS + 256 <= 64 * 1024);
@@ -154,23 +156,21 @@ static int trace_tile_mode(rt_scene *sc, int slot, const rt_params *p, DevMap md
   // (measured on 3840x2160 frames: with the all-primitives scan the direct route wins, 0.52 vs 0.66 ms; with the
   // hierarchy the wavefront passes win, 4.9 vs 5.3 ms)
   uint32_t tail_threshold = S.bvh ? 1u << 21 : 1u << 24;
-  if (const char *e = getenv("RT355_TAIL_THRESHOLD")) tail_threshold = (uint32_t)strtoul(e, nullptr, 10);
-  // RT355_WHOLE_FRAME=1: the whole frame in ONE launch (k_tail<RT_TAIL_PRIMARY>), every workgroup carrying its paths
+  if (K.tail_threshold >= 0) tail_threshold = (uint32_t)K.tail_threshold;
+  // option whole_frame = 1: the whole frame in ONE launch (k_tail<RT_TAIL_PRIMARY>), every workgroup carrying its paths
   // from the camera ray to their end -- fewest launches, but the fused first pass then runs at the tail kernel's
   // lower occupancy; measured slower than the pipeline below on full frames.
-  bool whole_frame = false;
-  if (const char *e = getenv("RT355_WHOLE_FRAME")) whole_frame = atoi(e) != 0;
+  const bool whole_frame = K.whole_frame != 0;
   uint32_t ub = (uint32_t)n_paths;                          // upper bound of the current queue length
   uint32_t wave_bounces = 0;
   // when the tail kernel follows the first pass directly, the survivors go to it through sub-queues (their order
   // does not matter to it) and no scan / scatter launches are needed
   const bool direct = !whole_frame && ub <= tail_threshold && RT_MAX_WAVE_BOUNCES >= 1;
   C.subq_cap = direct ? subq_cap_all : 0;
-  // ... optionally (RT355_BOUNCE_PASSES=1|2) after single-bounce passes at the first pass's occupancy (k_bounce).
+  // ... optionally (option bounce_passes = 1|2) after single-bounce passes at the first pass's occupancy (k_bounce).
   // Off by default: on the 1080p frames measured, a pass costs more (state through global memory, another append)
   // than the iteration of k_tail it replaces.
-  uint32_t bounce_passes = 0;
-  if (const char *e = getenv("RT355_BOUNCE_PASSES")) bounce_passes = direct ? std::min<uint32_t>((uint32_t)atoi(e), RT_MAX_BOUNCE_PASSES) : 0;
+  uint32_t bounce_passes = direct ? std::min<uint32_t>((uint32_t)std::max(K.bounce_passes, 0), RT_MAX_BOUNCE_PASSES) : 0;
   if ((int)bounce_passes > C.max_bounces - 1) bounce_passes = (uint32_t)std::max(C.max_bounces - 1, 0);    // pass j traces segment j
   C.iter_base = bounce_passes;
   if (whole_frame) {
@@ -241,7 +241,7 @@ static int trace_tile_mode(rt_scene *sc, int slot, const rt_params *p, DevMap md
   RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
   RT_HIP(ctx, hipGetLastError());
 #ifdef RT_TAIL_PROBE
-  if (getenv("RT355_PROBE")) {
+  if (K.probe) {
     static const char *ph[5] = { "load", "scan", "shade+store", "compact", "top" };
     for (int a = 0; a < 3; a++) {
       fprintf(stderr, "probe %s: block-iterations %llu;", a == 0 ? "iter 1" : (a == 1 ? "iter 2-3" : "iter 4+"), hc.probe[a][5]);
