@@ -197,6 +197,17 @@ int rt_kd_knn(rt_photon_map *map, const float *queries, uint32_t nq, uint32_t k,
  * distance (k > 0).  hits: nq x 9 fp32 = pos3 normal3 albedo3; rgb_out: nq x 3 fp32. */
 int rt_gather_radiance(rt_photon_map *map, const float *hits, uint32_t nq, double r, uint32_t k, float *rgb_out);
 
+/* rt_gather_radiance for callers that cannot allocate device memory (code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc).  NO COUNTERPART IN THE REFERENCE.  Same results as rt_gather_radiance, but the
+ * call allocates nothing: `hits_dev` and `rgb_dev` must already be device memory of the context's GPU (a host array is
+ * rejected with RT_ERR_INVALID), and the k-nearest gather's scratch (fallback flags and work lists) lives in a static
+ * device array of about 1.3 MB that each GPU the library runs on holds until the process ends.  nq may be at most
+ * RT_GATHER_STATIC_MAX_QUERIES (RT_ERR_TOO_LARGE beyond: split the queries over several calls).  All calls on one GPU
+ * share that array: calls that overlap in time on one GPU (two contexts, two host threads) race.  Returns when the
+ * results are complete. */
+#define RT_GATHER_STATIC_MAX_QUERIES 262144u
+int rt_gather_radiance_static(rt_photon_map *map, const float *hits_dev, uint32_t nq, double r, uint32_t k, float *rgb_dev);
+
 /* The adaptive-radius search sketched in the reference's commented block (rayphoton.js:1766-1778, :1789-1801): start at
  * r0 and, up to max_attempts times (10 there), multiply the radius by `grow` (3) while fewer than min_count (10) photons
  * are inside; fewer than min_keep (3) photons in the end give no contribution.  rgb as rt_gather_radiance with the area of

@@ -16,6 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RT355_LIB") or os.path.join(_HERE, "csrc", "librt355.so")      # override: kernel-variant experiments
 
 PRECISION_F32, PRECISION_F64 = 0, 1
+GATHER_STATIC_MAX_QUERIES = 262144
 MODE_PHOTON, MODE_WHITTED = 0, 1
 SCAN_CLOSEST, SCAN_CLOSEST_NOLIGHT, SCAN_ANY = 0, 1, 2
 
@@ -24,7 +25,7 @@ EXPORTS = [
     "rt_profile_enable", "rt_profile_select", "rt_profile_reset", "rt_profile_get", "rt_scene_upload", "rt_scene_free",
     "rt_intersect_pairs", "rt_intersect", "rt_emit_photons", "rt_emit_many", "rt_photon_map_build",
     "rt_photon_map_free", "rt_photon_map_size", "rt_photon_map_nodes", "rt_kd_build", "rt_find_median",
-    "rt_kd_radius", "rt_kd_knn", "rt_gather_radiance", "rt_gather_radiance_adaptive", "rt_trace_tile",
+    "rt_kd_radius", "rt_kd_knn", "rt_gather_radiance", "rt_gather_radiance_static", "rt_gather_radiance_adaptive", "rt_trace_tile",
 ]
 
 
@@ -353,6 +354,12 @@ class PhotonMap:
                                                                 C.c_uint32(min_count), C.c_uint32(min_keep), C.c_uint32(max_attempts),
                                                                 _ptr(rgb), _ptr(r_used)))
         return rgb, r_used
+
+    def gather_static(self, hits_dev, out_dev, r=0.0, k=0):
+        """rt_gather_radiance_static: device tensors in and out, nothing is allocated by the call"""
+        nq = hits_dev.shape[0]
+        self.ctx.check(self.ctx.lib.rt_gather_radiance_static(self.h, _ptr(hits_dev), C.c_uint32(nq), C.c_double(r), C.c_uint32(k), _ptr(out_dev)))
+        return out_dev
 
     def gather(self, hits, r=0.0, k=0, out=None):
         h = _c(hits, np.float32) if isinstance(hits, np.ndarray) else hits

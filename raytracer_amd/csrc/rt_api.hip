@@ -97,6 +97,8 @@ int rt_init(const int *device_ids, int n, rt_ctx **out) {
     for (const char *c = nm; *c; c++) env += (char)toupper((unsigned char)*c);
     if (const char *e = getenv(env.c_str())) (void)rt_set_option(ctx, nm, atof(e));
   }
+  int rc = rt_static_scratch_setup(ctx);
+  if (rc != RT_OK) { g_init_error = ctx->err; rt_shutdown(ctx); return rc; }
   *out = ctx;
   return RT_OK;
 }

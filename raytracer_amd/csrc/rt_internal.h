@@ -121,7 +121,7 @@ struct rt_scene {
   // rt_trace_tile's workspaces, one set per frame in flight
   struct TraceWs { DevMem paths, queue, ctr, masks, blocks, levels; } tws[RT_MAX_IN_FLIGHT];
   int next_slot = 0;
-  DevMem ws_emit_kind, ws_emit_rec, ws_emit_blocks, ws_misc;
+  DevMem ws_emit_kind, ws_emit_rec, ws_emit_seg, ws_emit_blocks, ws_emit_shard, ws_misc;
 };
 
 // ---- photon map ----
@@ -137,4 +137,6 @@ struct rt_photon_map {
   }
 };
 
+// looks up this device's copy of the static scratch array (rt_kd.hip); called by rt_init with the device current
+int rt_static_scratch_setup(rt_ctx *ctx);
 int rt_kd_build_device(rt_ctx *ctx, const float *d_pos, uint32_t n, int32_t *d_perm, uint8_t *d_dim, float *bbox6);

@@ -746,12 +746,31 @@ __global__ void __launch_bounds__(256) k_compact_flags(const uint8_t *flags, uin
 }
 
 // ---- scratch of the k-nearest gather: per query group a fallback flag, the list of flagged groups, the same for the
-// second pass's parts, and two counters.  rt_gather_radiance keeps it in a grow-only buffer of the map.
+// second pass's parts, and two counters.  rt_gather_radiance keeps it in a grow-only buffer of the map;
+// rt_gather_radiance_static uses the array below, which exists once per GPU for the life of the process.
 #define KNN_SPLIT 64u                                       // parts of a flagged group in the second pass: one query per wave
 static size_t knn_scratch_bytes(uint32_t nq) {
   const size_t blocks = div_up(nq, KNN_LANES);
   return (blocks + blocks * KNN_SPLIT) * 5 + 64;
 }
+#define RT_STATIC_SCRATCH_BYTES ((((size_t)RT_GATHER_STATIC_MAX_QUERIES / KNN_LANES) * (1 + KNN_SPLIT) * 5 + 64 + 255) / 256 * 256)
+static __device__ __align__(256) unsigned char scratch[RT_STATIC_SCRATCH_BYTES];
+// The array's name is only a host-side stand-in; the address of each GPU's copy is looked up once per device
+// (rt_static_scratch_setup, called by rt_init with that device current) and host code uses that pointer from then on.
+#define RT_MAX_DEVICES 64
+static void *g_scratch_ptr[RT_MAX_DEVICES];
+
+int rt_static_scratch_setup(rt_ctx *ctx) {
+  if (ctx->device < 0 || ctx->device >= RT_MAX_DEVICES) return rt_fail(ctx, RT_ERR_NO_DEVICE, "device ordinal %d beyond %d", ctx->device, RT_MAX_DEVICES);
+  if (g_scratch_ptr[ctx->device]) return RT_OK;
+  void *ptr = nullptr;
+  RT_HIP(ctx, hipSetDevice(ctx->device));
+  RT_HIP(ctx, hipGetSymbolAddress((void **)&ptr, HIP_SYMBOL(scratch)));
+  if (!ptr) return rt_fail(ctx, RT_ERR_HIP, "hipGetSymbolAddress returned no address for the static scratch array");
+  g_scratch_ptr[ctx->device] = ptr;
+  return RT_OK;
+}
+
 // The k-nearest gather over device arrays, with its scratch in `ws` (knn_scratch_bytes(nq) bytes of device memory whose
 // old contents do not matter: every word that is read has been written by an earlier kernel of the same call).
 static int gather_knn_run(rt_photon_map *m, const float *dh, uint32_t nq, uint32_t k, float *dout, void *ws) {
@@ -834,6 +853,35 @@ extern "C" int rt_gather_radiance(rt_photon_map *m, const float *hits, uint32_t 
     RT_TRY(gather_knn_run(m, (const float *)dh, nq, k, (float *)dout, m->ws_flags.p));
   }
   RT_TRY(rt_stage_out_end(ctx, rgb_out, (size_t)nq * 12, to));
+  return RT_OK;
+}
+
+// rt_gather_radiance for callers that cannot allocate: nothing here calls hipMalloc / hipFree or any allocating
+// routine.  Inputs and outputs must already be device memory (staging a host array would allocate); the scratch is
+// this GPU's copy of the static array, shared by every call on the GPU -- calls that overlap on one GPU race.
+extern "C" int rt_gather_radiance_static(rt_photon_map *m, const float *hits_dev, uint32_t nq, double r, uint32_t k, float *rgb_dev) {
+  if (!m) return RT_ERR_INVALID;
+  rt_ctx *ctx = m->ctx;
+  if (!rgb_dev || !hits_dev) return rt_fail(ctx, RT_ERR_INVALID, "rt_gather_radiance_static: hits_dev and rgb_dev are required");
+  if (k > 192) return rt_fail(ctx, RT_ERR_INVALID, "k must be <= 192, got %u", k);
+  if (k == 0 && !(r > 0)) return rt_fail(ctx, RT_ERR_INVALID, "rt_gather_radiance_static: need k > 0 or r > 0");
+  if (nq > RT_GATHER_STATIC_MAX_QUERIES)
+    return rt_fail(ctx, RT_ERR_TOO_LARGE, "rt_gather_radiance_static: %u queries exceed the static scratch's limit of %u; split the call or use rt_gather_radiance",
+                   nq, (unsigned)RT_GATHER_STATIC_MAX_QUERIES);
+  if (nq == 0) return RT_OK;
+  RT_HIP(ctx, hipSetDevice(ctx->device));
+  if (!rt_is_device_ptr(hits_dev) || !rt_is_device_ptr(rgb_dev))
+    return rt_fail(ctx, RT_ERR_INVALID, "rt_gather_radiance_static: hits_dev and rgb_dev must be device memory (a host array would need a staging allocation)");
+  void *ws = g_scratch_ptr[ctx->device];
+  if (!ws) return rt_fail(ctx, RT_ERR_HIP, "static scratch of device %d was not set up", ctx->device);
+  if (knn_scratch_bytes(nq) > RT_STATIC_SCRATCH_BYTES) return rt_fail(ctx, RT_ERR_TOO_LARGE, "static scratch too small");      // (never: the limit above covers it)
+  if (k == 0) {
+    RT_LAUNCH(ctx, "gather_radius", k_gather_radius, div_up(nq, 256), 256, m->view(), hits_dev, nq, r, rgb_dev);
+    RT_HIP(ctx, hipGetLastError());
+  } else {
+    RT_TRY(gather_knn_run(m, hits_dev, nq, k, rgb_dev, ws));
+  }
+  RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return RT_OK;
 }
 
