@@ -47,6 +47,7 @@ enum { RT_DOMAIN_RENDER = 0, RT_DOMAIN_EMIT_PHASE1 = 1, RT_DOMAIN_EMIT_PHASE2 = 
 typedef struct rt_ctx rt_ctx;
 typedef struct rt_scene rt_scene;
 typedef struct rt_photon_map rt_photon_map;
+typedef struct rt_photon_lists rt_photon_lists;
 
 /* Flat scene: what `new Scene(ctx)` + `loadPreset` leave in scene.shapes / scene.lights /
  * scene.camera (rayphoton.js:715-727, :1313-1324), flattened by the host. */
@@ -89,6 +90,13 @@ typedef struct rt_params {
   int32_t super_sample_block;   /* SUPER_SAMPLE_BASE ** superSampleScale (rayphoton.js:1574-1596, :1911): rt_trace_tile traces one
                                    jittered sample per block of this many pixels squared and its outputs hold one value per
                                    block, ceil(h / block) rows of ceil(w / block); 0 or 1 = every pixel */
+  /* Multi-GPU tile split (no counterpart in the reference, whose traceTile calls are serial): with band_count > 1
+   * rt_trace_tile traces only the rows of the tile that lie in the bands band_index, band_index + band_count, ... of
+   * band_rows rows each (a power of two, >= 8) -- rank band_index's interleaved share -- and its outputs hold those
+   * rt_band_rows(h, ...) rows only, top to bottom.  Pixels come out exactly as in the undivided tile (RNG streams are
+   * keyed by canvas pixel). */
+  int32_t band_rows, band_count, band_index;
+  int32_t reserved_;
 } rt_params;
 
 typedef struct rt_trace_stats {
@@ -104,7 +112,8 @@ typedef struct rt_trace_stats {
 
 typedef struct rt_emit_stats {
   uint64_t attempts_phase1, attempts_phase2;
-  uint64_t segments;            /* emitPhoton calls */
+  uint64_t segments;            /* emitPhoton calls: of exactly the attempts the sequential loop runs (rt_emit_many*), of the whole
+                                   range (rt_emit_photons, rt_emit_shard) */
   uint32_t n_diffuse, n_caustic;
   int32_t capped;               /* 1 when an attempt cap was hit (rayphoton.js:1365-1368, :1377-1380) */
   int32_t errors;               /* attempts that would throw "photon exited all materials" (rayphoton.js:1489) */
@@ -170,11 +179,55 @@ int rt_emit_photons(rt_scene *scene, const rt_params *p, int phase, uint64_t att
 int rt_emit_many(rt_scene *scene, const rt_params *p, double *diffuse, int64_t *diffuse_attempt,
                  double *caustic, int64_t *caustic_attempt, rt_emit_stats *stats);
 
+/* ---- device-resident emission: the same loop with the photon lists kept in GPU memory ----
+ * photonListDiffuse / photonListCaustic with their caps (storePhoton, rayphoton.js:1346-1352) live in an rt_photon_lists
+ * object on the GPU.  A SHARD is what an attempt range leaves: its stored photons compacted in attempt order as records of
+ * W + 1 32-bit words, W words of payload and a tag = (attempt - tag_base) | (caustic ? 1 << 31 : 0).
+ *   RT_SHARD_FULL   payload = the 11 record values in the working precision (W = 11 for fp32, 22 for fp64)
+ *   RT_SHARD_PACKED payload = position, direction, power * colour as 9 floats (W = 9): the 36-byte photon of the map
+ * Multi-GPU emission (one process per GPU): every rank runs rt_emit_shard on its sub-range of a batch with the batch's
+ * first attempt as tag_base, the shards and their counts are all-gathered in rank order (any transport; the buffers are
+ * plain device memory), and every rank calls rt_lists_apply on the identical merged batch: identical lists, hence
+ * identical photon maps, on every rank.  No counterpart in the reference (its loop is sequential); results are the
+ * sequential loop's for any batch size and rank count because every attempt has its own RNG stream. */
+enum { RT_SHARD_FULL = 0, RT_SHARD_PACKED = 1 };
+typedef struct rt_lists_info {
+  uint32_t n_diffuse, n_caustic;          /* list lengths after the batch */
+  uint32_t batch_diffuse, batch_caustic;  /* stored photons of either kind in the batch */
+  uint32_t taken_diffuse, taken_caustic;  /* ... of which the lists took */
+  int32_t phase_ended;                    /* 1: an attempt of this batch filled the phase's list (rayphoton.js:1361, :1373) */
+  uint64_t last_attempt;                  /* that attempt: the phase's attempt counter is last_attempt + 1 */
+} rt_lists_info;
+/* lists with the caps num_photons_diffuse / num_photons_caustic of p, records in `format` and p->precision */
+int rt_lists_create(rt_ctx *ctx, const rt_params *p, int format, rt_photon_lists **out);
+void rt_lists_free(rt_photon_lists *lists);
+uint32_t rt_lists_record_words(const rt_photon_lists *lists);     /* W */
+/* attempts [begin, end) of one phase -> shard_out (capacity cap records of W + 1 words; end - begin always suffices),
+ * number of stored photons -> *n_out (4 bytes; like shard_out, device or host memory). */
+int rt_emit_shard(rt_scene *scene, const rt_params *p, int phase, uint64_t attempt_begin, uint64_t attempt_end, int format,
+                  uint64_t tag_base, uint32_t cap, uint32_t *shard_out, uint32_t *n_out, rt_emit_stats *stats);
+/* one batch of n_shards shards, shard s at shards + s * stride * (W + 1) words with counts[s] records (device or host
+ * memory), in attempt order: appended to the lists under the reference's caps.  Returns after the (tiny) state read-back. */
+int rt_lists_apply(rt_photon_lists *lists, int phase, uint64_t tag_base, const uint32_t *shards, const uint32_t *counts,
+                   uint32_t n_shards, uint32_t stride, rt_lists_info *info);
+int rt_lists_counts(rt_photon_lists *lists, uint32_t *n_diffuse, uint32_t *n_caustic);
+/* which: 0 diffuse, 1 caustic.  rec_out: n x 11 doubles (RT_SHARD_FULL lists only), attempt_out: n (phase, attempt) pairs;
+ * either may be NULL; device or host memory */
+int rt_lists_export(rt_photon_lists *lists, int which, double *rec_out, int64_t *attempt_out);
+/* the list's records where they are: device pointer, length, W, precision */
+int rt_lists_view(rt_photon_lists *lists, int which, const void **records_dev, uint32_t *n, uint32_t *words, int *precision);
+/* rt_emit_many that leaves the lists on the GPU (*lists_out is set whenever lists exist, also with RT_ERR_ATTEMPT_CAP) */
+int rt_emit_many_lists(rt_scene *scene, const rt_params *p, int format, rt_photon_lists **lists_out, rt_emit_stats *stats);
+
 /* ---- photon map: `new KdTree(photons)` (kdtree.js:1-8, :82-124) ---- */
 /* rec: n x 11 doubles as above.  Positions are rounded to fp32 for the device record
  * (pos 3xf32, dir 3xf32, power*colour 3xf32); the tree is the reference's left-balanced
  * tree over those rounded positions.  n == 0 -> RT_ERR_EMPTY_TREE (kdtree.js:6). */
 int rt_photon_map_build(rt_ctx *ctx, const double *rec, uint32_t n, rt_photon_map **out);
+/* the same from packed photons (n x 9 floats: position, direction, power * colour; device or host memory) and from a
+ * device-resident list (which: 0 diffuse, 1 caustic) without the records leaving the GPU */
+int rt_photon_map_build_packed(rt_ctx *ctx, const float *photons, uint32_t n, rt_photon_map **out);
+int rt_photon_map_build_lists(rt_photon_lists *lists, int which, rt_photon_map **out);
 void rt_photon_map_free(rt_photon_map *map);
 uint32_t rt_photon_map_size(const rt_photon_map *map);
 /* nodes[pos] for pos = 1..n: perm[pos-1] = index of nodes[pos].photon in the input list,
@@ -229,6 +282,7 @@ int rt_gather_radiance_adaptive(rt_photon_map *map, const float *hits, uint32_t 
  * of the context in turn: the outputs are complete after rt_synchronize() (or any later call that returns host data),
  * or, for work the caller puts on rt_stream(), after rt_join(); consecutive frames run back to back without a host
  * round trip in between. */
+uint32_t rt_band_rows(uint32_t height, int band_rows, int band_count, int band_index);
 int rt_trace_tile(rt_scene *scene, const rt_params *p, rt_photon_map *diffuse, rt_photon_map *caustic,
                   int x0, int y0, int w, int h, double *pre_rgba, double *post_rgba, uint8_t *rgba8,
                   rt_trace_stats *stats);

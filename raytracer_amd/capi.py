@@ -16,6 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RT355_LIB") or os.path.join(_HERE, "csrc", "librt355.so")      # override: kernel-variant experiments
 
 PRECISION_F32, PRECISION_F64 = 0, 1
+SHARD_FULL, SHARD_PACKED = 0, 1
 GATHER_STATIC_MAX_QUERIES = 262144
 MODE_PHOTON, MODE_WHITTED = 0, 1
 SCAN_CLOSEST, SCAN_CLOSEST_NOLIGHT, SCAN_ANY = 0, 1, 2
@@ -23,7 +24,9 @@ SCAN_CLOSEST, SCAN_CLOSEST_NOLIGHT, SCAN_ANY = 0, 1, 2
 EXPORTS = [
     "rt_default_params", "rt_init", "rt_shutdown", "rt_last_error", "rt_stream", "rt_synchronize", "rt_join", "rt_set_option", "rt_set_frames_in_flight",
     "rt_profile_enable", "rt_profile_select", "rt_profile_reset", "rt_profile_get", "rt_scene_upload", "rt_scene_free",
-    "rt_intersect_pairs", "rt_intersect", "rt_emit_photons", "rt_emit_many", "rt_photon_map_build",
+    "rt_intersect_pairs", "rt_intersect", "rt_emit_photons", "rt_emit_many", "rt_emit_many_lists", "rt_emit_shard",
+    "rt_lists_create", "rt_lists_free", "rt_lists_record_words", "rt_lists_apply", "rt_lists_counts", "rt_lists_export", "rt_lists_view",
+    "rt_photon_map_build", "rt_photon_map_build_packed", "rt_photon_map_build_lists", "rt_band_rows",
     "rt_photon_map_free", "rt_photon_map_size", "rt_photon_map_nodes", "rt_kd_build", "rt_find_median",
     "rt_kd_radius", "rt_kd_knn", "rt_gather_radiance", "rt_gather_radiance_static", "rt_gather_radiance_adaptive", "rt_trace_tile",
 ]
@@ -49,7 +52,8 @@ class Params(C.Structure):
                 ("caustic_radius", C.c_double), ("standard_lamp_area", C.c_double), ("seed", C.c_uint64),
                 ("use_direct_light", C.c_int32), ("use_photon_maps", C.c_int32), ("precision", C.c_int32),
                 ("mode", C.c_int32), ("shadow_bias", C.c_double), ("epsilon_f32", C.c_double), ("max_bounces", C.c_int32),
-                ("super_sample_block", C.c_int32)]
+                ("super_sample_block", C.c_int32), ("band_rows", C.c_int32), ("band_count", C.c_int32),
+                ("band_index", C.c_int32), ("reserved_", C.c_int32)]
 
 
 class TraceStats(C.Structure):
@@ -61,6 +65,11 @@ class TraceStats(C.Structure):
 class EmitStats(C.Structure):
     _fields_ = [("attempts_phase1", C.c_uint64), ("attempts_phase2", C.c_uint64), ("segments", C.c_uint64),
                 ("n_diffuse", C.c_uint32), ("n_caustic", C.c_uint32), ("capped", C.c_int32), ("errors", C.c_int32)]
+
+
+class ListsInfo(C.Structure):
+    _fields_ = [("n_diffuse", C.c_uint32), ("n_caustic", C.c_uint32), ("batch_diffuse", C.c_uint32), ("batch_caustic", C.c_uint32),
+                ("taken_diffuse", C.c_uint32), ("taken_caustic", C.c_uint32), ("phase_ended", C.c_int32), ("last_attempt", C.c_uint64)]
 
 
 _LIB = None
@@ -81,7 +90,11 @@ def load_library():
         lib.rt_find_median.restype = C.c_uint32
         lib.rt_photon_map_size.restype = C.c_uint32
         lib.rt_photon_map_size.argtypes = [C.c_void_p]
-        for name in ("rt_shutdown", "rt_scene_free", "rt_photon_map_free"):
+        lib.rt_lists_record_words.restype = C.c_uint32
+        lib.rt_lists_record_words.argtypes = [C.c_void_p]
+        lib.rt_band_rows.restype = C.c_uint32
+        lib.rt_band_rows.argtypes = [C.c_uint32, C.c_int, C.c_int, C.c_int]
+        for name in ("rt_shutdown", "rt_scene_free", "rt_photon_map_free", "rt_lists_free"):
             getattr(lib, name).argtypes = [C.c_void_p]
             getattr(lib, name).restype = None
         _LIB = lib
@@ -212,6 +225,16 @@ class Context:
     def photon_map(self, rec) -> "PhotonMap":
         return PhotonMap(self, rec)
 
+    def photon_map_packed(self, photons) -> "PhotonMap":
+        """photons: (n, 9) float32 -- position, direction, power * colour -- numpy array or device tensor"""
+        return PhotonMap(self, photons, packed=True)
+
+    def lists(self, params, fmt=SHARD_PACKED) -> "PhotonLists":
+        return PhotonLists(self, params, fmt)
+
+    def band_rows(self, height, band_rows, band_count, band_index):
+        return self.lib.rt_band_rows(C.c_uint32(height), band_rows, band_count, band_index)
+
 
 class Scene:
     def __init__(self, ctx: Context, flat: FlatScene):
@@ -265,6 +288,8 @@ class Scene:
         h = self.flat.height if h is None else h
         b = max(1, params.super_sample_block)
         wo, ho = -(-w // b), -(-h // b)                       # one output value per block
+        if params.band_count > 1:                             # this rank's row bands only
+            ho = self.ctx.band_rows(h, params.band_rows, params.band_count, params.band_index)
         pre = out_pre if out_pre is not None else (np.empty((ho, wo, 4), np.float64) if "pre" in want else None)
         post = out_post if out_post is not None else (np.empty((ho, wo, 4), np.float64) if "post" in want else None)
         rgba8 = out_rgba8 if out_rgba8 is not None else (np.empty((ho, wo, 4), np.uint8) if "rgba8" in want else None)
@@ -287,6 +312,25 @@ class Scene:
         k = n.value
         return rec[:k], att[:k], kind[:k], {f: getattr(st, f) for f, _ in EmitStats._fields_}
 
+    def emit_shard(self, params, phase, a0, a1, fmt, tag_base, shard, n_out, cap=None, stats=False):
+        """attempts [a0, a1) -> shard (uint32/float32 array or device tensor of >= cap * (W + 1) words), count -> n_out"""
+        st = EmitStats()
+        cap = max(a1 - a0, 1) if cap is None else cap
+        self.ctx.check(self.ctx.lib.rt_emit_shard(self.h, C.byref(params), C.c_int(phase), C.c_uint64(a0), C.c_uint64(a1), C.c_int(fmt),
+                                                  C.c_uint64(tag_base), C.c_uint32(cap), _ptr(shard), _ptr(n_out), C.byref(st) if stats else None))
+        return {f: getattr(st, f) for f, _ in EmitStats._fields_} if stats else None
+
+    def emit_many_lists(self, params, fmt=SHARD_PACKED, strict=True):
+        """emitManyPhotons with the lists left on the GPU: (PhotonLists, stats)"""
+        h = C.c_void_p()
+        st = EmitStats()
+        rc = self.ctx.lib.rt_emit_many_lists(self.h, C.byref(params), C.c_int(fmt), C.byref(h), C.byref(st))
+        if rc != 0 and (strict or not h.value):
+            self.ctx.check(rc)
+        stats = {f: getattr(st, f) for f, _ in EmitStats._fields_}
+        stats["rc"] = rc
+        return PhotonLists(self.ctx, params, fmt, handle=h), stats
+
     def emit_many(self, params, strict=True):
         nd, nc = params.num_photons_diffuse, params.num_photons_caustic
         diffuse = np.zeros((nd, 11), np.float64)
@@ -303,16 +347,64 @@ class Scene:
                     caustic_attempt=ca[:st.n_caustic], stats=stats)
 
 
-class PhotonMap:
-    """`new KdTree(photons)`: rec is (n, 11) float64 records origin3 dir3 power rgba."""
+class PhotonLists:
+    """photonListDiffuse / photonListCaustic under construction, resident on the GPU (rt_photon_lists)."""
 
-    def __init__(self, ctx: Context, rec):
+    def __init__(self, ctx: Context, params, fmt=SHARD_PACKED, handle=None):
+        self.ctx, self.fmt = ctx, fmt
+        if handle is None:
+            handle = C.c_void_p()
+            ctx.check(ctx.lib.rt_lists_create(ctx.h, C.byref(params), C.c_int(fmt), C.byref(handle)))
+        self.h = handle
+        self.words = ctx.lib.rt_lists_record_words(self.h)
+
+    def close(self):
+        if getattr(self, "h", None) and self.ctx.h:
+            self.ctx.lib.rt_lists_free(self.h)
+        self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def apply(self, phase, tag_base, shards, counts, n_shards, stride):
+        info = ListsInfo()
+        self.ctx.check(self.ctx.lib.rt_lists_apply(self.h, C.c_int(phase), C.c_uint64(tag_base), _ptr(shards), _ptr(counts),
+                                                   C.c_uint32(n_shards), C.c_uint32(stride), C.byref(info)))
+        return {f: getattr(info, f) for f, _ in ListsInfo._fields_}
+
+    def counts(self):
+        a, b = C.c_uint32(), C.c_uint32()
+        self.ctx.check(self.ctx.lib.rt_lists_counts(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def export(self, which, records=True):
+        """(records (n, 11) float64 or None, (phase, attempt) pairs (n, 2) int64) of list `which` (0 diffuse, 1 caustic)"""
+        n = self.counts()[which]
+        rec = np.zeros((n, 11), np.float64) if records else None
+        att = np.zeros((n, 2), np.int64)
+        self.ctx.check(self.ctx.lib.rt_lists_export(self.h, C.c_int(which), _ptr(rec), _ptr(att)))
+        return rec, att
+
+    def photon_map(self, which) -> "PhotonMap":
+        h = C.c_void_p()
+        self.ctx.check(self.ctx.lib.rt_photon_map_build_lists(self.h, C.c_int(which), C.byref(h)))
+        return PhotonMap(self.ctx, None, handle=h, n=self.counts()[which])
+
+
+class PhotonMap:
+    """`new KdTree(photons)`: rec is (n, 11) float64 records origin3 dir3 power rgba (or, packed, (n, 9) float32)."""
+
+    def __init__(self, ctx: Context, rec, packed=False, handle=None, n=0):
         self.ctx = ctx
+        if handle is not None:
+            self.h, self.n = handle, n
+            return
         if isinstance(rec, np.ndarray):
-            rec = _c(rec, np.float64)
+            rec = _c(rec, np.float32 if packed else np.float64)
         n = rec.shape[0]
         h = C.c_void_p()
-        ctx.check(ctx.lib.rt_photon_map_build(ctx.h, _ptr(rec) if n else C.c_void_p(None), C.c_uint32(n), C.byref(h)))
+        build = ctx.lib.rt_photon_map_build_packed if packed else ctx.lib.rt_photon_map_build
+        ctx.check(build(ctx.h, _ptr(rec) if n else C.c_void_p(None), C.c_uint32(n), C.byref(h)))
         self.h = h
         self.n = n
 

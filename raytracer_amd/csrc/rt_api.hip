@@ -60,6 +60,7 @@ void rt_default_params(rt_params *p) {
   p->diffuse_radius = 0.40; p->caustic_radius = 0.15; p->standard_lamp_area = 100;
   p->seed = 12345; p->use_direct_light = 1; p->use_photon_maps = 1;
   p->precision = RT_PRECISION_F32; p->mode = RT_MODE_PHOTON; p->shadow_bias = 0; p->epsilon_f32 = 1e-4; p->max_bounces = 4096; p->super_sample_block = 0;
+  p->band_rows = 0; p->band_count = 0; p->band_index = 0;
 }
 
 int rt_init(const int *device_ids, int n, rt_ctx **out) {
@@ -101,6 +102,17 @@ int rt_init(const int *device_ids, int n, rt_ctx **out) {
   if (rc != RT_OK) { g_init_error = ctx->err; rt_shutdown(ctx); return rc; }
   *out = ctx;
   return RT_OK;
+}
+
+// rows of a tile of `height` rows that fall into the bands index, index + count, index + 2 count, ... of band_rows rows
+uint32_t rt_band_rows(uint32_t height, int band_rows, int band_count, int band_index) {
+  if (band_count <= 1) return height;
+  if (band_rows <= 0 || band_index < 0 || band_index >= band_count) return 0;
+  const uint32_t period = (uint32_t)band_rows * (uint32_t)band_count, first = (uint32_t)band_rows * (uint32_t)band_index;
+  const uint32_t full = height / period, rest = height % period;
+  uint32_t rows = full * (uint32_t)band_rows;
+  if (rest > first) rows += std::min<uint32_t>(rest - first, (uint32_t)band_rows);
+  return rows;
 }
 
 int rt_set_option(rt_ctx *ctx, const char *name, double value) {
@@ -594,7 +606,14 @@ int rt_trace_tile(rt_scene *sc, const rt_params *p, rt_photon_map *diffuse, rt_p
   RT_HIP(ctx, hipSetDevice(ctx->device));
   if (p->super_sample_block < 0 || p->super_sample_block > 65536) return rt_fail(ctx, RT_ERR_INVALID, "super_sample_block must be in 0..65536");
   const int blk = p->super_sample_block > 1 ? p->super_sample_block : 1;
-  const size_t npx = (size_t)((w + blk - 1) / blk) * (size_t)((h + blk - 1) / blk);      // outputs hold one value per block
+  size_t npx = (size_t)((w + blk - 1) / blk) * (size_t)((h + blk - 1) / blk);      // outputs hold one value per block
+  if (p->band_count > 1) {
+    if (blk > 1) return rt_fail(ctx, RT_ERR_INVALID, "row bands and super_sample_block cannot be combined");
+    if (p->band_rows < 8 || p->band_rows > 4096 || (p->band_rows & (p->band_rows - 1)) || p->band_index < 0 || p->band_index >= p->band_count)
+      return rt_fail(ctx, RT_ERR_INVALID, "row bands: band_rows must be a power of two in 8..4096 and 0 <= band_index < band_count");
+    npx = (size_t)w * rt_band_rows((uint32_t)h, p->band_rows, p->band_count, p->band_index);      // outputs hold this rank's rows only
+    if (npx == 0) return RT_OK;
+  }
   DevMem t1, t2, t3; void *pre, *post, *r8;
   RT_TRY(rt_stage_out_begin(ctx, pre_rgba, npx * 32, t1, &pre));
   RT_TRY(rt_stage_out_begin(ctx, post_rgba, npx * 32, t2, &post));
@@ -677,83 +696,233 @@ int rt_emit_photons(rt_scene *sc, const rt_params *p, int phase, uint64_t attemp
   return rt_stage_out_end(ctx, kind_out, (size_t)*n_out, t3);
 }
 
-// emitManyPhotons (rayphoton.js:1354-1383) in batches.  A batch's stored photons come back as two
-// attempt-ordered lists; list caps are then applied exactly as the sequential loop would:
-// phase 1 ends with the attempt that stores the N_D-th diffuse photon, caustic photons of
-// phase-1 attempts up to that one are kept (up to N_C), phase 2 stops at the N_C-th caustic.
-int rt_emit_many(rt_scene *sc, const rt_params *p, double *diffuse, int64_t *diffuse_attempt, double *caustic,
-                 int64_t *caustic_attempt, rt_emit_stats *stats) {
-  if (!sc || !p) return RT_ERR_INVALID;
+// ------------------------------------------------------------------ device-resident photon lists
+// photonListDiffuse / photonListCaustic (rayphoton.js:1346-1352) while they are being filled: records, the attempt that
+// stored each of them, and the caps, all in device memory.  Shards of stored photons (rt_emit_shard; rt_emit.h) are fed
+// to rt_lists_apply batch by batch in attempt order; the host sees eight words of state per batch and nothing else.
+struct rt_photon_lists {
+  rt_ctx *ctx = nullptr;
+  int format = RT_SHARD_FULL, precision = RT_PRECISION_F32;
+  uint32_t W = 0, cap_d = 0, cap_c = 0;
+  DevMem list[2], att[2], blocks, state;
+  ListsState host = {};
+};
+
+static uint32_t lists_words(int format, int precision) {
+  return format == RT_SHARD_PACKED ? 9u : (precision == RT_PRECISION_F64 ? 22u : 11u);
+}
+
+int rt_lists_create(rt_ctx *ctx, const rt_params *p, int format, rt_photon_lists **out) {
+  if (!ctx || !p || !out) return RT_ERR_INVALID;
+  *out = nullptr;
+  if (format != RT_SHARD_FULL && format != RT_SHARD_PACKED) return rt_fail(ctx, RT_ERR_INVALID, "unknown record format %d", format);
+  RT_HIP(ctx, hipSetDevice(ctx->device));
+  rt_photon_lists *L = new rt_photon_lists();
+  L->ctx = ctx; L->format = format; L->precision = p->precision == RT_PRECISION_F64 ? RT_PRECISION_F64 : RT_PRECISION_F32;
+  L->W = lists_words(format, L->precision); L->cap_d = p->num_photons_diffuse; L->cap_c = p->num_photons_caustic;
+  hipError_t e = L->list[0].alloc((size_t)L->cap_d * L->W * 4);
+  if (e == hipSuccess) e = L->list[1].alloc((size_t)L->cap_c * L->W * 4);
+  if (e == hipSuccess) e = L->att[0].alloc((size_t)L->cap_d * 8);
+  if (e == hipSuccess) e = L->att[1].alloc((size_t)L->cap_c * 8);
+  if (e == hipSuccess) e = L->state.alloc(sizeof(ListsState));
+  if (e == hipSuccess) e = hipMemsetAsync(L->state.p, 0, sizeof(ListsState), ctx->stream);
+  if (e != hipSuccess) { delete L; return rt_fail(ctx, RT_ERR_HIP, "photon list allocation failed: %s", hipGetErrorString(e)); }
+  *out = L;
+  return RT_OK;
+}
+void rt_lists_free(rt_photon_lists *L) { if (L) { (void)hipSetDevice(L->ctx->device); delete L; } }
+uint32_t rt_lists_record_words(const rt_photon_lists *L) { return L ? L->W : 0; }
+rt_ctx *rt_lists_ctx(rt_photon_lists *L) { return L->ctx; }
+
+int rt_lists_apply(rt_photon_lists *L, int phase, uint64_t tag_base, const uint32_t *shards, const uint32_t *counts, uint32_t n_shards,
+                   uint32_t stride, rt_lists_info *info) {
+  if (!L) return RT_ERR_INVALID;
+  rt_ctx *ctx = L->ctx;
+  if (phase != 1 && phase != 2) return rt_fail(ctx, RT_ERR_INVALID, "phase must be 1 or 2");
+  if (!shards || !counts || n_shards == 0 || stride == 0) return rt_fail(ctx, RT_ERR_INVALID, "rt_lists_apply: shards, counts, n_shards and stride are required");
+  if ((uint64_t)n_shards * stride > 0x7FFFFFFFull) return rt_fail(ctx, RT_ERR_TOO_LARGE, "batch of %u x %u records is too large", n_shards, stride);
+  RT_HIP(ctx, hipSetDevice(ctx->device));
+  DevMem ts, tc; const void *dsh, *dct;
+  RT_TRY(rt_stage_in(ctx, shards, (size_t)n_shards * stride * (L->W + 1) * 4, ts, &dsh));
+  RT_TRY(rt_stage_in(ctx, counts, (size_t)n_shards * 4, tc, &dct));
+  const uint32_t total = n_shards * stride, blocks = div_up(total, 256);
+  RT_HIP(ctx, L->blocks.reserve(((size_t)blocks * 2 + 2) * 4));
+  uint32_t *bd = L->blocks.as<uint32_t>(), *bcq = bd + blocks, *totals = bcq + blocks;
+  ListsState *st = L->state.as<ListsState>();
+  RT_HIP(ctx, hipMemsetAsync(&st->last_tag, 0xFF, 8, ctx->stream));        // last_tag = pad_ = 0xFFFFFFFF: no attempt has ended the phase
+  RT_LAUNCH(ctx, "lists_count", k_lists_count, blocks, 256, (const uint32_t *)dsh, (const uint32_t *)dct, n_shards, stride, L->W, bd, bcq);
+  RT_LAUNCH(ctx, "lists_scan", k_scan_blocks, 1, 1024, bd, blocks, totals, (const uint32_t *)nullptr);
+  RT_LAUNCH(ctx, "lists_scan", k_scan_blocks, 1, 1024, bcq, blocks, totals + 1, (const uint32_t *)nullptr);
+  RT_LAUNCH(ctx, "lists_take", k_lists_take<0>, blocks, 256, (const uint32_t *)dsh, (const uint32_t *)dct, n_shards, stride, L->W, (const uint32_t *)bd,
+            (const uint32_t *)bcq, (const uint32_t *)totals, phase, L->cap_d, L->cap_c, (unsigned long long)tag_base, st, L->list[0].as<uint32_t>(),
+            L->att[0].as<long long>(), L->list[1].as<uint32_t>(), L->att[1].as<long long>());
+  if (phase == 1)
+    RT_LAUNCH(ctx, "lists_take", k_lists_take<1>, blocks, 256, (const uint32_t *)dsh, (const uint32_t *)dct, n_shards, stride, L->W, (const uint32_t *)bd,
+              (const uint32_t *)bcq, (const uint32_t *)totals, phase, L->cap_d, L->cap_c, (unsigned long long)tag_base, st, L->list[0].as<uint32_t>(),
+              L->att[0].as<long long>(), L->list[1].as<uint32_t>(), L->att[1].as<long long>());
+  RT_LAUNCH(ctx, "lists_finish", k_lists_finish, 1, 1, (const uint32_t *)totals, phase, L->cap_d, L->cap_c, st);
+  RT_HIP(ctx, hipGetLastError());
+  static_assert(sizeof(ListsState) <= 64, "the state goes through the context's pinned words");
+  RT_HIP(ctx, hipMemcpyAsync(ctx->pinned, st, sizeof(ListsState), hipMemcpyDeviceToHost, ctx->stream));
+  RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  memcpy(&L->host, ctx->pinned, sizeof(ListsState));
+  if (info) {
+    info->n_diffuse = L->host.n_d; info->n_caustic = L->host.n_c; info->batch_diffuse = L->host.total_d; info->batch_caustic = L->host.total_c;
+    info->taken_diffuse = L->host.take_d; info->taken_caustic = L->host.take_c;
+    info->phase_ended = L->host.last_tag != 0xFFFFFFFFu;
+    info->last_attempt = info->phase_ended ? tag_base + L->host.last_tag : 0;
+  }
+  return RT_OK;
+}
+
+int rt_lists_counts(rt_photon_lists *L, uint32_t *n_diffuse, uint32_t *n_caustic) {
+  if (!L) return RT_ERR_INVALID;
+  if (n_diffuse) *n_diffuse = L->host.n_d;
+  if (n_caustic) *n_caustic = L->host.n_c;
+  return RT_OK;
+}
+
+// the records of one list as the boundary's 11 doubles (full format) and their (phase, attempt) pairs
+int rt_lists_export(rt_photon_lists *L, int which, double *rec_out, int64_t *attempt_out) {
+  if (!L || (which != 0 && which != 1)) return RT_ERR_INVALID;
+  rt_ctx *ctx = L->ctx;
+  if (L->format != RT_SHARD_FULL && rec_out) return rt_fail(ctx, RT_ERR_INVALID, "rt_lists_export: packed lists hold no full records");
+  const uint32_t n = which == 0 ? L->host.n_d : L->host.n_c;
+  if (n == 0) return RT_OK;
+  RT_HIP(ctx, hipSetDevice(ctx->device));
+  DevMem t1, t2; void *drec, *datt;
+  RT_TRY(rt_stage_out_begin(ctx, rec_out, (size_t)n * 88, t1, &drec));
+  RT_TRY(rt_stage_out_begin(ctx, attempt_out, (size_t)n * 16, t2, &datt));
+  if (L->precision == RT_PRECISION_F64 || L->format == RT_SHARD_PACKED)
+    RT_LAUNCH(ctx, "lists_export", k_lists_export<double>, div_up(n, 256), 256, (const uint32_t *)L->list[which].p, (const long long *)L->att[which].p, n,
+              (double *)drec, (long long *)datt);
+  else
+    RT_LAUNCH(ctx, "lists_export", k_lists_export<float>, div_up(n, 256), 256, (const uint32_t *)L->list[which].p, (const long long *)L->att[which].p, n,
+              (double *)drec, (long long *)datt);
+  RT_HIP(ctx, hipGetLastError());
+  RT_TRY(rt_stage_out_end(ctx, rec_out, (size_t)n * 88, t1));
+  return rt_stage_out_end(ctx, attempt_out, (size_t)n * 16, t2);
+}
+
+int rt_lists_view(rt_photon_lists *L, int which, const void **records_dev, uint32_t *n, uint32_t *words, int *precision) {
+  if (!L || (which != 0 && which != 1)) return RT_ERR_INVALID;
+  if (records_dev) *records_dev = L->list[which].p;
+  if (n) *n = which == 0 ? L->host.n_d : L->host.n_c;
+  if (words) *words = L->W;
+  if (precision) *precision = L->precision;
+  return RT_OK;
+}
+
+// attempts [begin, end) of one phase on this GPU, left as a shard (rt_emit.h) in attempt order
+int rt_emit_shard(rt_scene *sc, const rt_params *p, int phase, uint64_t attempt_begin, uint64_t attempt_end, int format, uint64_t tag_base,
+                  uint32_t cap, uint32_t *shard_out, uint32_t *n_out_dev, rt_emit_stats *stats) {
+  if (!sc || !p || !shard_out || !n_out_dev) return RT_ERR_INVALID;
+  rt_ctx *ctx = sc->ctx;
+  if (phase != 1 && phase != 2) return rt_fail(ctx, RT_ERR_INVALID, "phase must be 1 or 2");
+  if (format != RT_SHARD_FULL && format != RT_SHARD_PACKED) return rt_fail(ctx, RT_ERR_INVALID, "unknown record format %d", format);
+  if (attempt_end < attempt_begin || attempt_end - attempt_begin > 0x7FFFFFFFull) return rt_fail(ctx, RT_ERR_INVALID, "bad attempt range");
+  if (attempt_begin < tag_base || attempt_end - tag_base > 0x7FFFFFFFull) return rt_fail(ctx, RT_ERR_INVALID, "attempt range outside [tag_base, tag_base + 2^31)");
+  if (sc->d32.n_lights == 0) return rt_fail(ctx, RT_ERR_INVALID, "No lights! Can't emit photons.");     // rayphoton.js:1355-1358
+  RT_HIP(ctx, hipSetDevice(ctx->device));
+  const uint32_t count = (uint32_t)(attempt_end - attempt_begin);
+  const uint32_t W = lists_words(format, p->precision);
+  DevMem t1, t2; void *dsh, *dn;
+  RT_TRY(rt_stage_out_begin(ctx, shard_out, (size_t)cap * (W + 1) * 4, t1, &dsh));
+  RT_TRY(rt_stage_out_begin(ctx, n_out_dev, 4, t2, &dn));
+  if (count == 0) { RT_HIP(ctx, hipMemsetAsync(dn, 0, 4, ctx->stream)); }
+  else {
+    RT_TRY(pl_emit_counters(sc, true, nullptr, nullptr));
+    RT_TRY(emit_batch(sc, p, phase, attempt_begin, count));
+    if (p->precision == RT_PRECISION_F64) RT_TRY(pl_emit_shard<double>(sc, count, format, (uint32_t)(attempt_begin - tag_base), cap, (uint32_t *)dsh, (uint32_t *)dn));
+    else RT_TRY(pl_emit_shard<float>(sc, count, format, (uint32_t)(attempt_begin - tag_base), cap, (uint32_t *)dsh, (uint32_t *)dn));
+  }
+  if (stats) {
+    memset(stats, 0, sizeof *stats);
+    uint64_t seg = 0, err = 0;
+    if (count) RT_TRY(pl_emit_counters(sc, true, &seg, &err));
+    stats->segments = seg; stats->errors = (int32_t)err;
+    if (phase == 1) stats->attempts_phase1 = count; else stats->attempts_phase2 = count;
+  }
+  RT_TRY(rt_stage_out_end(ctx, shard_out, (size_t)cap * (W + 1) * 4, t1));
+  return rt_stage_out_end(ctx, n_out_dev, 4, t2);
+}
+
+// emitManyPhotons (rayphoton.js:1354-1383) in batches on one GPU.  Every batch's stored photons are compacted into a
+// shard and the list caps are applied on the device exactly as the sequential loop would: phase 1 ends with the attempt
+// that stores the N_D-th diffuse photon, caustic photons of phase-1 attempts up to that one are kept (up to N_C), phase 2
+// stops at the N_C-th caustic.  Per batch the host reads back eight words.
+static int emit_many_lists(rt_scene *sc, const rt_params *p, int format, rt_photon_lists **lists_out, rt_emit_stats *stats) {
   rt_ctx *ctx = sc->ctx;
   rt_emit_stats st; memset(&st, 0, sizeof st);
   if (stats) *stats = st;
+  *lists_out = nullptr;
   if (sc->d32.n_lights == 0) return rt_fail(ctx, RT_ERR_INVALID, "No lights! Can't emit photons.");
   const uint32_t ND = p->num_photons_diffuse, NC = p->num_photons_caustic;
   RT_HIP(ctx, hipSetDevice(ctx->device));
-  DevMem t1, t2, bd, bc, bda, bca; void *drec, *crec;
-  RT_TRY(rt_stage_out_begin(ctx, diffuse, (size_t)ND * 88, t1, &drec));
-  RT_TRY(rt_stage_out_begin(ctx, caustic, (size_t)NC * 88, t2, &crec));
-  if (!drec) { RT_HIP(ctx, t1.alloc((size_t)ND * 88)); drec = t1.p; }
-  if (!crec) { RT_HIP(ctx, t2.alloc((size_t)NC * 88)); crec = t2.p; }
-  std::vector<int64_t> d_att, c_att;     // (phase, attempt) pairs of the accepted photons
+  rt_photon_lists *L = nullptr;
+  RT_TRY(rt_lists_create(ctx, p, format, &L));
+  struct Guard { rt_photon_lists *&l; bool keep = false; ~Guard() { if (!keep) { rt_lists_free(l); l = nullptr; } } } guard{ L };
   RT_TRY(pl_emit_counters(sc, true, nullptr, nullptr));
+  if (!sc->ws_misc.p) { RT_HIP(ctx, sc->ws_misc.alloc(256)); }
+  unsigned long long *seg_exact = (unsigned long long *)((char *)sc->ws_misc.p + 64);
+  RT_HIP(ctx, hipMemsetAsync(sc->ws_misc.p, 0, 256, ctx->stream));
   uint32_t nd = 0, nc = 0;
-  int rc = RT_OK;
+  const uint32_t W = L->W;
   for (int phase = 1; phase <= 2 && !st.capped; phase++) {
     uint64_t attempt = 0;
     const uint64_t cap = 100ull * (phase == 1 ? ND : NC);
     while (phase == 1 ? nd < ND : nc < NC) {
       const uint32_t need = phase == 1 ? ND - nd : NC - nc;
-      uint64_t batch = std::min<uint64_t>(std::max<uint64_t>(4ull * need, 65536), 4u << 20);
+      uint64_t batch = std::min<uint64_t>(std::max<uint64_t>(4ull * need, 65536), 8u << 20);
       batch = std::min<uint64_t>(batch, cap + 1 - attempt);
       const uint32_t count = (uint32_t)batch;
       RT_TRY(emit_batch(sc, p, phase, attempt, count));
-      // attempt-ordered lists of this batch
-      RT_HIP(ctx, bd.reserve((size_t)count * 88)); RT_HIP(ctx, bc.reserve((size_t)count * 88));
-      RT_HIP(ctx, bda.reserve((size_t)count * 8)); RT_HIP(ctx, bca.reserve((size_t)count * 8));
-      uint32_t bnd = 0, bnc = 0;
-      RT_TRY(emit_compact(sc, p, count, 1, attempt, 0, count, bd.as<double>(), bda.as<int64_t>(), nullptr, &bnd));
-      RT_TRY(emit_compact(sc, p, count, 2, attempt, 0, count, bc.as<double>(), bca.as<int64_t>(), nullptr, &bnc));
-      std::vector<int64_t> hda(bnd), hca(bnc);
-      if (bnd) RT_HIP(ctx, hipMemcpy(hda.data(), bda.p, (size_t)bnd * 8, hipMemcpyDeviceToHost));
-      if (bnc) RT_HIP(ctx, hipMemcpy(hca.data(), bca.p, (size_t)bnc * 8, hipMemcpyDeviceToHost));
-      uint64_t last_attempt = attempt + count - 1;      // last attempt of this batch the sequential loop would run
-      uint32_t take_d = 0, take_c = 0;
-      if (phase == 1) {
-        take_d = std::min<uint32_t>(bnd, ND - nd);
-        if (nd + take_d == ND) last_attempt = (uint64_t)hda[take_d - 1];
-        uint32_t upto = (uint32_t)(std::upper_bound(hca.begin(), hca.end(), (int64_t)last_attempt) - hca.begin());
-        take_c = std::min<uint32_t>(upto, NC - nc);
-      } else {
-        take_c = std::min<uint32_t>(bnc, NC - nc);
-        if (nc + take_c == NC) last_attempt = (uint64_t)hca[take_c - 1];
-        // non-caustic absorptions of phase 2 would go to the diffuse list, which is already full
-      }
-      if (take_d) RT_HIP(ctx, hipMemcpyAsync((double *)drec + (size_t)nd * 11, bd.p, (size_t)take_d * 88, hipMemcpyDeviceToDevice, ctx->stream));
-      if (take_c) RT_HIP(ctx, hipMemcpyAsync((double *)crec + (size_t)nc * 11, bc.p, (size_t)take_c * 88, hipMemcpyDeviceToDevice, ctx->stream));
-      RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-      for (uint32_t i = 0; i < take_d; i++) { d_att.push_back(phase); d_att.push_back(hda[i]); }
-      for (uint32_t i = 0; i < take_c; i++) { c_att.push_back(phase); c_att.push_back(hca[i]); }
-      nd += take_d; nc += take_c;
+      RT_HIP(ctx, sc->ws_emit_shard.reserve((size_t)count * (W + 1) * 4 + 16));
+      uint32_t *shard = sc->ws_emit_shard.as<uint32_t>(), *n_dev = shard + (size_t)count * (W + 1);
+      if (p->precision == RT_PRECISION_F64) RT_TRY(pl_emit_shard<double>(sc, count, format, 0u, count, shard, n_dev));
+      else RT_TRY(pl_emit_shard<float>(sc, count, format, 0u, count, shard, n_dev));
+      rt_lists_info info;
+      RT_TRY(rt_lists_apply(L, phase, attempt, shard, n_dev, 1, count, &info));
+      nd = info.n_diffuse; nc = info.n_caustic;
+      const uint64_t last_attempt = info.phase_ended ? info.last_attempt : attempt + count - 1;    // last attempt the sequential loop would run
+      RT_LAUNCH(ctx, "sum_segments", k_sum_segments, 256, 256, (const uint8_t *)sc->ws_emit_seg.p, (uint32_t)(last_attempt - attempt + 1), seg_exact);
       attempt = last_attempt + 1;
       if (attempt > cap) { st.capped = 1; break; }      // `attempt++; if (attempt > 100 * N) return` (:1364-1368)
     }
     if (phase == 1) st.attempts_phase1 = attempt; else st.attempts_phase2 = attempt;
   }
   uint64_t seg = 0, err = 0;
+  unsigned long long exact = 0;
+  RT_HIP(ctx, hipMemcpyAsync(&exact, seg_exact, 8, hipMemcpyDeviceToHost, ctx->stream));
   RT_TRY(pl_emit_counters(sc, true, &seg, &err));
-  st.segments = seg; st.errors = (int32_t)err; st.n_diffuse = nd; st.n_caustic = nc;
+  st.segments = exact; st.errors = (int32_t)err; st.n_diffuse = nd; st.n_caustic = nc;
   if (stats) *stats = st;
-  if (diffuse_attempt) memcpy(diffuse_attempt, d_att.data(), d_att.size() * 8);
-  if (caustic_attempt) memcpy(caustic_attempt, c_att.data(), c_att.size() * 8);
-  if (diffuse) RT_TRY(rt_stage_out_end(ctx, diffuse, (size_t)nd * 88, t1));
-  if (caustic) RT_TRY(rt_stage_out_end(ctx, caustic, (size_t)nc * 88, t2));
+  guard.keep = true;
+  *lists_out = L;
   // The reference throws here (rayphoton.js:1489).  The fp64 build mirrors that; in fp32 the rim gaps between a
   // cylinder and its caps are epsilon_f32 wide, a photon can slip through one and later meet the inside of the
   // glass with an empty stack: such attempts are dropped and only counted (stats.errors).
-  if (err && p->precision == RT_PRECISION_F64) rc = rt_fail(ctx, RT_ERR_MATERIAL_STACK, "photon exited all materials? check consistency of objects? (%llu attempts)",
-                        (unsigned long long)err);                                  // rayphoton.js:1489
-  else if (st.capped) rc = rt_fail(ctx, RT_ERR_ATTEMPT_CAP, "I tried many times but only created %u diffuse / %u caustic photons.", nd, nc);
-  return rc;
+  if (err && p->precision == RT_PRECISION_F64)
+    return rt_fail(ctx, RT_ERR_MATERIAL_STACK, "photon exited all materials? check consistency of objects? (%llu attempts)", (unsigned long long)err);   // rayphoton.js:1489
+  if (st.capped) return rt_fail(ctx, RT_ERR_ATTEMPT_CAP, "I tried many times but only created %u diffuse / %u caustic photons.", nd, nc);
+  return RT_OK;
+}
+
+int rt_emit_many_lists(rt_scene *sc, const rt_params *p, int format, rt_photon_lists **lists_out, rt_emit_stats *stats) {
+  if (!sc || !p || !lists_out) return RT_ERR_INVALID;
+  if (format != RT_SHARD_FULL && format != RT_SHARD_PACKED) return rt_fail(sc->ctx, RT_ERR_INVALID, "unknown record format %d", format);
+  return emit_many_lists(sc, p, format, lists_out, stats);
+}
+
+int rt_emit_many(rt_scene *sc, const rt_params *p, double *diffuse, int64_t *diffuse_attempt, double *caustic,
+                 int64_t *caustic_attempt, rt_emit_stats *stats) {
+  if (!sc || !p) return RT_ERR_INVALID;
+  rt_photon_lists *L = nullptr;
+  const int rc = emit_many_lists(sc, p, RT_SHARD_FULL, &L, stats);
+  if (!L) return rc;
+  int rc2 = rt_lists_export(L, 0, diffuse, diffuse_attempt);
+  if (rc2 == RT_OK) rc2 = rt_lists_export(L, 1, caustic, caustic_attempt);
+  rt_lists_free(L);
+  return rc != RT_OK ? rc : rc2;
 }
 

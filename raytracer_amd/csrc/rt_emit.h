@@ -20,7 +20,7 @@ struct EmitCounters { unsigned long long segments, errors, overflows; };
 
 template <typename T, bool LDS>
 __global__ void __launch_bounds__(256) k_emit(DevScene<T> S, EmitCfg C, int phase, unsigned long long a0, uint32_t count,
-                                              uint8_t *kind, T *rec, EmitCounters *ctr) {
+                                              uint8_t *kind, T *rec, uint8_t *nseg, EmitCounters *ctr) {
   extern __shared__ __align__(16) unsigned char rt_lds[];
   const ScanSrc<T> G = LDS ? stage_scene_lds<T>(S, rt_lds) : global_scan_src<T>(S);
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -86,6 +86,7 @@ __global__ void __launch_bounds__(256) k_emit(DevScene<T> S, EmitCfg C, int phas
       break;
     }
     kind[i] = (uint8_t)stored;
+    nseg[i] = (uint8_t)(segments < 255 ? segments : 255);
   }
   // one atomic per wave for the statistics
   for (int off = 32; off > 0; off >>= 1) {
@@ -132,4 +133,157 @@ __global__ void __launch_bounds__(256) k_compact_scatter(const uint8_t *kind, co
   for (int c = 0; c < RT_REC_STRIDE; c++) o[c] = (double)r[c];
   if (out_attempt) out_attempt[dst] = (long long)(a0 + i);
   if (out_kind) out_kind[dst] = kind[i];
+}
+
+// ------------------------------------------------------------------ device-resident photon lists
+// A SHARD is what one rank's attempt range leaves: its stored photons, compacted in attempt order, as records of
+// W + 1 32-bit words -- W words of payload and a tag word = (attempt - tag_base) | (caustic ? 1 << 31 : 0).
+//   payload formats: full = the 11 record values in the working precision (W = 11 or 22 words);
+//                    packed = position, direction, power * colour as 9 floats (W = 9: the 36-byte photon of the map).
+// Shards of one batch share tag_base, so the shards of all ranks, concatenated in rank order, are the batch's stored
+// photons in attempt order with directly comparable tags.
+// (RT_SHARD_FULL / RT_SHARD_PACKED: include/rt355.h)
+template <typename T> constexpr uint32_t shard_words(int format) { return format == RT_SHARD_PACKED ? 9u : (uint32_t)(11 * sizeof(T) / 4); }
+
+template <typename T, int FORMAT>
+__global__ void __launch_bounds__(256) k_compact_shard(const uint8_t *kind, const T *rec, uint32_t count, const uint32_t *block_offset,
+                                                       uint32_t tag_offset, uint32_t cap, uint32_t *shard) {
+  __shared__ uint32_t wave_cnt[4];
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint8_t kd = i < count ? kind[i] : 0;
+  const bool m = kd != 0;
+  const unsigned long long mask = __ballot(m);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (lane == 0) wave_cnt[wv] = (uint32_t)__popcll(mask);
+  __syncthreads();
+  if (!m) return;
+  uint32_t rank = block_offset[blockIdx.x] + (uint32_t)__popcll(mask & (((unsigned long long)1 << lane) - 1));
+  for (int w = 0; w < wv; w++) rank += wave_cnt[w];
+  if (rank >= cap) return;
+  constexpr uint32_t W = shard_words<T>(FORMAT);
+  const T *r = rec + (size_t)i * RT_REC_STRIDE;
+  uint32_t *o = shard + (size_t)rank * (W + 1);
+  if (FORMAT == RT_SHARD_PACKED) {
+    float *f = (float *)o;
+    f[0] = (float)r[0]; f[1] = (float)r[1]; f[2] = (float)r[2]; f[3] = (float)r[3]; f[4] = (float)r[4]; f[5] = (float)r[5];
+    f[6] = (float)(r[7] * r[6]); f[7] = (float)(r[8] * r[6]); f[8] = (float)(r[9] * r[6]);
+  } else {
+    const uint32_t *src = (const uint32_t *)r;
+#pragma unroll
+    for (uint32_t c = 0; c < W; c++) o[c] = src[c];
+  }
+  o[W] = (tag_offset + i) | (kd == 2 ? 0x80000000u : 0u);
+}
+
+// State of the capped lists on the device; the host reads it back once per batch.
+struct ListsState {
+  uint32_t n_d, n_c;              // photons in the diffuse / caustic list
+  uint32_t total_d, total_c;      // stored photons of either kind in the batch just applied
+  uint32_t take_d, take_c;        // ... of which the lists took
+  uint32_t last_tag;              // tag (without the kind bit) of the attempt that ended the phase inside this batch, or 0xFFFFFFFF
+  uint32_t pad_;
+};
+
+// merged position i = shard (i / stride), record (i % stride); valid while the record index is below the shard's count
+__device__ __forceinline__ uint32_t merged_tag(const uint32_t *shards, const uint32_t *counts, uint32_t n_shards, uint32_t stride, uint32_t W,
+                                               uint32_t i, bool &valid) {
+  const uint32_t sh = i / stride, j = i - sh * stride;
+  valid = sh < n_shards && j < min(counts[sh], stride);
+  return valid ? shards[(size_t)i * (W + 1) + W] : 0u;
+}
+
+// per-workgroup numbers of diffuse and caustic records of the merged batch
+static __global__ void __launch_bounds__(256) k_lists_count(const uint32_t *shards, const uint32_t *counts, uint32_t n_shards, uint32_t stride,
+                                                            uint32_t W, uint32_t *block_d, uint32_t *block_c) {
+  __shared__ uint32_t cd[4], cc[4];
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  bool valid; const uint32_t tag = merged_tag(shards, counts, n_shards, stride, W, i, valid);
+  const unsigned long long md = __ballot(valid && !(tag >> 31)), mc = __ballot(valid && (tag >> 31));
+  if ((threadIdx.x & 63) == 0) { cd[threadIdx.x >> 6] = (uint32_t)__popcll(md); cc[threadIdx.x >> 6] = (uint32_t)__popcll(mc); }
+  __syncthreads();
+  if (threadIdx.x == 0) { block_d[blockIdx.x] = cd[0] + cd[1] + cd[2] + cd[3]; block_c[blockIdx.x] = cc[0] + cc[1] + cc[2] + cc[3]; }
+}
+
+// The caps of emitManyPhotons (rayphoton.js:1346-1383) on one merged, attempt-ordered batch.
+// Phase 1: the diffuse list takes records until it is full; the attempt that fills it is the last one the sequential
+// loop runs, so the caustic list takes the caustic records up to that attempt (and up to its own cap).  Phase 2: only
+// the caustic list takes records; the attempt that fills it ends the phase.  Pass A (kind 1 in phase 1, kind 2 in
+// phase 2) finds that attempt; pass B (phase 1 only) takes the caustic records before it.
+//   block_off: exclusive scans of the per-workgroup counts; totals[0] = diffuse, totals[1] = caustic records in the batch
+template <int PASS>
+__global__ void __launch_bounds__(256) k_lists_take(const uint32_t *shards, const uint32_t *counts, uint32_t n_shards, uint32_t stride, uint32_t W,
+                                                    const uint32_t *block_d, const uint32_t *block_c, const uint32_t *totals, int phase,
+                                                    uint32_t cap_d, uint32_t cap_c, unsigned long long tag_base, ListsState *st,
+                                                    uint32_t *list_d, long long *att_d, uint32_t *list_c, long long *att_c) {
+  __shared__ uint32_t cd[4], cc[4];
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  bool valid; const uint32_t tag = merged_tag(shards, counts, n_shards, stride, W, i, valid);
+  const bool is_c = valid && (tag >> 31), is_d = valid && !(tag >> 31);
+  const unsigned long long md = __ballot(is_d), mc = __ballot(is_c);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (lane == 0) { cd[wv] = (uint32_t)__popcll(md); cc[wv] = (uint32_t)__popcll(mc); }
+  __syncthreads();
+  const unsigned long long below = ((unsigned long long)1 << lane) - 1;
+  uint32_t rd = block_d[blockIdx.x] + (uint32_t)__popcll(md & below), rc = block_c[blockIdx.x] + (uint32_t)__popcll(mc & below);
+  for (int w = 0; w < wv; w++) { rd += cd[w]; rc += cc[w]; }      // this record's rank among the batch's diffuse / caustic records
+  const uint32_t n_d = st->n_d, n_c = st->n_c;                     // list lengths before this batch
+  const uint32_t room_d = cap_d - min(n_d, cap_d), room_c = cap_c - min(n_c, cap_c);
+  const long long ph = (long long)phase << 62;
+  if (PASS == 0) {
+    if (phase == 1) {
+      if (is_d && rd < room_d) {
+        uint32_t *o = list_d + (size_t)(n_d + rd) * W; const uint32_t *src = shards + (size_t)i * (W + 1);
+        for (uint32_t c = 0; c < W; c++) o[c] = src[c];
+        att_d[n_d + rd] = ph | (long long)(tag_base + (tag & 0x7FFFFFFFu));
+        if (rd + 1 == room_d) { st->last_tag = tag & 0x7FFFFFFFu; st->pad_ = rc; }      // rc: caustic records before the last attempt
+      }
+    } else if (is_c && rc < room_c) {
+      uint32_t *o = list_c + (size_t)(n_c + rc) * W; const uint32_t *src = shards + (size_t)i * (W + 1);
+      for (uint32_t c = 0; c < W; c++) o[c] = src[c];
+      att_c[n_c + rc] = ph | (long long)(tag_base + (tag & 0x7FFFFFFFu));
+      if (rc + 1 == room_c) st->last_tag = tag & 0x7FFFFFFFu;
+    }
+  } else {                                                        // phase 1, caustic records up to the last attempt
+    const uint32_t upto = st->last_tag == 0xFFFFFFFFu ? totals[1] : st->pad_;
+    const uint32_t take = min(upto, room_c);
+    if (is_c && rc < take) {
+      uint32_t *o = list_c + (size_t)(n_c + rc) * W; const uint32_t *src = shards + (size_t)i * (W + 1);
+      for (uint32_t c = 0; c < W; c++) o[c] = src[c];
+      att_c[n_c + rc] = ph | (long long)(tag_base + (tag & 0x7FFFFFFFu));
+    }
+  }
+}
+
+// closes a batch: new list lengths, what was taken (one thread)
+static __global__ void k_lists_finish(const uint32_t *totals, int phase, uint32_t cap_d, uint32_t cap_c, ListsState *st) {
+  const uint32_t n_d = st->n_d, n_c = st->n_c;
+  const uint32_t room_d = cap_d - min(n_d, cap_d), room_c = cap_c - min(n_c, cap_c);
+  uint32_t take_d = 0, take_c = 0;
+  if (phase == 1) {
+    take_d = min(totals[0], room_d);
+    const uint32_t upto = st->last_tag == 0xFFFFFFFFu ? totals[1] : st->pad_;
+    take_c = min(upto, room_c);
+  } else {
+    take_c = min(totals[1], room_c);
+  }
+  st->total_d = totals[0]; st->total_c = totals[1]; st->take_d = take_d; st->take_c = take_c;
+  st->n_d = n_d + take_d; st->n_c = n_c + take_c;
+}
+
+// sum of the per-attempt segment counts of attempts [0, upto) of a batch (emitPhoton calls the sequential loop makes)
+static __global__ void __launch_bounds__(256) k_sum_segments(const uint8_t *nseg, uint32_t upto, unsigned long long *out) {
+  unsigned long long s = 0;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < upto; i += gridDim.x * blockDim.x) s += nseg[i];
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  if ((threadIdx.x & 63) == 0 && s) atomicAdd(out, s);
+}
+
+// list records -> the boundary's 11 doubles (full format) for the host's photon lists
+template <typename T>
+__global__ void __launch_bounds__(256) k_lists_export(const uint32_t *list, const long long *att, uint32_t n, double *rec_out, long long *att_out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const T *r = (const T *)(list + (size_t)i * (11 * sizeof(T) / 4));
+  if (rec_out) for (int c = 0; c < 11; c++) rec_out[(size_t)i * 11 + c] = (double)r[c];
+  if (att_out) { const long long a = att[i]; att_out[2 * (size_t)i] = (a >> 62) & 3; att_out[2 * (size_t)i + 1] = a & (((long long)1 << 62) - 1); }
 }

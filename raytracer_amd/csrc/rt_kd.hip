@@ -217,30 +217,48 @@ extern "C" int rt_kd_build(rt_ctx *ctx, const float *pos, uint32_t n, int32_t *p
 }
 
 // ------------------------------------------------------------------ photon map object
-__global__ void __launch_bounds__(256) k_map_extract_pos(uint32_t n, const double *rec, float *pos3) {
+// Where the photons come from: the boundary's 11-double records, a list of full fp32 records (11 floats) or a list of
+// packed photons (9 floats: position, direction, power * colour).
+enum { MAP_SRC_REC64 = 0, MAP_SRC_FULL32 = 1, MAP_SRC_PACKED = 2 };
+template <int SRC> __device__ __forceinline__ void map_load(const void *src, size_t i, float pos[3], float pay[6]) {
+  if (SRC == MAP_SRC_REC64) {
+    const double *r = (const double *)src + i * 11;
+    for (int d = 0; d < 3; d++) { pos[d] = (float)r[d]; pay[d] = (float)r[3 + d]; pay[3 + d] = (float)(r[7 + d] * r[6]); }
+  } else if (SRC == MAP_SRC_FULL32) {
+    const float *r = (const float *)src + i * 11;
+    for (int d = 0; d < 3; d++) { pos[d] = r[d]; pay[d] = r[3 + d]; pay[3 + d] = r[7 + d] * r[6]; }
+  } else {
+    const float *r = (const float *)src + i * 9;
+    for (int d = 0; d < 3; d++) { pos[d] = r[d]; pay[d] = r[3 + d]; pay[3 + d] = r[6 + d]; }
+  }
+}
+template <int SRC> __global__ void __launch_bounds__(256) k_map_extract_pos(uint32_t n, const void *src, float *pos3) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  for (int d = 0; d < 3; d++) pos3[(size_t)i * 3 + d] = (float)rec[(size_t)i * 11 + d];
+  float pos[3], pay[6];
+  map_load<SRC>(src, i, pos, pay);
+  for (int d = 0; d < 3; d++) pos3[(size_t)i * 3 + d] = pos[d];
 }
-__global__ void __launch_bounds__(256) k_map_permute(uint32_t n, const double *rec, const int32_t *perm, const uint8_t *dim,
-                                                     float4 *node, float *pay, double *rec64) {
+template <int SRC> __global__ void __launch_bounds__(256) k_map_permute(uint32_t n, const void *src, const int32_t *perm, const uint8_t *dim,
+                                                                        float4 *node, float *pay_out, double *rec64) {
   uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= n) return;
-  const double *r = rec + (size_t)perm[s] * 11;
-  node[s] = make_float4((float)r[0], (float)r[1], (float)r[2], __int_as_float((int)dim[s]));
-  float *p = pay + (size_t)s * 6;
-  p[0] = (float)r[3]; p[1] = (float)r[4]; p[2] = (float)r[5];
-  p[3] = (float)(r[7] * r[6]); p[4] = (float)(r[8] * r[6]); p[5] = (float)(r[9] * r[6]);
-  if (rec64) for (int c = 0; c < 11; c++) rec64[(size_t)s * 11 + c] = r[c];
+  float pos[3], pay[6];
+  map_load<SRC>(src, (size_t)perm[s], pos, pay);
+  node[s] = make_float4(pos[0], pos[1], pos[2], __int_as_float((int)dim[s]));
+  float2 *p = (float2 *)(pay_out + (size_t)s * 6);
+  p[0] = make_float2(pay[0], pay[1]); p[1] = make_float2(pay[2], pay[3]); p[2] = make_float2(pay[4], pay[5]);
+  if (SRC == MAP_SRC_REC64 && rec64) {
+    const double *r = (const double *)src + (size_t)perm[s] * 11;
+    for (int c = 0; c < 11; c++) rec64[(size_t)s * 11 + c] = r[c];
+  }
 }
 
-extern "C" int rt_photon_map_build(rt_ctx *ctx, const double *rec, uint32_t n, rt_photon_map **out) {
-  if (!ctx || !out) return RT_ERR_INVALID;
+// src: device memory
+int rt_map_build_device(rt_ctx *ctx, const void *src, int src_kind, uint32_t n, rt_photon_map **out) {
   *out = nullptr;
   if (n == 0) return rt_fail(ctx, RT_ERR_EMPTY_TREE, "tried to build a k-d tree with no data!");
-  RT_HIP(ctx, hipSetDevice(ctx->device));
-  DevMem trec, tpos; const void *drec;
-  RT_TRY(rt_stage_in(ctx, rec, (size_t)n * 88, trec, &drec));
+  DevMem tpos;
   RT_HIP(ctx, tpos.alloc((size_t)n * 12));
   rt_photon_map *m = new rt_photon_map();
   m->ctx = ctx; m->n = n;
@@ -248,19 +266,55 @@ extern "C" int rt_photon_map_build(rt_ctx *ctx, const double *rec, uint32_t n, r
   if (e == hipSuccess) e = m->pay.alloc((size_t)n * 24);
   if (e == hipSuccess) e = m->perm.alloc((size_t)n * 4);
   if (e == hipSuccess) e = m->dim.alloc((size_t)n);
-  // fp64 copy of the records for the parity (fp64) renderer; skipped for very large maps
-  const bool keep64 = n <= (1u << 24);
+  // fp64 copy of the records for the parity (fp64) renderer; only from fp64 records, and skipped for very large maps
+  const bool keep64 = src_kind == MAP_SRC_REC64 && n <= (1u << 24);
   if (e == hipSuccess && keep64) e = m->rec64.alloc((size_t)n * 88);
   if (e != hipSuccess) { delete m; return rt_fail(ctx, RT_ERR_HIP, "photon map allocation failed: %s", hipGetErrorString(e)); }
   const uint32_t grid = div_up(n, 256);
-  RT_LAUNCH(ctx, "map_extract_pos", k_map_extract_pos, grid, 256, n, (const double *)drec, tpos.as<float>());
+  if (src_kind == MAP_SRC_REC64) RT_LAUNCH(ctx, "map_extract_pos", k_map_extract_pos<MAP_SRC_REC64>, grid, 256, n, src, tpos.as<float>());
+  else if (src_kind == MAP_SRC_FULL32) RT_LAUNCH(ctx, "map_extract_pos", k_map_extract_pos<MAP_SRC_FULL32>, grid, 256, n, src, tpos.as<float>());
+  else RT_LAUNCH(ctx, "map_extract_pos", k_map_extract_pos<MAP_SRC_PACKED>, grid, 256, n, src, tpos.as<float>());
   int rc = rt_kd_build_device(ctx, tpos.as<float>(), n, m->perm.as<int32_t>(), m->dim.as<uint8_t>(), m->bbox);
   if (rc != RT_OK) { delete m; return rc; }
-  RT_LAUNCH(ctx, "map_permute", k_map_permute, grid, 256, n, (const double *)drec, m->perm.as<int32_t>(), m->dim.as<uint8_t>(),
-            m->node.as<float4>(), m->pay.as<float>(), keep64 ? m->rec64.as<double>() : (double *)nullptr);
+  double *r64 = keep64 ? m->rec64.as<double>() : (double *)nullptr;
+  if (src_kind == MAP_SRC_REC64) RT_LAUNCH(ctx, "map_permute", k_map_permute<MAP_SRC_REC64>, grid, 256, n, src, m->perm.as<int32_t>(), m->dim.as<uint8_t>(), m->node.as<float4>(), m->pay.as<float>(), r64);
+  else if (src_kind == MAP_SRC_FULL32) RT_LAUNCH(ctx, "map_permute", k_map_permute<MAP_SRC_FULL32>, grid, 256, n, src, m->perm.as<int32_t>(), m->dim.as<uint8_t>(), m->node.as<float4>(), m->pay.as<float>(), r64);
+  else RT_LAUNCH(ctx, "map_permute", k_map_permute<MAP_SRC_PACKED>, grid, 256, n, src, m->perm.as<int32_t>(), m->dim.as<uint8_t>(), m->node.as<float4>(), m->pay.as<float>(), r64);
   if (hipStreamSynchronize(ctx->stream) != hipSuccess) { delete m; return rt_fail(ctx, RT_ERR_HIP, "photon map build failed"); }
   *out = m;
   return RT_OK;
+}
+
+extern "C" int rt_photon_map_build(rt_ctx *ctx, const double *rec, uint32_t n, rt_photon_map **out) {
+  if (!ctx || !out) return RT_ERR_INVALID;
+  *out = nullptr;
+  if (n == 0) return rt_fail(ctx, RT_ERR_EMPTY_TREE, "tried to build a k-d tree with no data!");
+  RT_HIP(ctx, hipSetDevice(ctx->device));
+  DevMem trec; const void *drec;
+  RT_TRY(rt_stage_in(ctx, rec, (size_t)n * 88, trec, &drec));
+  return rt_map_build_device(ctx, drec, MAP_SRC_REC64, n, out);
+}
+// packed photons: n x 9 floats (position, direction, power * colour), host or device memory
+extern "C" int rt_photon_map_build_packed(rt_ctx *ctx, const float *photons, uint32_t n, rt_photon_map **out) {
+  if (!ctx || !out) return RT_ERR_INVALID;
+  *out = nullptr;
+  if (n == 0) return rt_fail(ctx, RT_ERR_EMPTY_TREE, "tried to build a k-d tree with no data!");
+  RT_HIP(ctx, hipSetDevice(ctx->device));
+  DevMem trec; const void *drec;
+  RT_TRY(rt_stage_in(ctx, photons, (size_t)n * 36, trec, &drec));
+  return rt_map_build_device(ctx, drec, MAP_SRC_PACKED, n, out);
+}
+extern "C" int rt_photon_map_build_lists(rt_photon_lists *lists, int which, rt_photon_map **out) {
+  if (!lists || !out) return RT_ERR_INVALID;
+  *out = nullptr;
+  const void *rec = nullptr; uint32_t n = 0, words = 0; int precision = 0;
+  int rc = rt_lists_view(lists, which, &rec, &n, &words, &precision);
+  if (rc != RT_OK) return rc;
+  rt_ctx *ctx = rt_lists_ctx(lists);
+  RT_HIP(ctx, hipSetDevice(ctx->device));
+  if (n == 0) return rt_fail(ctx, RT_ERR_EMPTY_TREE, "tried to build a k-d tree with no data!");
+  const int kind = words == 9 ? MAP_SRC_PACKED : (words == 22 ? MAP_SRC_REC64 : MAP_SRC_FULL32);
+  return rt_map_build_device(ctx, rec, kind, n, out);
 }
 extern "C" void rt_photon_map_free(rt_photon_map *m) { delete m; }
 extern "C" uint32_t rt_photon_map_size(const rt_photon_map *m) { return m ? m->n : 0; }

@@ -20,4 +20,5 @@ template <typename T> int pl_emit_batch(rt_scene *sc, const rt_params *p, int ph
 // out_rec[out_base + rank]; *n_match = number of matches (device-side scan result, read back)
 template <typename T> int pl_emit_compact(rt_scene *sc, uint32_t count, int want, uint64_t a0, uint32_t out_base, uint32_t out_cap,
                                           double *out_rec, int64_t *out_attempt, uint8_t *out_kind, uint32_t *n_match);
+template <typename T> int pl_emit_shard(rt_scene *sc, uint32_t count, int format, uint32_t tag_offset, uint32_t cap, uint32_t *shard, uint32_t *n_dev);
 int pl_emit_counters(rt_scene *sc, bool reset, uint64_t *segments, uint64_t *errors);

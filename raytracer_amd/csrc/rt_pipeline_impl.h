@@ -98,7 +98,13 @@ static int trace_tile_mode(rt_scene *sc, int slot, const rt_params *p, DevMap md
   DevScene<T> S = SceneOf<T>::get(sc);                        // (a copy: the kernels take it by value)
   if constexpr (sizeof(T) == 4) { if (K.no_cull) S.sbound = nullptr; }
   const int blk = p->super_sample_block > 1 ? p->super_sample_block : 1;       // one traced sample per blk x blk pixels
-  const int wb = (w + blk - 1) / blk, hb = (h + blk - 1) / blk;
+  const int wb = (w + blk - 1) / blk;
+  int hb = (h + blk - 1) / blk;
+  int band_shift = 0;
+  if (p->band_count > 1) {                                    // this call traces one rank's row bands of the tile
+    while ((1 << band_shift) < p->band_rows) band_shift++;
+    hb = (int)rt_band_rows((uint32_t)h, p->band_rows, p->band_count, p->band_index);
+  }
   const size_t n_pixels = (size_t)wb * hb;
   const size_t n_paths = n_pixels * p->sub_sample * p->sub_sample;
   if (n_paths == 0) return RT_OK;
@@ -125,6 +131,8 @@ static int trace_tile_mode(rt_scene *sc, int slot, const rt_params *p, DevMap md
   C.magic_s = (uint32_t)(0x100000000ull / (uint64_t)p->sub_sample);
   C.tiles_x = (wb % 32 == 0 && hb % 8 == 0 && !K.raster_order) ? (uint32_t)(wb / 32) : 0u;
   C.magic_tx = C.tiles_x ? (uint32_t)(0x100000000ull / (uint64_t)C.tiles_x) : 0u;
+  C.band_shift = (uint32_t)band_shift; C.band_period = band_shift ? (uint32_t)(p->band_rows * p->band_count) : 0u;
+  C.band_first = band_shift ? (uint32_t)(p->band_rows * p->band_index) : 0u;
   C.fuse_resolve = (!WHITTED && p->sub_sample == 1) ? 1 : 0; C.pre = pre; C.post = post; C.rgba8 = rgba8;
   if (!p->use_photon_maps) { md.n = 0; mc.n = 0; }
   T *levels = nullptr;
@@ -288,16 +296,17 @@ int pl_emit_batch(rt_scene *sc, const rt_params *p, int phase, uint64_t a0, uint
   rt_ctx *ctx = sc->ctx;
   DevScene<T> &S = SceneOf<T>::get(sc);
   RT_HIP(ctx, sc->ws_emit_kind.reserve(count));
+  RT_HIP(ctx, sc->ws_emit_seg.reserve(count));
   RT_HIP(ctx, sc->ws_emit_rec.reserve((size_t)count * RT_REC_STRIDE * sizeof(T)));
   if (!sc->ws_misc.p) { RT_HIP(ctx, sc->ws_misc.alloc(256)); RT_HIP(ctx, hipMemsetAsync(sc->ws_misc.p, 0, 256, ctx->stream)); }
   EmitCfg C; C.epsilon = working_eps<T>(p); C.max_depth = p->max_depth; C.num_diffuse = p->num_photons_diffuse;
   C.num_caustic = p->num_photons_caustic; C.seed = p->seed;
   if (!S.bvh && scene_fits_lds<T>(S.n_shapes))
     RT_LAUNCH_SMEM(ctx, "photon_emit_bounce", (k_emit<T, true>), div_up(count, 256), 256, scan_lds_bytes<T>(S.n_shapes), S, C, phase,
-                   (unsigned long long)a0, count, sc->ws_emit_kind.as<uint8_t>(), sc->ws_emit_rec.as<T>(), sc->ws_misc.as<EmitCounters>());
+                   (unsigned long long)a0, count, sc->ws_emit_kind.as<uint8_t>(), sc->ws_emit_rec.as<T>(), sc->ws_emit_seg.as<uint8_t>(), sc->ws_misc.as<EmitCounters>());
   else
     RT_LAUNCH_SMEM(ctx, "photon_emit_bounce", (k_emit<T, false>), div_up(count, 256), 256, 0, S, C, phase,
-                   (unsigned long long)a0, count, sc->ws_emit_kind.as<uint8_t>(), sc->ws_emit_rec.as<T>(), sc->ws_misc.as<EmitCounters>());
+                   (unsigned long long)a0, count, sc->ws_emit_kind.as<uint8_t>(), sc->ws_emit_rec.as<T>(), sc->ws_emit_seg.as<uint8_t>(), sc->ws_misc.as<EmitCounters>());
   RT_HIP(ctx, hipGetLastError());
   return RT_OK;
 }
@@ -320,6 +329,26 @@ int pl_emit_compact(rt_scene *sc, uint32_t count, int want, uint64_t a0, uint32_
   return RT_OK;
 }
 
+// The batch in the workspace, compacted in attempt order into a shard (rt_emit.h) of capacity `cap` records; the
+// number of stored photons goes to *n_dev (device memory; it may exceed cap, the records beyond cap are dropped).
+template <typename T>
+int pl_emit_shard(rt_scene *sc, uint32_t count, int format, uint32_t tag_offset, uint32_t cap, uint32_t *shard, uint32_t *n_dev) {
+  rt_ctx *ctx = sc->ctx;
+  const uint32_t blocks = div_up(count, 256);
+  RT_HIP(ctx, sc->ws_emit_blocks.reserve(((size_t)blocks + 1) * 4));
+  uint32_t *bc = sc->ws_emit_blocks.as<uint32_t>();
+  RT_LAUNCH(ctx, "compact_count", k_compact_count, blocks, 256, sc->ws_emit_kind.as<uint8_t>(), count, 0, bc);
+  RT_LAUNCH(ctx, "compact_scan", k_scan_blocks, 1, 1024, bc, blocks, n_dev, (const uint32_t *)nullptr);
+  if (format == RT_SHARD_PACKED)
+    RT_LAUNCH(ctx, "compact_shard", (k_compact_shard<T, RT_SHARD_PACKED>), blocks, 256, sc->ws_emit_kind.as<uint8_t>(), sc->ws_emit_rec.as<T>(), count,
+              (const uint32_t *)bc, tag_offset, cap, shard);
+  else
+    RT_LAUNCH(ctx, "compact_shard", (k_compact_shard<T, RT_SHARD_FULL>), blocks, 256, sc->ws_emit_kind.as<uint8_t>(), sc->ws_emit_rec.as<T>(), count,
+              (const uint32_t *)bc, tag_offset, cap, shard);
+  RT_HIP(ctx, hipGetLastError());
+  return RT_OK;
+}
+
 #define RT_INSTANTIATE_PIPELINE(T)                                                                                     \
   template int pl_intersect_pairs<T>(rt_ctx *, const rt_params *, uint32_t, const double *, const double *, int,       \
                                      const uint8_t *, const double *, double *);                                       \
@@ -328,5 +357,6 @@ int pl_emit_compact(rt_scene *sc, uint32_t count, int want, uint64_t a0, uint32_
   template int pl_trace_tile<T>(rt_scene *, int, const rt_params *, DevMap, DevMap, int, int, int, int, double *, double *, \
                                 uint8_t *, rt_trace_stats *);                                                          \
   template int pl_emit_batch<T>(rt_scene *, const rt_params *, int, uint64_t, uint32_t);                               \
+  template int pl_emit_shard<T>(rt_scene *, uint32_t, int, uint32_t, uint32_t, uint32_t *, uint32_t *);                \
   template int pl_emit_compact<T>(rt_scene *, uint32_t, int, uint64_t, uint32_t, uint32_t, double *, int64_t *,        \
                                   uint8_t *, uint32_t *);

@@ -84,7 +84,16 @@ struct TraceCfg {
   // h % 8 == 0); 0: row by row.  A workgroup of the first pass then covers a compact rectangle: a tighter culling
   // pyramid, and chunks of survivors that live about equally long.
   uint32_t tiles_x, magic_tx;
+  // Row bands (multi-GPU tile split): band_shift > 0 means this call traces only the bands of 2^band_shift rows that
+  // belong to one rank, band_first + j * band_period for j = 0, 1, ...; traced row r (and the outputs, which hold the
+  // traced rows only) maps to tile row (r >> band_shift) * band_period + band_first + (r & (2^band_shift - 1)).
+  uint32_t band_shift, band_period, band_first;
 };
+// row of the tile that traced row `row` stands for
+RT_D uint32_t band_row(const TraceCfg &C, uint32_t row) {
+  if (!C.band_shift) return row;
+  return (row >> C.band_shift) * C.band_period + C.band_first + (row & ((1u << C.band_shift) - 1u));
+}
 
 #define RT_MAX_WAVE_BOUNCES 62
 // device-side bookkeeping of one rt_trace_tile call; counts[b] = queue length of wavefront pass b
@@ -151,7 +160,7 @@ RT_D void path_pixel(const TraceCfg &C, uint32_t p, int &X, int &Y, uint32_t &su
   uint32_t col, row;
   const uint32_t pix = div_by(p, (uint32_t)(C.sub_sample * C.sub_sample), C.magic_ss, sub);
   pixel_colrow(C, pix, col, row);
-  X = C.x0 + (int)col * C.block; Y = C.y0 + (int)row * C.block;
+  X = C.x0 + (int)col * C.block; Y = C.y0 + (int)band_row(C, row) * C.block;
 }
 
 // traceOnCanvas ray set-up (rayphoton.js:1589-1609, superSampleScale 0) for path p: the initial path state
@@ -506,7 +515,7 @@ RT_D void cull_primitives(const DevScene<float> &S, const TraceCfg &C, uint16_t 
     } else if (row0 != row1) { c0 = 0; c1 = (uint32_t)C.w - 1; }
     const float jit = (C.block > 1 ? (float)C.block : 0.0f) + 1.0f;        // block jitter + sub-sample jitter, in pixels
     const float xa = (float)(C.x0 + (int)c0 * C.block) - 1.0f, xb = (float)(C.x0 + (int)c1 * C.block) + jit + 1.0f;
-    const float ya = (float)(C.y0 + (int)row0 * C.block) - 1.0f, yb = (float)(C.y0 + (int)row1 * C.block) + jit + 1.0f;
+    const float ya = (float)(C.y0 + (int)band_row(C, row0) * C.block) - 1.0f, yb = (float)(C.y0 + (int)band_row(C, row1) * C.block) + jit + 1.0f;
     const float ua = (xa * 2.0f / (float)S.width - 1.0f) * S.camera[12], ub = (xb * 2.0f / (float)S.width - 1.0f) * S.camera[12];
     const float vb = -(ya * 2.0f / (float)S.height - 1.0f) * S.camera[13], va = -(yb * 2.0f / (float)S.height - 1.0f) * S.camera[13];
     const V3<float> o = ld3(S.camera), cu = ld3(S.camera + 3), cv = ld3(S.camera + 6), cw = ld3(S.camera + 9);

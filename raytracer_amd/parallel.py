@@ -1,19 +1,23 @@
-"""Multi-GPU sharding of the hot path (one process and one rt_ctx per GPU, torch.distributed for
-the exchange: backend "nccl" is RCCL over xGMI on ROCm, "gloo" on CPU for tests).
+"""Multi-GPU sharding of the hot path: one process and one rt_ctx per GPU, torch.distributed for the two
+exchange steps (backend "nccl" is RCCL over xGMI on ROCm; "gloo" with CPU tensors in the tests).
 
-The path shards by construction: every emission attempt and every pixel has its own RNG stream
-keyed by its index, so ranks take disjoint index ranges and no collective sits inside a kernel.
-Two exchange steps exist:
+The path shards by construction: every emission attempt and every pixel has its own RNG stream keyed by its
+index, so ranks take disjoint index ranges and no collective sits inside a kernel.
 
-  * emission: each round, rank k runs attempts [A + k*B/R, A + (k+1)*B/R); the attempt-ordered
-    records are all-gathered (padded to the longest shard) and every rank applies the reference's
-    list caps (rayphoton.js:1346-1383) to the identical merged sequence -> identical photon lists
-    on every rank, hence identical (deterministic) kd-trees with no tree broadcast;
-  * render: row bands are interleaved over ranks (cost per pixel is uneven) and gathered to rank 0.
+  * emission (emitManyPhotons, rayphoton.js:1354-1383): a batch of attempts [A, A + B) is cut into `world`
+    contiguous sub-ranges in rank order.  Rank k emits its sub-range into a SHARD in its own device memory
+    (rt_emit_shard: stored photons in attempt order, W + 1 words each, tag = attempt - A | caustic bit).  The
+    shard lengths are all-gathered (one int per rank), then the shards themselves, cut to the longest, in ONE
+    all-gather straight from and into device memory -- with the packed format that is the 36-byte photon plus
+    4 bytes of tag.  Every rank then applies the reference's list caps to the identical merged batch on its GPU
+    (rt_lists_apply): identical photon lists and therefore identical, deterministically built kd-trees on every
+    rank, with no tree broadcast.
+  * render: row bands of the frame are interleaved over the ranks (cost per pixel is uneven: glass against bare
+    wall); each rank traces its bands in one call (rt_params.band_*) into device memory and the bands are
+    gathered to rank 0.
 
-`engine` is anything with emit(phase, a0, a1) -> (rec[n,11] f64, attempt[n] i64, kind[n] u8) and
-render(x0, y0, w, h) -> post[h,w,4] f64; on a GPU rank that is a thin adapter over capi.Scene, in the
-CPU tests it is the oracle.
+An ENGINE hides who computes: DeviceEngine drives librt355 through raytracer_amd.capi; the CPU tests use the
+oracle behind the same five methods with CPU tensors.
 """
 from __future__ import annotations
 
@@ -29,9 +33,11 @@ except Exception:                                       # pragma: no cover
     dist = None
 
 
+# ------------------------------------------------------------------ the caps, restated for engines without a GPU
 @dataclass
 class EmitState:
-    """list caps of emitManyPhotons, applied batch by batch in attempt order"""
+    """list caps of emitManyPhotons, applied batch by batch in attempt order (numpy; the GPU path applies the same
+    rules on the device, csrc/rt_emit.h)"""
     nd_cap: int
     nc_cap: int
     diffuse: list = field(default_factory=list)
@@ -40,29 +46,24 @@ class EmitState:
     caustic_attempt: list = field(default_factory=list)
     nd: int = 0
     nc: int = 0
-    attempts: dict = field(default_factory=lambda: {1: 0, 2: 0})
-    capped: bool = False
 
-    def phase_done(self, phase):
-        return self.nd >= self.nd_cap if phase == 1 else self.nc >= self.nc_cap
-
-    def apply(self, phase, a0, a1, rec, attempt, kind):
-        """Consume the stored photons of attempts [a0, a1) (attempt-ordered).  Returns the next attempt
-        index the sequential loop would run (== a1 unless a cap ended the phase inside this batch)."""
+    def apply(self, phase, a0, rec, attempt, kind):
+        """Consume the stored photons of one batch (attempt-ordered).  Returns (phase_ended, last_attempt)."""
         rec, attempt, kind = np.asarray(rec), np.asarray(attempt), np.asarray(kind)
         d, c = kind == 1, kind == 2
         da, ca = attempt[d], attempt[c]
-        last = a1 - 1
+        ended, last = False, None
         take_d = take_c = 0
         if phase == 1:
             take_d = min(int(d.sum()), self.nd_cap - self.nd)
             if self.nd + take_d == self.nd_cap and take_d > 0:
-                last = int(da[take_d - 1])              # the attempt that stores the N_D-th diffuse photon ends phase 1
-            take_c = min(int(np.searchsorted(ca, last, side="right")), self.nc_cap - self.nc)
+                ended, last = True, int(da[take_d - 1])     # the attempt that stores the N_D-th diffuse photon ends phase 1
+            upto = int(np.searchsorted(ca, last, side="right")) if ended else int(c.sum())
+            take_c = min(upto, self.nc_cap - self.nc)
         else:
             take_c = min(int(c.sum()), self.nc_cap - self.nc)
             if self.nc + take_c == self.nc_cap and take_c > 0:
-                last = int(ca[take_c - 1])
+                ended, last = True, int(ca[take_c - 1])
         if take_d:
             self.diffuse.append(rec[d][:take_d])
             self.diffuse_attempt.append(np.stack([np.full(take_d, phase), da[:take_d]], axis=1))
@@ -71,17 +72,13 @@ class EmitState:
             self.caustic_attempt.append(np.stack([np.full(take_c, phase), ca[:take_c]], axis=1))
         self.nd += take_d
         self.nc += take_c
-        self.attempts[phase] = last + 1
-        if self.attempts[phase] > 100 * (self.nd_cap if phase == 1 else self.nc_cap):   # rayphoton.js:1365, :1377
-            self.capped = True
-        return last + 1
+        return ended, last
 
     def result(self):
         cat = lambda xs, w: np.concatenate(xs) if xs else np.zeros((0, w))
         return dict(diffuse=cat(self.diffuse, 11), caustic=cat(self.caustic, 11),
                     diffuse_attempt=cat(self.diffuse_attempt, 2).astype(np.int64),
-                    caustic_attempt=cat(self.caustic_attempt, 2).astype(np.int64),
-                    attempts1=self.attempts[1], attempts2=self.attempts[2], capped=self.capped)
+                    caustic_attempt=cat(self.caustic_attempt, 2).astype(np.int64))
 
 
 def _world():
@@ -90,92 +87,166 @@ def _world():
     return 0, 1
 
 
-def _all_gather_ragged(arrays, device):
-    """all-gather a tuple of per-rank arrays of equal leading length n_k (different per rank);
-    returns per-array concatenation in rank order."""
-    rank, world = _world()
-    if world == 1:
-        return arrays
-    n = torch.tensor([arrays[0].shape[0]], dtype=torch.int64, device=device)
-    counts = [torch.zeros_like(n) for _ in range(world)]
-    dist.all_gather(counts, n)
-    counts = [int(c.item()) for c in counts]
-    m = max(max(counts), 1)
-    out = []
-    for a in arrays:
-        t = torch.zeros((m,) + a.shape[1:], dtype=torch.from_numpy(a[:0]).dtype, device=device)
-        if a.shape[0]:
-            t[:a.shape[0]] = torch.from_numpy(np.ascontiguousarray(a)).to(device)
-        parts = [torch.empty_like(t) for _ in range(world)]
-        dist.all_gather(parts, t)                       # padded shards, one collective per field
-        out.append(np.concatenate([p[:counts[k]].cpu().numpy() for k, p in enumerate(parts)]))
-    return tuple(out)
+def _all_gather_rows(local, world):
+    """local: (m, w) tensor, the same m on every rank -> (world, m, w) in rank order, one collective"""
+    out = torch.empty((world,) + tuple(local.shape), dtype=local.dtype, device=local.device)
+    try:
+        dist.all_gather_into_tensor(out.view(-1, *local.shape[1:]), local.contiguous())
+    except (RuntimeError, NotImplementedError, AttributeError):
+        dist.all_gather([out[k] for k in range(world)], local.contiguous())
+    return out
 
 
-def emit_sharded(engine, nd_cap, nc_cap, batch=1 << 16, device="cpu"):
-    """emitManyPhotons over all ranks.  Every rank returns the same lists."""
+def emit_sharded(engine, batch=1 << 22, world_override=None, timings=None):
+    """emitManyPhotons over all ranks; every rank ends with the same lists inside its engine.
+
+    batch: attempts per round over ALL ranks.  world_override=R makes this one process play R ranks in turn (a
+    single-GPU rehearsal of the protocol: same shards, same merge, no collective).
+    timings (optional dict) receives seconds per phase of the protocol and the bytes all-gathered."""
+    import time
     rank, world = _world()
-    st = EmitState(nd_cap, nc_cap)
+    sim = world_override if (world_override and world == 1) else None
+    nranks = sim or world
+    nd_cap, nc_cap = engine.caps()
+    attempts = {1: 0, 2: 0}
+    capped = False
+    T = dict(emit_s=0.0, exchange_s=0.0, apply_s=0.0, allgather_bytes=0, rounds=0)
     for phase in (1, 2):
         a = 0
-        cap = 100 * (nd_cap if phase == 1 else nc_cap)
-        while not st.phase_done(phase) and not st.capped:
-            b = min(batch, cap + 1 - a)
-            # contiguous sub-ranges in rank order, so rank-major concatenation is attempt order
-            lo = a + (b * rank) // world
-            hi = a + (b * (rank + 1)) // world
-            rec, att, kind = engine.emit(phase, lo, hi)
-            rec, att, kind = _all_gather_ragged((np.asarray(rec, np.float64).reshape(-1, 11), np.asarray(att, np.int64),
-                                                 np.asarray(kind, np.uint8)), device)
-            a = st.apply(phase, a, a + b, rec, att, kind)
-        if st.capped:
+        limit = 100 * (nd_cap if phase == 1 else nc_cap)            # rayphoton.js:1365, :1377
+        while not engine.phase_done(phase):
+            b = int(min(batch, limit + 1 - a))
+            bounds = [a + (b * k) // nranks for k in range(nranks + 1)]   # contiguous sub-ranges in rank order = attempt order
+            t0 = time.perf_counter()
+            mine = range(nranks) if sim else [rank]
+            shards, counts = [], []
+            for k in mine:
+                sh, n = engine.emit_shard(phase, bounds[k], bounds[k + 1], a)
+                shards.append(sh)
+                counts.append(n)
+            engine.sync()
+            t1 = time.perf_counter()
+            if sim:
+                cnt = torch.cat(counts)
+                m = max(int(cnt.max().item()), 1)
+                merged = torch.stack([_first_rows(s, m) for s in shards])
+            elif world > 1:
+                cnt = _all_gather_rows(counts[0].view(1, 1), world).view(world)
+                m = max(int(cnt.max().item()), 1)                     # (host sync: the longest shard sizes the exchange)
+                merged = _all_gather_rows(_first_rows(shards[0], m), world)
+                T["allgather_bytes"] += merged.numel() * merged.element_size()
+            else:
+                cnt = counts[0]
+                m = max(int(cnt.item()), 1)
+                merged = _first_rows(shards[0], m).unsqueeze(0)
+            engine.sync()
+            t2 = time.perf_counter()
+            ended, last = engine.apply(phase, a, merged, cnt.to(torch.int32), nranks, m)
+            t3 = time.perf_counter()
+            T["emit_s"] += t1 - t0
+            T["exchange_s"] += t2 - t1
+            T["apply_s"] += t3 - t2
+            T["rounds"] += 1
+            a = (last if ended else a + b - 1) + 1
+            attempts[phase] = a
+            if a > limit:
+                capped = True
+                break
+        attempts[phase] = a
+        if capped:
             break
-    return st.result()
+    if timings is not None:
+        timings.update(T)
+    nd, nc = engine.counts()
+    return dict(attempts1=attempts[1], attempts2=attempts[2], capped=capped, n_diffuse=nd, n_caustic=nc)
 
 
-def band_plan(height, world, band=16):
-    """row bands interleaved over ranks: band i -> rank i % world"""
-    return [(y0, min(band, height - y0), (y0 // band) % world) for y0 in range(0, height, band)]
+def _first_rows(shard, m):
+    """the first m records of a shard tensor, padded with zero rows if the shard's capacity is smaller"""
+    if shard.shape[0] >= m:
+        return shard[:m]
+    pad = torch.zeros((m - shard.shape[0], shard.shape[1]), dtype=shard.dtype, device=shard.device)
+    return torch.cat([shard, pad])
 
 
-def render_sharded(engine, width, height, band=16, device="cpu"):
-    """Every rank renders its bands; rank 0 returns the assembled post-floor RGBA frame, others None."""
+def band_rows_of(height, band, world, rank):
+    """rows of the frame in rank's interleaved bands (band i -> rank i % world), top to bottom"""
+    y = np.arange(height)
+    return y[(y // band) % world == rank]
+
+
+def render_sharded(engine, width, height, band=16, out=None):
+    """Every rank traces its row bands; rank 0 returns the assembled (height, width, C) frame tensor, others None.
+    The per-rank parts travel as device tensors (padded to the longest part)."""
     rank, world = _world()
-    plan = band_plan(height, world, band)
-    mine = {y0: engine.render(0, y0, width, h) for (y0, h, r) in plan if r == rank}
+    part = engine.render_bands(width, height, band, world, rank)      # (rows_k, width, C) tensor on the engine's device
     if world == 1:
-        frame = np.zeros((height, width, 4))
-        for y0, img in mine.items():
-            frame[y0:y0 + img.shape[0]] = img
-        return frame
-    rows = max(1, sum(h for (_, h, r) in plan if r == 0))       # rank 0 owns the most rows
-    buf = torch.zeros((rows, width, 4), dtype=torch.float64, device=device)
-    o = 0
-    for (y0, h, r) in plan:
-        if r == rank:
-            buf[o:o + h] = torch.from_numpy(mine[y0]).to(device)
-            o += h
-    parts = [torch.empty_like(buf) for _ in range(world)] if rank == 0 else None
-    dist.gather(buf, parts, dst=0)
+        return part
+    rows_max = max(len(band_rows_of(height, band, world, k)) for k in range(world))
+    if part.shape[0] < rows_max:
+        part = torch.cat([part, torch.zeros((rows_max - part.shape[0],) + tuple(part.shape[1:]), dtype=part.dtype, device=part.device)])
+    parts = [torch.empty_like(part) for _ in range(world)] if rank == 0 else None
+    dist.gather(part.contiguous(), parts, dst=0)
     if rank != 0:
         return None
-    frame = np.zeros((height, width, 4))
-    offs = [0] * world
-    for (y0, h, r) in plan:
-        frame[y0:y0 + h] = parts[r][offs[r]:offs[r] + h].cpu().numpy()
-        offs[r] += h
+    frame = out if out is not None else torch.empty((height, width) + tuple(part.shape[2:]), dtype=part.dtype, device=part.device)
+    for k in range(world):
+        rows = torch.from_numpy(band_rows_of(height, band, world, k)).to(part.device)
+        frame.index_copy_(0, rows, parts[k][:rows.numel()])
     return frame
 
 
-class GpuEngine:
-    """adapter: capi.Scene (+ photon maps) -> the engine interface above"""
+class DeviceEngine:
+    """librt355 behind the engine interface: shards, lists and frames stay in this rank's GPU memory"""
 
-    def __init__(self, scene, params, diffuse=None, caustic=None):
-        self.scene, self.params, self.diffuse, self.caustic = scene, params, diffuse, caustic
+    def __init__(self, scene, params, fmt=None, device="cuda"):
+        from . import capi
+        self.capi, self.scene, self.params, self.device = capi, scene, params, device
+        self.fmt = capi.SHARD_PACKED if fmt is None else fmt
+        self.lists = scene.ctx.lists(params, self.fmt)
+        self.words = self.lists.words
+        self.maps = [None, None]
+        self._nd = self._nc = 0
 
-    def emit(self, phase, a0, a1):
-        rec, att, kind, _ = self.scene.emit_photons(self.params, phase, a0, a1)
-        return rec, att, kind
+    def caps(self):
+        return self.params.num_photons_diffuse, self.params.num_photons_caustic
 
-    def render(self, x0, y0, w, h):
-        return self.scene.trace_tile(self.params, self.diffuse, self.caustic, x0=x0, y0=y0, w=w, h=h, want=("post",))["post"]
+    def counts(self):
+        return self._nd, self._nc
+
+    def phase_done(self, phase):
+        return self._nd >= self.params.num_photons_diffuse if phase == 1 else self._nc >= self.params.num_photons_caustic
+
+    def sync(self):
+        """host wait for the library's streams and for torch's (the two sides hand buffers to each other)"""
+        self.scene.ctx.synchronize()
+        if str(self.device).startswith("cuda"):
+            torch.cuda.synchronize()
+
+    def emit_shard(self, phase, a0, a1, tag_base):
+        cap = max(a1 - a0, 1)                                         # every attempt stores at most one photon
+        buf = torch.empty((cap, self.words + 1), dtype=torch.int32, device=self.device)     # (torch's allocator recycles these)
+        n = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self.scene.emit_shard(self.params, phase, a0, a1, self.fmt, tag_base, buf, n, cap=cap)
+        return buf, n
+
+    def apply(self, phase, tag_base, merged, counts, n_shards, stride):
+        info = self.lists.apply(phase, tag_base, merged.contiguous(), counts.contiguous(), n_shards, stride)
+        self._nd, self._nc = info["n_diffuse"], info["n_caustic"]
+        return bool(info["phase_ended"]), int(info["last_attempt"])
+
+    def build_maps(self):
+        """the replicated, deterministic kd-tree builds (identical on every rank)"""
+        self.maps = [self.lists.photon_map(w) if n else None for w, n in ((0, self._nd), (1, self._nc))]
+        return self.maps
+
+    def render_bands(self, width, height, band, world, rank, out=None):
+        capi = self.capi
+        q = capi.Params.from_buffer_copy(self.params)
+        q.band_rows, q.band_count, q.band_index = (band, world, rank) if world > 1 else (0, 0, 0)
+        rows = self.scene.ctx.band_rows(height, band, world, rank) if world > 1 else height
+        if out is None:
+            out = torch.empty((rows, width, 4), dtype=torch.uint8, device=self.device)
+        if rows:
+            self.scene.trace_tile(q, self.maps[0], self.maps[1], x0=0, y0=0, w=width, h=height, want=(), out_rgba8=out, stats=False)
+        return out

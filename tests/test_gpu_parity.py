@@ -394,17 +394,6 @@ def same_px(a, b):
     return ((a == b) | (np.isnan(a) & np.isnan(b))).all(axis=-1)
 
 
-def test_sharded_protocol_on_gpu_equals_emit_many(c1_emit):
-    """the multi-GPU emission protocol (attempt sub-ranges + caps on the merged sequence), run through
-    rt_emit_photons on one GPU, reproduces rt_emit_many"""
-    from raytracer_amd import parallel
-    sc, p, whole = c1_emit
-    res = parallel.emit_sharded(parallel.GpuEngine(sc, p), 10000, 10000, batch=5000)
-    assert same(res["diffuse"], whole["diffuse"]) and same(res["caustic"], whole["caustic"])
-    assert np.array_equal(res["diffuse_attempt"], whole["diffuse_attempt"])
-    assert res["attempts1"] == whole["stats"]["attempts_phase1"] and res["attempts2"] == whole["stats"]["attempts_phase2"]
-
-
 # ------------------------------------------------------------------ mode A: the older tracer (ray.js)
 @pytest.mark.parametrize("preset,rays", [(2, 52993), (3, 59233), (0, 58604), (1, 90165)])
 def test_image_mode_a_f64_matches_reference(rt, preset, rays):
@@ -924,3 +913,99 @@ def test_join_orders_the_main_stream_behind_frames_in_flight(rt):
         ctx.set_frames_in_flight(1)
     for w, g in zip(want, got):
         assert np.array_equal(g, w)
+
+
+# ------------------------------------------------------------------ device-resident photon lists, shards, row bands
+def test_emission_segment_count_is_the_sequential_loops(c1_emit):
+    """stats.segments = emitPhoton calls of exactly the attempts the sequential loop runs (not of whole batches)"""
+    sc, p, e = c1_emit
+    osc = ora.Scene(load_scene(10))
+    oe = ora.emit_many(osc, ora.params(num_photons_diffuse=10000, num_photons_caustic=10000, seed=SEED))
+    assert e["stats"]["segments"] == oe["segments"]
+
+
+def test_device_lists_and_maps_equal_the_host_path(rt):
+    """rt_emit_many_lists keeps the lists on the GPU: exported, they are rt_emit_many's lists; a photon map built straight
+    from a list (full or packed 36-byte records) is the map built from the exported records"""
+    capi, ctx = rt
+    sc = ctx.upload(load_scene(10))
+    hits = load_bundle("queries_c1")["queries"][:512]
+    rng = np.random.default_rng(4)
+    nrm = rng.normal(size=(hits.shape[0], 3))
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    hits = np.concatenate([hits, nrm, rng.uniform(0, 255, (hits.shape[0], 3))], axis=1).astype(np.float32)
+    for prec in (capi.PRECISION_F64, capi.PRECISION_F32):
+        p = capi.default_params(precision=prec, num_photons_diffuse=6000, num_photons_caustic=3000, seed=SEED)
+        whole = sc.emit_many(p)
+        full, st = sc.emit_many_lists(p, capi.SHARD_FULL)
+        assert st == whole["stats"]
+        for which, name in ((0, "diffuse"), (1, "caustic")):
+            rec, att = full.export(which)
+            assert same(rec, whole[name]) and np.array_equal(att, whole[name + "_attempt"])
+        packed, st2 = sc.emit_many_lists(p, capi.SHARD_PACKED)
+        assert st2 == whole["stats"] and packed.words == 9
+        for which, name in ((0, "diffuse"), (1, "caustic")):
+            _, att = packed.export(which, records=False)
+            assert np.array_equal(att, whole[name + "_attempt"])
+            ref = ctx.photon_map(whole[name])
+            rperm, rdim = ref.nodes()
+            r = 0.4 if which == 0 else 0.15
+            want = ref.gather(hits, r=r)
+            for lst in (full, packed):
+                m = lst.photon_map(which)
+                perm, dim = m.nodes()
+                assert np.array_equal(perm, rperm) and np.array_equal(dim, rdim)
+                assert np.array_equal(m.gather(hits, r=r), want) and np.array_equal(m.gather(hits, k=16), ref.gather(hits, k=16))
+            # the packed records themselves, through the host: rt_photon_map_build_packed
+            w = whole[name]
+            pk = np.concatenate([w[:, :6], w[:, 7:10] * w[:, 6:7]], axis=1).astype(np.float32)
+            m = ctx.photon_map_packed(pk)
+            assert np.array_equal(m.nodes()[0], rperm) and np.array_equal(m.gather(hits, r=r), want)
+
+
+def test_sharded_emission_through_device_lists(c1_emit):
+    """the multi-GPU emission protocol on one GPU: every batch is cut into 3 ranks' attempt sub-ranges, each emitted into
+    its own shard (device memory), the shards applied in rank order -- the lists are rt_emit_many's"""
+    import torch
+    from raytracer_amd import parallel
+    sc, p, whole = c1_emit
+    capi = __import__("raytracer_amd.capi", fromlist=["x"])
+    for fmt in (capi.SHARD_FULL, capi.SHARD_PACKED):
+        eng = parallel.DeviceEngine(sc, p, fmt=fmt, device="cuda")
+        res = parallel.emit_sharded(eng, batch=7001, world_override=3)
+        assert res["attempts1"] == whole["stats"]["attempts_phase1"] and res["attempts2"] == whole["stats"]["attempts_phase2"]
+        for which, name in ((0, "diffuse"), (1, "caustic")):
+            rec, att = eng.lists.export(which, records=fmt == capi.SHARD_FULL)
+            assert np.array_equal(att, whole[name + "_attempt"])
+            if rec is not None:
+                assert same(rec, whole[name])
+
+
+@pytest.mark.parametrize("size,band,count", [((640, 360), 8, 3), ((1000, 563), 16, 8), ((320, 40), 32, 2)])
+def test_row_bands_assemble_to_the_whole_frame(rt, size, band, count):
+    """rt_params.band_*: every rank's interleaved row bands, put back together, are the undivided frame bit for bit"""
+    capi, ctx = rt
+    W, H = size
+    sc = ctx.upload(load_scene(10, W, H))
+    for prec, kw in ((capi.PRECISION_F32, dict(use_direct_light=0, use_photon_maps=0)), (capi.PRECISION_F64, dict(use_photon_maps=0, sub_sample=2))):
+        if prec == capi.PRECISION_F64 and W > 700:
+            continue
+        p = capi.default_params(precision=prec, seed=9, shadow_bias=1e-4, **kw)
+        whole = sc.trace_tile(p, want=("pre", "rgba8"))
+        got = np.full_like(whole["pre"], -1.0)
+        got8 = np.zeros_like(whole["rgba8"])
+        rays = 0
+        for idx in range(count):
+            q = capi.default_params(precision=prec, seed=9, shadow_bias=1e-4, band_rows=band, band_count=count, band_index=idx, **kw)
+            rows = np.array([y for y in range(H) if (y // band) % count == idx], dtype=np.int64)
+            assert ctx.band_rows(H, band, count, idx) == rows.size
+            part = sc.trace_tile(q, want=("pre", "rgba8"))
+            if rows.size == 0:
+                continue
+            assert part["pre"].shape[0] == rows.size
+            got[rows] = part["pre"]
+            got8[rows] = part["rgba8"]
+            rays += part["stats"]["rays"]
+        assert same(got, whole["pre"]) and np.array_equal(got8, whole["rgba8"]) and rays == whole["stats"]["rays"]
+    with pytest.raises(capi.RtError):
+        sc.trace_tile(capi.default_params(band_rows=12, band_count=2, band_index=0))
