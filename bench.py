@@ -1,13 +1,19 @@
 #!/usr/bin/env python3
-"""Headline benchmark: Mrays/s (primary + secondary segments) of the wavefront tracer on the
-reference's default scene at 1920x1080, 1 spp, reflection/refraction only -- plus, as extra
-fields of the same JSON line, photon k-NN gathers/s on a 1M-photon map.
+"""Headline benchmark: Mrays/s (primary + secondary segments) of the wavefront tracer on the reference's default
+scene at 1920x1080, 1 spp, reflection/refraction only -- plus, as extra fields of the same JSON line, photon k-NN
+gathers/s on a 1M-photon map, photon emission, the kd-tree build and the other BASELINE configurations.
 
-  python bench.py --gpus N --steps K --warmup W      (N > 1: launched by torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W      (N > 1: launched by torch.distributed.run, one rank per GPU)
 
-A step is one full-frame pass of the hot path.  With N ranks every rank renders its own frame
-(same scene, its own RNG key: independent sub-sample passes), so scaling is weak and no
-collective sits on the data path; frames are gathered to rank 0 after the timed region only.
+A step is one full-frame pass of the hot path.
+  N = 1   every step renders the frame on the one GPU (frames queued back to back, two in flight).
+  N > 1   ONE job over N ranks, the split of the north star: photon emission sharded by attempt range, the photon
+          shards all-gathered from and into device memory (RCCL), the list caps applied and the kd-trees built
+          identically on every rank, then every step's frame traced as interleaved row bands, one share per rank,
+          and gathered to rank 0.  `value` is the frames' segments per second (strong scaling); the emission,
+          all-gather and build phases are reported under "phases".
+          --independent-frames gives the old mode instead: every rank renders whole frames of its own (weak scaling,
+          no collective in the timed region).
 """
 import argparse
 import json
@@ -23,49 +29,99 @@ sys.path.insert(0, ROOT)
 # algorithmic flop per ray/primitive test, by primitive type (add/sub/mul/div/sqrt = 1, FMA = 2,
 # compare/abs/neg/select = 0; the path that reaches the first candidate root's validity test)
 FLOP_PER_TEST = {0: 14, 1: 20, 2: 34, 3: 54, 4: 46, 5: 45, 6: 30, 7: 32}
-PEAK_FP32_VALU_TFLOPS = 157.3      # 256 CU x 4 SIMD x 32 lanes x 2 (FMA) x 2 (packed) x 2.4 GHz
+PEAK_FP32_VALU_TFLOPS = 157.3      # 256 CU x 4 SIMD x 64 flop/clk (32 lanes x FMA) x 2.4 GHz; packed fp32 issues at half rate, so it is the same peak
 PEAK_HBM_GBS = 8000.0
 BYTES_PER_GATHER = 64 * 36 + 36 + 12
+PROFILE_TAG = "r02"
 
 
 def measured_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed PMC passes of this same command (rocprofv3 cannot run
-    inside the benchmark): profiles/r01_c_traffic.json, written by tools/profile_round.sh + tools/make_profiles.py."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_c_traffic.json")) as f:
-            return json.load(f)[kernel]["traffic_bytes_per_launch"]
-    except (OSError, KeyError, ValueError):
-        return None
+    inside the benchmark): profiles/<tag>_traffic.json, written by tools/profile_round.sh + tools/make_profiles.py."""
+    for tag in (PROFILE_TAG, "r01_c"):
+        try:
+            with open(os.path.join(ROOT, "profiles", f"{tag}_traffic.json")) as f:
+                return json.load(f)[kernel]["traffic_bytes_per_launch"]
+        except (OSError, KeyError, ValueError):
+            continue
+    return None
 
 
 def flop_per_ray_pass(flat):
     return int(sum(FLOP_PER_TEST[int(t)] for t in flat.shape_meta[:, 0]))
 
 
-def cpu_baseline(flat, seed, budget_s=12.0):
-    """The CPU oracle (fp64 restatement of the reference) on the same workload, one host core: whole frames with
-    successive seeds until about budget_s seconds have been spent."""
+# ------------------------------------------------------------------ CPU baselines (the oracle on the host's cores)
+def _cpu_band(job):
+    """worker: one row band of one frame with the C oracle"""
     from oracle import oracle as ora
-    osc = ora.Scene(flat)
+    flat, seed, y0, h, full = job
+    osc = _cpu_band.cache.get("scene")
+    if osc is None:
+        osc = _cpu_band.cache["scene"] = ora.Scene(flat)
+    op = ora.params(seed=seed, use_direct_light=int(full), use_photon_maps=0)
+    _, _, rays, _ = ora.render(osc, op, None, 0, y0, flat.width, h)
+    return rays
+
+
+_cpu_band.cache = {}
+
+
+def cpu_workers():
+    try:
+        share = int(os.environ.get("OMP_NUM_THREADS", "0"))
+    except ValueError:
+        share = 0
+    n = os.cpu_count() or 1
+    return max(1, min(n, share if share > 0 else 16))
+
+
+def cpu_baseline(flat, seed, budget_s=10.0):
+    """The CPU oracle (fp64 restatement of the reference; the reference's JavaScript cannot travel to the GPU box) on
+    the same workload: whole frames cut into row bands over a pool of worker processes, one per host core of this
+    job's share, for about budget_s seconds; then one frame on ONE core for the per-core figure.  Must run before the
+    process touches the GPU (the pool forks)."""
+    import multiprocessing as mp
+    workers = cpu_workers()
+    band = 8
+    bands = [(y, min(band, flat.height - y)) for y in range(0, flat.height, band)]
     rays_total, frames = 0, 0
-    t0 = time.perf_counter()
-    while True:
-        op = ora.params(seed=seed + frames, use_direct_light=0, use_photon_maps=0)
-        _, _, rays, _ = ora.render(osc, op, None, 0, 0, flat.width, flat.height)
-        rays_total += rays
-        frames += 1
-        dt = time.perf_counter() - t0
-        if dt >= budget_s or frames >= 64:
-            break
-    return {"value": rays_total / dt / 1e6, "unit": "Mrays/s", "cores": 1, "kind": "port",
-            "sample": f"{frames} full {flat.width}x{flat.height} frames of the same workload (seeds {seed}..{seed + frames - 1}), "
-                      f"{rays_total} rays in {dt:.2f} s, oracle/rt_oracle.c (fp64, bit-exact with the reference JS on its golden frames)"}
+    with mp.get_context("fork").Pool(workers) as pool:
+        pool.map(_cpu_band, [(flat, seed, y, h, False) for (y, h) in bands[:workers]])     # warm the workers (library load, scene)
+        t0 = time.perf_counter()
+        while True:
+            rays_total += sum(pool.map(_cpu_band, [(flat, seed + frames, y, h, False) for (y, h) in bands], chunksize=2))
+            frames += 1
+            dt = time.perf_counter() - t0
+            if dt >= budget_s or frames >= 64:
+                break
+    t1 = time.perf_counter()
+    one = sum(_cpu_band((flat, seed, y, h, False)) for (y, h) in bands[::8])                # every 8th band on one core
+    dt1 = time.perf_counter() - t1
+    return {"value": rays_total / dt / 1e6, "unit": "Mrays/s", "cores": workers, "kind": "port", "workers": workers,
+            "host_cpus": os.cpu_count(), "one_core_value": one / dt1 / 1e6,
+            "sample": f"{frames} full {flat.width}x{flat.height} frames of the same workload (seeds {seed}..{seed + frames - 1}) in {band}-row bands over "
+                      f"{workers} worker processes, {rays_total} rays in {dt:.2f} s; one core: every 8th band of one frame, {one} rays in {dt1:.2f} s; "
+                      "oracle/rt_oracle.c (fp64, bit-exact with the reference JS on its golden frames)"}
 
 
-def cpu_baseline_gather(rec, hits, k, n_queries=100_000):
+_KD = {}       # the oracle's tree, set before the pool forks (the workers inherit it instead of unpickling 30 MB per chunk)
+
+
+def _cpu_gather_chunk(q):
+    from oracle import oracle as ora
+    pos, perm, dim, r = _KD["tree"]
+    found = 0
+    for i in range(q.shape[0]):
+        found += ora.kd_radius(pos, perm, dim, q[i], r, cap=1024).size
+    return found
+
+
+def cpu_baseline_gather(rec, hits, k, n_queries=1_000_000):
     """CPU side of the photon-map leg: the oracle's kd-tree (the reference's makeTree / nearestNeighbours restated in C)
-    built on the same photons, and its radius query at the radius that holds k photons on average -- the reference has
-    no k-nearest query -- for a sample of the same hit points, one core."""
+    built on the same photons (one core: the build is sequential), and its radius query at the radius that holds k
+    photons on average -- the reference has no k-nearest query -- for a sample of the same hit points, over the worker pool."""
+    import multiprocessing as mp
     from oracle import oracle as ora
     pos = np.ascontiguousarray(rec[:, :3])
     t0 = time.perf_counter()
@@ -77,16 +133,20 @@ def cpu_baseline_gather(rec, hits, k, n_queries=100_000):
     r = float(np.sqrt(k * area / (np.pi * pos.shape[0])))
     rows = np.random.default_rng(0).choice(hits.shape[0], min(n_queries, hits.shape[0]), replace=False)
     q = hits[rows, :3].astype(np.float64)
-    t0 = time.perf_counter()
-    found = 0
-    for i in range(q.shape[0]):
-        found += ora.kd_radius(pos, perm, dim, q[i], r, cap=1024).size
-    dt = time.perf_counter() - t0
-    return {"value": q.shape[0] / dt, "unit": "gathers/s", "cores": 1, "kind": "port", "kd_build_s": build_s,
+    workers = cpu_workers()
+    chunks = np.array_split(q, workers * 4)
+    _KD["tree"] = (pos, perm, dim, r)
+    with mp.get_context("fork").Pool(workers) as pool:
+        pool.map(_cpu_gather_chunk, [c[:8] for c in chunks[:workers]])          # warm the workers
+        t0 = time.perf_counter()
+        found = sum(pool.map(_cpu_gather_chunk, chunks))
+        dt = time.perf_counter() - t0
+    return {"value": q.shape[0] / dt, "unit": "gathers/s", "cores": workers, "kind": "port", "kd_build_s": build_s, "kd_build_cores": 1,
             "sample": f"{q.shape[0]} of the {hits.shape[0]} hit points, radius query r={r:.4f} ({found / q.shape[0]:.1f} photons per query) "
-                      f"on the oracle's kd-tree of the same {pos.shape[0]} photons, {dt:.2f} s"}
+                      f"on the oracle's kd-tree of the same {pos.shape[0]} photons, {dt:.2f} s over {workers} worker processes"}
 
 
+# ------------------------------------------------------------------ GPU legs
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -98,14 +158,31 @@ def main():
     ap.add_argument("--knn", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="skip the photon-map (k-NN gather) leg")
-    ap.add_argument("--no-other-configs", action="store_true", help="skip the short legs for the older tracer, the 10k-primitive scene and photon emission")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the short legs for the older tracer, the 10k-primitive scene, emission and the full render")
+    ap.add_argument("--independent-frames", action="store_true", help="N > 1: every rank renders whole frames of its own (weak scaling) instead of the one-job split")
+    ap.add_argument("--photons-per-gpu", type=int, default=12_500_000, help="N > 1: stored photons per GPU of the sharded emission (half diffuse, half caustic)")
+    ap.add_argument("--band", type=int, default=16, help="N > 1: rows per interleaved band")
     args = ap.parse_args()
 
-    import torch
-    import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+
+    from raytracer_amd.scene import FlatScene
+    W, H = args.width, args.height
+    flat = FlatScene.from_json(os.path.join(ROOT, "tests", "golden", "scene_preset10_flat.json")).with_size(W, H)
+    seed = 1 + (rank if args.independent_frames else 0)
+
+    # the CPU baselines fork worker processes: they run first, before this process initialises the GPU
+    cpu_line, cpu_gather_line = None, None
+    if not args.no_cpu_baseline and world == 1:
+        from raytracer_amd import synth as _synth
+        cpu_line = cpu_baseline(flat, seed)
+        if not args.no_gather:
+            cpu_gather_line = cpu_baseline_gather(_synth.box_photons(args.photons, seed=7), _synth.box_queries(W, H), args.knn)
+
+    import torch
+    import torch.distributed as dist
     # RT355_BENCH_REHEARSAL=1: all ranks share GPU 0 and talk over gloo -- a dry run of the N > 1 control flow on a
     # one-GPU box (the numbers mean nothing); the real thing is one GPU per rank over RCCL
     rehearsal = os.environ.get("RT355_BENCH_REHEARSAL") == "1"
@@ -118,8 +195,7 @@ def main():
     dev = torch.device("cuda", local)
     cdev = torch.device("cpu") if rehearsal else dev          # where the tensors of the collectives live
 
-    from raytracer_amd import capi, synth
-    from raytracer_amd.scene import FlatScene
+    from raytracer_amd import capi, parallel, synth
 
     def barrier():
         torch.cuda.synchronize()
@@ -128,75 +204,155 @@ def main():
         torch.cuda.synchronize()
 
     ctx = capi.Context(local)
-    W, H = args.width, args.height
-    flat = FlatScene.from_json(os.path.join(ROOT, "tests", "golden", "scene_preset10_flat.json")).with_size(W, H)
     sc = ctx.upload(flat)
-    seed = 1 + rank
+    fl = flop_per_ray_pass(flat)
     p = capi.default_params(precision=capi.PRECISION_F32, use_direct_light=0, use_photon_maps=0, seed=seed, sub_sample=1)
-    in_flight = 1 if os.environ.get("RT355_BENCH_SERIAL_FRAMES") else int(os.environ.get("RT355_BENCH_IN_FLIGHT", "2"))
-    frames_out = [torch.empty((H, W, 4), dtype=torch.uint8, device=dev) for _ in range(in_flight)]   # outputs stay in HBM
-    frame = frames_out[0]
+    split = world > 1 and not args.independent_frames
+    phases = None
 
-    def step(stats=True, i=0):
-        return sc.trace_tile(p, out_rgba8=frames_out[i % in_flight], want=(), stats=stats)["stats"]
+    if not split:
+        # ---- frames of config[1] on this rank's GPU, queued back to back, two in flight
+        in_flight = 1 if os.environ.get("RT355_BENCH_SERIAL_FRAMES") else int(os.environ.get("RT355_BENCH_IN_FLIGHT", "2"))
+        frames_out = [torch.empty((H, W, 4), dtype=torch.uint8, device=dev) for _ in range(in_flight)]   # outputs stay in HBM
+        frame = frames_out[0]
 
-    ctx.profile_enable(os.environ.get("RT355_BENCH_NO_EVENTS") is None)
-    ctx.profile_select(None if os.environ.get("RT355_BENCH_ALL_EVENTS") else "primary")   # time the roofline kernel only: every event pair costs ~8 us of stream time
-    for _ in range(max(args.warmup, 1)):
-        st = step()                         # every step renders the same frame (same seed): its ray count is this one's
-    ctx.profile_reset()                     # (the warm-up's timing events go back to the library's pool)
-    # the timed frames are only queued (no statistics read back in between: that would put a host round trip after
-    # every frame) and the clock stops after the library's streams have drained
-    # Two frames in flight: consecutive frames go to alternate streams, workspaces and output buffers, so the thinly
-    # occupied end of one frame's path tracing overlaps the start of the next.
-    ctx.set_frames_in_flight(in_flight)
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(stats=False, i=i)
-    ctx.synchronize()
-    barrier()
-    dt = time.perf_counter() - t0
-    ctx.set_frames_in_flight(1)
-    rays = st["rays"] * args.steps
-    bounces = st["bounces"] * args.steps
-    k_ms, k_launches = ctx.profile_get("primary")        # the fused first pass: the roofline kernel
-    # for the report only, a few extra steps outside the timed region, one frame at a time: the tail kernel's duration,
-    # and the first pass's when it has the chip to itself (in the timed region it shares it with the previous frame's tail)
-    ctx.profile_select("primary,tail")
-    ctx.profile_reset()
-    for _ in range(3):
-        step()
-    tail_ms, tail_launches = ctx.profile_get("tail")
-    tail_ms = tail_ms / max(1, tail_launches) * args.steps
-    kx_ms, kx_launches = ctx.profile_get("primary")
-    ctx.profile_enable(False)
+        def step(stats=True, i=0):
+            return sc.trace_tile(p, out_rgba8=frames_out[i % in_flight], want=(), stats=stats)["stats"]
 
-    tot = torch.tensor([float(rays), dt], dtype=torch.float64, device=cdev)
-    if world > 1:
-        rays_all = tot[0:1].clone()
-        dist.all_reduce(rays_all, op=dist.ReduceOp.SUM)
-        tmax = tot[1:2].clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        rays_total, t_total = float(rays_all.item()), float(tmax.item())
-        fr = frame.to(cdev)
-        frames = [torch.empty_like(fr) for _ in range(world)] if rank == 0 else None
-        dist.gather(fr, frames, dst=0)                                     # tiles/frames to rank 0 (outside the timed region)
+        ctx.profile_enable(os.environ.get("RT355_BENCH_NO_EVENTS") is None)
+        ctx.profile_select(None if os.environ.get("RT355_BENCH_ALL_EVENTS") else "tail")   # time the dominant kernel only: every event pair costs stream time
+        for _ in range(max(args.warmup, 1)):
+            st = step()                         # every step renders the same frame (same seed): its ray count is this one's
+        ctx.profile_reset()                     # (the warm-up's timing events go back to the library's pool)
+        # the timed frames are only queued (no statistics read back in between) and the clock stops after the library's
+        # streams have drained.  Two frames in flight: consecutive frames go to alternate streams, workspaces and output
+        # buffers, so the thinly occupied end of one frame's path tracing overlaps the start of the next.
+        ctx.set_frames_in_flight(in_flight)
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(stats=False, i=i)
+        t_submit = time.perf_counter() - t0    # host time to queue the frames (the GPU is still running)
+        ctx.synchronize()
+        barrier()
+        dt = time.perf_counter() - t0
+        ctx.set_frames_in_flight(1)
+        rays = st["rays"] * args.steps
+        bounces = st["bounces"] * args.steps
+        tail_ms, tail_launches = ctx.profile_get("tail")          # the dominant kernel of the frame
+        # for the report only, a few extra steps outside the timed region, one frame at a time: both kernels with the
+        # chip to themselves (in the timed region a kernel shares it with the neighbouring frame's other kernel)
+        ctx.profile_select("primary,tail")
+        ctx.profile_reset()
+        for _ in range(5):
+            step()
+        tx_ms, tx_n = ctx.profile_get("tail")
+        px_ms, px_n = ctx.profile_get("primary")
+        ctx.profile_enable(False)
+        tot = torch.tensor([float(rays), dt], dtype=torch.float64, device=cdev)
+        if world > 1:
+            rays_all = tot[0:1].clone()
+            dist.all_reduce(rays_all, op=dist.ReduceOp.SUM)
+            tmax = tot[1:2].clone()
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            rays_total, t_total = float(rays_all.item()), float(tmax.item())
+            fr = frame.to(cdev)
+            frames = [torch.empty_like(fr) for _ in range(world)] if rank == 0 else None
+            dist.gather(fr, frames, dst=0)                                     # frames to rank 0 (outside the timed region)
+        else:
+            rays_total, t_total = float(rays), dt
+        tail_rays = (rays - W * H * args.steps) // args.steps
+        parallelism = f"{world} independent frame(s), one per GPU"
+        scaling = "weak"
     else:
-        rays_total, t_total = float(rays), dt
+        # ---- ONE job over all ranks: sharded emission -> all-gather -> replicated build -> band-split frames -> gather
+        in_flight = 1
+        per_gpu = args.photons_per_gpu
+        nd = nc = (per_gpu * world) // 2
+        pe = capi.default_params(precision=capi.PRECISION_F32, num_photons_diffuse=nd, num_photons_caustic=nc, seed=seed)
+        if rehearsal:
+            eng = _RehearsalEngine(sc, pe, device=dev)
+        else:
+            eng = parallel.DeviceEngine(sc, pe, fmt=capi.SHARD_PACKED, device=dev)
+        T = {}
+        barrier()
+        t0 = time.perf_counter()
+        res = parallel.emit_sharded(eng, batch=min(world * (8 << 20), 1 << 30), timings=T)
+        barrier()
+        t_emit = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        eng.build_maps()
+        barrier()
+        t_build = time.perf_counter() - t0
+        # frames of config[1], every frame's row bands interleaved over the ranks and gathered to rank 0
+        reng = parallel.DeviceEngine(sc, p, device=dev, with_lists=False)      # config[1] frames: no maps, no lists
+        if rehearsal:
+            reng = _RehearsalEngine(sc, p, device=dev, inner=reng)
+        rows = ctx.band_rows(H, args.band, world, rank)
+        st_full = sc.trace_tile(p, want=())["stats"]                     # the whole frame once, for its segment count (every rank, same number)
+        bufs = [torch.empty((rows, W, 4), dtype=torch.uint8, device=dev) for _ in range(2)]
+        frame0 = torch.empty((H, W, 4), dtype=torch.uint8, device=cdev) if rank == 0 else None
+
+        def frame_step(i):
+            reng.out = bufs[i % 2]
+            parallel.render_sharded(reng, W, H, band=args.band, out=frame0)
+
+        for i in range(max(args.warmup, 1)):
+            frame_step(i)
+        barrier()
+        t0 = time.perf_counter()
+        t_render = 0.0
+        for i in range(args.steps):
+            frame_step(i)
+        barrier()
+        dt = time.perf_counter() - t0
+        tmax = torch.tensor([dt], dtype=torch.float64, device=cdev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        t_total = float(tmax.item())
+        rays = st_full["rays"] * args.steps
+        rays_total = float(rays)
+        bounces = st_full["bounces"] * args.steps
+        tail_rays = st_full["tail_rays"]
+        tail_ms = tail_launches = tx_ms = tx_n = px_ms = px_n = 0
+        t_submit = 0.0
+        stored = res["n_diffuse"] + res["n_caustic"]
+        ag_bytes = T.get("allgather_bytes", 0)
+        phases = {
+            "emission": {"seconds": t_emit, "stored_photons": stored, "stored_photons_per_s": stored / t_emit, "attempts": res["attempts1"] + res["attempts2"],
+                         "rounds": T.get("rounds"), "emit_kernel_s": T.get("emit_s"), "exchange_s": T.get("exchange_s"), "caps_s": T.get("apply_s"),
+                         "record_bytes": 40, "note": "36-byte packed photon + 4-byte tag per stored photon, all-gathered from and into device memory"},
+            "allgather_bytes": ag_bytes, "allgather_gbps": (ag_bytes / T["exchange_s"] / 1e9) if T.get("exchange_s") else None,
+            "kd_build": {"seconds": t_build, "photons": stored, "note": "both maps, built identically on every rank from its own copy of the lists"},
+            "render": {"seconds": dt, "frames": args.steps, "ms_per_frame": dt / args.steps * 1e3, "band_rows": args.band,
+                       "gather_bytes_per_frame": W * H * 4, "note": "every frame: this rank's interleaved bands in one rt_trace_tile call, then gathered to rank 0"},
+        }
+        parallelism = f"one job over {world} GPUs: emission by attempt range, photon all-gather, replicated kd build, frames split into interleaved {args.band}-row bands gathered to rank 0"
+        scaling = "strong"
 
     # ---- photon-map leg: 1M-photon kd-tree build + k-NN radiance gather per pixel ----
     extra = {}
-    roof_gather = None
+    roof_gather = roof_build = roof_emit = None
     if not args.no_gather:                        # (every rank runs the report-only legs: they hold barriers)
         rec_host, hits_host = synth.box_photons(args.photons, seed=7), synth.box_queries(W, H)
         rec = torch.from_numpy(rec_host).to(dev)
         hits = torch.from_numpy(hits_host).to(dev)
         rgb = torch.empty((hits.shape[0], 3), dtype=torch.float32, device=dev)
+        pm = ctx.photon_map(rec)                  # warm-up build (first-use costs of the sort library)
+        del pm
         torch.cuda.synchronize()
-        tb = time.perf_counter()
-        pm = ctx.photon_map(rec)
-        build_s = time.perf_counter() - tb
+        builds = []
+        for _ in range(3):
+            tb = time.perf_counter()
+            pm = ctx.photon_map(rec)
+            builds.append(time.perf_counter() - tb)
+        build_s = min(builds)
+        n_ph = args.photons
+        levels = int(np.ceil(np.log2(max(n_ph, 2))))
+        build_bytes = n_ph * (12 + 12) * levels + n_ph * 5
+        roof_build = {"kernel": "photon map build (all launches of rt_photon_map_build: position extract, level-synchronous kd build, permute)", "bound": "hbm",
+                      "achieved": build_bytes / build_s / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": build_bytes / build_s / 1e9 / PEAK_HBM_GBS,
+                      "traffic": None, "algorithmic_bytes": build_bytes, "seconds": build_s, "photons": n_ph,
+                      "note": "algorithmic bytes = N x (12 B read + 12 B written) x ceil(log2 N) + 5 N; time = host clock around the whole call, best of 3"}
         pm.gather(hits, k=args.knn, out=rgb)                               # warm-up
         ctx.profile_enable(True)
         ctx.profile_select("gather_knn,gather_knn_heap_fallback")
@@ -223,16 +379,33 @@ def main():
         roof_gather = {"kernel": "k_gather_knn_wave", "bound": "hbm", "achieved": g_achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                        "frac": g_achieved / PEAK_HBM_GBS, "traffic": measured_traffic("k_gather_knn_wave"),
                        "algorithmic_bytes_per_gather": BYTES_PER_GATHER, "avg_launch_ms": g_ms / g_launches}
+        # the same gather on less friendly inputs: the queries in raster order instead of 8x8 tiles, and a real emitted map
+        # (the default scene's caustic + diffuse photons) queried at the frame's own first-hit points
+        order = np.arange(W * H).reshape(H // 8, 8, W // 8, 8).transpose(0, 2, 1, 3).reshape(-1) if (H % 8 == 0 and W % 8 == 0) else None
+        if order is not None:
+            raster = torch.from_numpy(np.ascontiguousarray(hits_host[np.argsort(order)])).to(dev)
+            pm.gather(raster, k=args.knn, out=rgb)
+            ctx.synchronize()
+            tg = time.perf_counter()
+            for _ in range(2):
+                pm.gather(raster, k=args.knn, out=rgb)
+            ctx.synchronize()
+            extra["knn_raster_order"] = {"gathers_per_s": 2 * hits.shape[0] / (time.perf_counter() - tg),
+                                         "note": "same queries, row by row (a wave's 64 queries are a 64-pixel strip instead of an 8x8 patch)"}
+            del raster
+        del pm, rec
 
     # ---- short legs for the other BASELINE configs (reported under "extra", never part of `value`) ----
     if not args.no_other_configs:
-        def timed_frames(scene, params, out, n=5):
+        frame = torch.empty((H, W, 4), dtype=torch.uint8, device=dev)
+
+        def timed_frames(scene, params, out, n=5, maps=(None, None)):
             for _ in range(2):
-                stt = scene.trace_tile(params, out_rgba8=out, want=())["stats"]
+                stt = scene.trace_tile(params, maps[0], maps[1], out_rgba8=out, want=())["stats"]
             ctx.synchronize()
             t_ = time.perf_counter()
             for _ in range(n):
-                stt = scene.trace_tile(params, out_rgba8=out, want=())["stats"]
+                stt = scene.trace_tile(params, maps[0], maps[1], out_rgba8=out, want=())["stats"]
             ctx.synchronize()
             return (time.perf_counter() - t_) / n, stt
         # the older tracer (ray.js) on its preset 3 at the same resolution
@@ -251,49 +424,139 @@ def main():
                                               "primitives": int(flat4.n_shapes), "prim_tests": st4["prim_tests"], "brute_force_tests": brute,
                                               "tests_avoided_frac": 1.0 - st4["prim_tests"] / brute}
         del frame4
-        # photon emission (the configs[4] kernel on one GPU's share): 2 M diffuse + 2 M caustic photons of the default scene
-        pe = capi.default_params(precision=capi.PRECISION_F32, num_photons_diffuse=2_000_000, num_photons_caustic=2_000_000, seed=seed)
-        sc.emit_many(pe, strict=False)
+        # photon emission on one GPU (the configs[4] kernel): 2 M diffuse + 2 M caustic photons of the default scene, the lists
+        # kept in device memory as packed 36-byte photons, then both kd-trees straight from the lists
+        pe1 = capi.default_params(precision=capi.PRECISION_F32, num_photons_diffuse=2_000_000, num_photons_caustic=2_000_000, seed=seed)
+        lists, _ = sc.emit_many_lists(pe1, capi.SHARD_PACKED, strict=False)
+        del lists
+        ctx.profile_enable(True)
+        ctx.profile_select("photon_emit_bounce")
+        ctx.profile_reset()
+        ctx.synchronize()
         t_ = time.perf_counter()
-        em = sc.emit_many(pe, strict=False)["stats"]
+        lists, em = sc.emit_many_lists(pe1, capi.SHARD_PACKED, strict=False)
+        ctx.synchronize()
         dte = time.perf_counter() - t_
-        extra["photon_emission"] = {"stored_photons_per_s": (em["n_diffuse"] + em["n_caustic"]) / dte, "segments_per_s": em["segments"] / dte,
-                                    "attempts": em["attempts_phase1"] + em["attempts_phase2"], "seconds": dte,
-                                    "note": "includes copying the 11-double records to host memory"}
+        e_ms, e_n = ctx.profile_get("photon_emit_bounce")
+        ctx.profile_enable(False)
+        t_ = time.perf_counter()
+        md, mc = lists.photon_map(0), lists.photon_map(1)
+        ctx.synchronize()
+        dtm = time.perf_counter() - t_
+        stored = em["n_diffuse"] + em["n_caustic"]
+        extra["photon_emission"] = {"stored_photons_per_s": stored / dte, "segments_per_s": em["segments"] / dte,
+                                    "attempts": em["attempts_phase1"] + em["attempts_phase2"], "segments": em["segments"], "seconds": dte,
+                                    "emit_kernel_ms": e_ms, "emit_kernel_launches": e_n, "maps_from_lists_s": dtm,
+                                    "note": "rt_emit_many_lists: photons stay in device memory (packed 36-byte records), list caps applied on the GPU, "
+                                            "8 words read back per batch; segments = emitPhoton calls of the attempts the sequential loop runs"}
+        if e_ms > 0:
+            # (the kernel also runs the attempts of a last batch beyond the one that ends a phase: its own segment count is the rate's numerator)
+            ach = em["segments"] * fl / (e_ms * 1e-3) / 1e12
+            roof_emit = {"kernel": "k_emit<float> (createPhoton + the emitPhoton random walk, one attempt per lane; every segment scans all primitives)",
+                         "bound": "valu", "achieved": ach, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_VALU_TFLOPS,
+                         "traffic": None, "algorithmic_flop_per_segment": fl, "segments": em["segments"], "kernel_ms": e_ms, "launches": e_n,
+                         "note": "segments counted are those of the sequential loop; the launches also trace the surplus attempts of each phase's last batch"}
+        # the reference's actual render (mode B): direct light + both radius gathers on those maps, one 1080p frame
+        pf = capi.default_params(precision=capi.PRECISION_F32, num_photons_diffuse=2_000_000, num_photons_caustic=2_000_000, seed=seed, shadow_bias=1e-4)
+        dtf, stf = timed_frames(sc, pf, frame, n=3, maps=(md, mc))
+        extra["full_mode_b_frame"] = {"ms_per_frame": dtf * 1e3, "Mrays_per_s": stf["rays"] / dtf / 1e6, "rays_per_frame": stf["rays"],
+                                      "shadow_rays_per_frame": stf["shadow_rays"], "gathers_per_frame": stf["gathers"], "gathers_per_s": stf["gathers"] / dtf,
+                                      "photons": stored, "note": "direct light, diffuse (r = 0.40) and caustic (r = 0.15) radius gathers: the reference's traceRay in full"}
+        # the k-nearest gather on that real map at the frame's own first-hit points
+        if not args.no_gather:
+            hp = capi.default_params(precision=capi.PRECISION_F32, use_direct_light=0, use_photon_maps=0, seed=seed, max_bounces=1)
+            real_hits = synth.first_hit_queries(sc, hp, W, H)
+            if real_hits.shape[0]:
+                rh = torch.from_numpy(real_hits).to(dev)
+                out_r = torch.empty((rh.shape[0], 3), dtype=torch.float32, device=dev)
+                mc.gather(rh, k=args.knn, out=out_r)
+                ctx.synchronize()
+                t_ = time.perf_counter()
+                for _ in range(2):
+                    mc.gather(rh, k=args.knn, out=out_r)
+                ctx.synchronize()
+                extra["knn_real_map"] = {"gathers_per_s": 2 * rh.shape[0] / (time.perf_counter() - t_), "photons": em["n_caustic"], "queries": int(rh.shape[0]),
+                                         "note": "the default scene's emitted caustic map, queried at the frame's first-hit points in 8x8-tile order"}
+        del md, mc, lists
 
     if rank == 0:
-        fl = flop_per_ray_pass(flat)
-        achieved = (W * H) * fl / ((max(k_ms, 1e-9) / max(1, k_launches)) * 1e-3) / 1e12     # TFLOP/s while the kernel runs
         line = {
             "metric": "Mrays/s (primary+secondary)", "value": rays_total / t_total / 1e6, "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": t_total / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"reference default scene (preset 10, {flat.n_shapes} primitives) at {W}x{H}, 1 spp, "
                                    "primary + reflection/refraction segments only (direct light and photon gathers off)",
-                       "parallelism": f"{world} independent frame(s), one per GPU", "frames_in_flight_per_gpu": in_flight, "rays_per_step": rays // args.steps,
-                       "longest_path_segments": bounces // args.steps},
-            "roofline": {"kernel": "k_primary<float> (camera ray + closest hit among the primitives its workgroup's rays can reach + shade, one lane per primary ray; algorithmic flops count the all-primitives scan the reference does)", "bound": "valu", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_VALU_TFLOPS, "traffic": measured_traffic("k_primary"),
-                         "algorithmic_flop_per_ray_pass": fl, "avg_launch_ms": k_ms / max(1, k_launches),
-                         "launches_per_step": k_launches / args.steps, "kernel_ms_per_step": k_ms / args.steps,
-                         "rays_per_launch": W * H, "tail_kernel_ms_per_step": tail_ms / args.steps,
-                         "tail_rays_per_step": (rays - W * H * args.steps) // args.steps,
-                         "note": "the timed frames overlap in pairs (two frames in flight), so this kernel's launches share the chip "
-                                 "with the previous frame's tail kernel; `exclusive` is the same kernel over frames run one at a time",
-                         "exclusive": {"avg_launch_ms": kx_ms / max(1, kx_launches),
-                                       "achieved": (W * H) * fl / ((max(kx_ms, 1e-9) / max(1, kx_launches)) * 1e-3) / 1e12,
-                                       "frac": (W * H) * fl / ((max(kx_ms, 1e-9) / max(1, kx_launches)) * 1e-3) / 1e12 / PEAK_FP32_VALU_TFLOPS}},
+                       "parallelism": parallelism, "frames_in_flight_per_gpu": in_flight, "rays_per_step": int(rays // args.steps),
+                       "longest_path_segments": int(bounces // args.steps)},
         }
+        if not split:
+            t_avg = tail_ms / max(1, tail_launches) * 1e-3
+            tail_flop = tail_rays * fl
+            ach = tail_flop / max(t_avg, 1e-12) / 1e12
+            tx_avg, px_avg = tx_ms / max(1, tx_n) * 1e-3, px_ms / max(1, px_n) * 1e-3
+            frame_ach = (rays // args.steps) * fl / (t_total / args.steps) / 1e12
+            line["roofline"] = {
+                "kernel": "k_tail<float> (every path that survives its first hit, to its end: all-primitives closest-hit scan + shade per segment, "
+                          "256-lane groups with LDS-resident path state) -- the longer of the frame's two kernels",
+                "bound": "valu", "achieved": ach, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_VALU_TFLOPS,
+                "traffic": measured_traffic("k_tail"), "algorithmic_flop_per_ray_pass": fl, "avg_launch_ms": t_avg * 1e3,
+                "segments_per_launch": int(tail_rays), "launches_per_step": tail_launches / args.steps,
+                "note": "the timed frames overlap in pairs (two frames in flight), so a launch shares the chip with the neighbouring frame's first "
+                        "pass; `exclusive` has both kernels on frames run one at a time; `frame` is the whole frame against the driver's clock. "
+                        "bound 'valu': this path is neither HBM- nor MFMA-bound; peak = fp32 vector FMA rate (the measured sustained v_fma_f32 "
+                        "rate on this chip is 106 TFLOP/s, profiles/r02_valu_issue_rate.txt)",
+                "exclusive": {"tail": {"avg_launch_ms": tx_avg * 1e3, "achieved": tail_flop / max(tx_avg, 1e-12) / 1e12,
+                                       "frac": tail_flop / max(tx_avg, 1e-12) / 1e12 / PEAK_FP32_VALU_TFLOPS},
+                              "primary": {"avg_launch_ms": px_avg * 1e3, "rays_per_launch": W * H, "achieved": W * H * fl / max(px_avg, 1e-12) / 1e12,
+                                          "frac": W * H * fl / max(px_avg, 1e-12) / 1e12 / PEAK_FP32_VALU_TFLOPS}},
+                "frame": {"achieved": frame_ach, "frac": frame_ach / PEAK_FP32_VALU_TFLOPS, "ms": t_total / args.steps * 1e3},
+                "host_submit_ms_per_frame": t_submit / args.steps * 1e3}
+        else:
+            frame_ach = (rays // args.steps) * fl / (t_total / args.steps) / 1e12
+            line["roofline"] = {"kernel": "whole band-split frame (k_primary + k_tail on every rank, plus the gather to rank 0)", "bound": "valu",
+                                "achieved": frame_ach, "peak": PEAK_FP32_VALU_TFLOPS * world, "unit": "TFLOP/s",
+                                "frac": frame_ach / (PEAK_FP32_VALU_TFLOPS * world), "traffic": None}
+            line["phases"] = phases
+            line["allgather_gbps"] = phases["allgather_gbps"]
         if roof_gather:
             line["roofline_gather"] = roof_gather
+        if roof_build:
+            line["roofline_build"] = roof_build
+        if roof_emit:
+            line["roofline_emit"] = roof_emit
         line["extra"] = extra
-        if not args.no_cpu_baseline and world == 1:         # (the CPU baseline is reported with the single-GPU line only)
-            line["cpu_baseline"] = cpu_baseline(flat, seed)
-            if not args.no_gather:
-                line["cpu_baseline_gather"] = cpu_baseline_gather(rec_host, hits_host, args.knn)
+        if cpu_line:
+            line["cpu_baseline"] = cpu_line
+        if cpu_gather_line:
+            line["cpu_baseline_gather"] = cpu_gather_line
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()
+
+
+class _RehearsalEngine:
+    """rehearsal only (all ranks on one GPU, gloo): the device engine with its shards moved to CPU tensors for the collectives"""
+
+    def __init__(self, scene, params, device, inner=None):
+        from raytracer_amd import capi, parallel
+        self.inner = inner if inner is not None else parallel.DeviceEngine(scene, params, fmt=capi.SHARD_PACKED, device=device)
+        self.device = device
+        self.out = None
+
+    def __getattr__(self, name):
+        return getattr(self.inner, name)
+
+    def emit_shard(self, phase, a0, a1, tag_base):
+        sh, n = self.inner.emit_shard(phase, a0, a1, tag_base)
+        self.inner.sync()
+        return sh.cpu(), n.cpu()
+
+    def apply(self, phase, tag_base, merged, counts, n_shards, stride):
+        return self.inner.apply(phase, tag_base, merged.to(self.device), counts.to(self.device), n_shards, stride)
+
+    def render_bands(self, width, height, band, world, rank):
+        self.inner.out = self.out
+        return self.inner.render_bands(width, height, band, world, rank).cpu()
 
 
 if __name__ == "__main__":

@@ -115,7 +115,11 @@ def emit_sharded(engine, batch=1 << 22, world_override=None, timings=None):
         a = 0
         limit = 100 * (nd_cap if phase == 1 else nc_cap)            # rayphoton.js:1365, :1377
         while not engine.phase_done(phase):
-            b = int(min(batch, limit + 1 - a))
+            # a round runs about four times the attempts the phase's list still needs (every attempt stores at most one
+            # photon, most store none), within [65536 per rank, batch] and the reference's attempt limit
+            nd_now, nc_now = engine.counts()
+            need = (nd_cap - nd_now) if phase == 1 else (nc_cap - nc_now)
+            b = int(min(batch, max(4 * need, 65536 * nranks), limit + 1 - a))
             bounds = [a + (b * k) // nranks for k in range(nranks + 1)]   # contiguous sub-ranges in rank order = attempt order
             t0 = time.perf_counter()
             mine = range(nranks) if sim else [rank]
@@ -191,20 +195,28 @@ def render_sharded(engine, width, height, band=16, out=None):
         return None
     frame = out if out is not None else torch.empty((height, width) + tuple(part.shape[2:]), dtype=part.dtype, device=part.device)
     for k in range(world):
-        rows = torch.from_numpy(band_rows_of(height, band, world, k)).to(part.device)
-        frame.index_copy_(0, rows, parts[k][:rows.numel()])
+        key = (height, band, world, k, str(part.device))
+        if key not in _ROWS:
+            _ROWS[key] = torch.from_numpy(band_rows_of(height, band, world, k)).to(part.device)
+        frame.index_copy_(0, _ROWS[key], parts[k][:_ROWS[key].numel()])
+    if part.is_cuda:
+        torch.cuda.current_stream().synchronize()
     return frame
+
+
+_ROWS = {}
 
 
 class DeviceEngine:
     """librt355 behind the engine interface: shards, lists and frames stay in this rank's GPU memory"""
 
-    def __init__(self, scene, params, fmt=None, device="cuda"):
+    def __init__(self, scene, params, fmt=None, device="cuda", with_lists=True):
         from . import capi
         self.capi, self.scene, self.params, self.device = capi, scene, params, device
         self.fmt = capi.SHARD_PACKED if fmt is None else fmt
-        self.lists = scene.ctx.lists(params, self.fmt)
-        self.words = self.lists.words
+        self.lists = scene.ctx.lists(params, self.fmt) if with_lists else None
+        self.words = self.lists.words if with_lists else 0
+        self.out = None                                               # optional caller buffer for the next render_bands
         self.maps = [None, None]
         self._nd = self._nc = 0
 
@@ -240,8 +252,10 @@ class DeviceEngine:
         self.maps = [self.lists.photon_map(w) if n else None for w, n in ((0, self._nd), (1, self._nc))]
         return self.maps
 
-    def render_bands(self, width, height, band, world, rank, out=None):
+    def render_bands(self, width, height, band, world, rank):
+        """this rank's bands of the frame, finished (the caller hands the tensor to a collective on torch's streams)"""
         capi = self.capi
+        out = self.out
         q = capi.Params.from_buffer_copy(self.params)
         q.band_rows, q.band_count, q.band_index = (band, world, rank) if world > 1 else (0, 0, 0)
         rows = self.scene.ctx.band_rows(height, band, world, rank) if world > 1 else height
@@ -249,4 +263,5 @@ class DeviceEngine:
             out = torch.empty((rows, width, 4), dtype=torch.uint8, device=self.device)
         if rows:
             self.scene.trace_tile(q, self.maps[0], self.maps[1], x0=0, y0=0, w=width, h=height, want=(), out_rgba8=out, stats=False)
+            self.scene.ctx.synchronize()
         return out

@@ -219,3 +219,31 @@ def many_primitive_scene(n_prims: int = 10000, seed: int = 42, width: int = 3840
     b.spotlight((-6, 0, 13), 1.0, (0.2, 0.1, -1), 400)
     b.spotlight((8, -5, 13), 1.0, (-0.1, 0.2, -1), 400)
     return b.finish((-22, -22, 9), 45, -12, width, height)
+
+
+def first_hit_queries(scene, params, width, height, tile=8):
+    """Radiance-gather queries at the first-hit points of a frame's primary rays (pixel centres), ordered by
+    tile x tile image tiles like box_queries: (n, 9) float32 -- position, normal, albedo.  The hits come from the
+    library's closest-hit scan; the normal is the direction back to the camera and the albedo white (only the positions
+    shape the cost of a gather).  Rays that miss or end on a light are left out."""
+    from . import capi
+    cam = np.asarray(scene.flat.camera, np.float64)
+    o, cu, cv, cw = cam[0:3], cam[3:6], cam[6:9], cam[9:12]
+    ys, xs = np.mgrid[0:height, 0:width]
+    if height % tile == 0 and width % tile == 0:                      # tile order
+        order = np.arange(width * height).reshape(height // tile, tile, width // tile, tile).transpose(0, 2, 1, 3).reshape(-1)
+        xs, ys = xs.reshape(-1)[order], ys.reshape(-1)[order]
+    else:
+        xs, ys = xs.reshape(-1), ys.reshape(-1)
+    u = ((xs + 0.5) * 2.0 / width - 1.0) * cam[12]
+    v = -((ys + 0.5) * 2.0 / height - 1.0) * cam[13]
+    d = u[:, None] * cu + v[:, None] * cv - cw
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    org = np.broadcast_to(o, d.shape).copy()
+    t, idx = scene.intersect(params, capi.SCAN_CLOSEST, org, d)
+    light = np.zeros(scene.flat.n_shapes, bool)
+    light[np.asarray(scene.flat.light_shape, np.int64)] = True
+    keep = (idx >= 0) & np.isfinite(t)
+    keep[keep] &= ~light[idx[keep]]
+    pos = org[keep] + t[keep, None] * d[keep]
+    return np.concatenate([pos, -d[keep], np.full((pos.shape[0], 3), 255.0)], axis=1).astype(np.float32)

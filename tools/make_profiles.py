@@ -10,7 +10,7 @@ import sys
 from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-CMD = "python3 bench.py --no-cpu-baseline --no-other-configs --steps 5 --warmup 2"
+CMD = "python3 bench.py --no-cpu-baseline --steps 5 --warmup 2"
 
 
 def db(sub):
@@ -54,7 +54,7 @@ def main():
     open(os.path.join(out, f"{tag}_pmc.md"), "w").write("\n".join(pmc))
     fetch, write = largest(db("fetch"), "FETCH_SIZE"), largest(db("write"), "WRITE_SIZE")
     traffic = {}
-    for key in ("k_primary", "k_tail", "k_gather_knn_wave"):
+    for key in ("k_primary", "k_tail", "k_gather_knn_wave", "k_emit", "k_kd_lds"):
         f = [v for n, v in fetch.items() if key + "<" in n or key + "(" in n]
         w = [v for n, v in write.items() if key + "<" in n or key + "(" in n]
         if f and w:
