@@ -13,6 +13,19 @@
 #include "rt_geom.h"
 #include "rt_kdq.h"
 
+// RAII device allocation
+struct DevMem {
+  void *p = nullptr; size_t bytes = 0;
+  DevMem() = default;
+  DevMem(const DevMem &) = delete;
+  DevMem &operator=(const DevMem &) = delete;
+  ~DevMem() { release(); }
+  void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+  hipError_t alloc(size_t n) { release(); if (n == 0) n = 16; hipError_t e = hipMalloc(&p, n); if (e == hipSuccess) bytes = n; return e; }
+  hipError_t reserve(size_t n) { return (n <= bytes) ? hipSuccess : alloc(n); }    // grow-only, contents dropped
+  template <typename T> T *as() const { return (T *)p; }
+};
+
 #define RT_MAX_IN_FLIGHT 4
 // Experiment / test switches of a context.  Their defaults are the measured best; rt_init reads the RT355_* environment
 // variables ONCE into this struct and rt_set_option changes single entries afterwards, so no frame pays a getenv.
@@ -46,6 +59,7 @@ struct rt_ctx {
   }
   uint32_t *pinned = nullptr;    // small pinned scratch for counters read back each bounce
   RtKnobs knobs;
+  DevMem ws_kd;                  // kd-tree build workspace (grow-only)
   hipEvent_t frame_done[RT_MAX_IN_FLIGHT] = {};   // recorded behind the last frame queued on streams[i], i >= 1
   bool frame_pending[RT_MAX_IN_FLIGHT] = {};      // ... and not yet joined into streams[0] (rt_join) or synchronised
 };
@@ -60,19 +74,6 @@ int rt_fail(rt_ctx *ctx, int code, const char *fmt, ...);
   } while (0)
 
 #define RT_TRY(expr) do { int rc_ = (expr); if (rc_ != RT_OK) return rc_; } while (0)
-
-// RAII device allocation
-struct DevMem {
-  void *p = nullptr; size_t bytes = 0;
-  DevMem() = default;
-  DevMem(const DevMem &) = delete;
-  DevMem &operator=(const DevMem &) = delete;
-  ~DevMem() { release(); }
-  void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
-  hipError_t alloc(size_t n) { release(); if (n == 0) n = 16; hipError_t e = hipMalloc(&p, n); if (e == hipSuccess) bytes = n; return e; }
-  hipError_t reserve(size_t n) { return (n <= bytes) ? hipSuccess : alloc(n); }    // grow-only, contents dropped
-  template <typename T> T *as() const { return (T *)p; }
-};
 
 bool rt_is_device_ptr(const void *p);
 

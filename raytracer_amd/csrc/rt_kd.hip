@@ -48,7 +48,13 @@ __device__ __forceinline__ float unsortable(uint32_t u) {
   return __uint_as_float(u ^ ((u >> 31) ? 0x80000000u : 0xFFFFFFFFu));
 }
 
-struct SegState { uint32_t *pos, *start, *len; };   // per array position: heap pos of its segment (0 = finished node)
+// per array position: heap position of its segment, or KD_DONE | heap position of the node it has become
+struct SegState { uint32_t *pos, *start, *len; };
+#define KD_DONE 0x80000000u
+__global__ void __launch_bounds__(256) k_kd_iota(uint32_t n, uint32_t *idx) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) idx[i] = i;
+}
 
 __global__ void __launch_bounds__(256) k_kd_init(uint32_t n, uint32_t *idx, SegState sg) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -77,7 +83,7 @@ __global__ void __launch_bounds__(256) k_kd_bbox(uint32_t n, const float *pos3, 
   // segments are contiguous runs of active positions, so the chunk lies in one segment iff the segment of its first
   // position reaches its end
   const uint32_t sp_first = sg.pos[c0];
-  const bool one_segment = sp_first != 0 && sg.start[c0] + sg.len[c0] >= c1;
+  const bool one_segment = sp_first != 0 && !(sp_first & KD_DONE) && sg.start[c0] + sg.len[c0] >= c1;
   if (one_segment) {
     uint32_t lo[3] = { 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu }, hi[3] = { 0, 0, 0 };
     for (uint32_t i = c0 + threadIdx.x; i < c1; i += 256) {
@@ -102,6 +108,7 @@ __global__ void __launch_bounds__(256) k_kd_bbox(uint32_t n, const float *pos3, 
   for (uint32_t row = 0; row < KD_BBOX_ITEMS; row++) {            // (workgroup-uniform trip count: the shuffles below need whole waves)
     const uint32_t i = c0 + row * 256u + threadIdx.x;
     uint32_t sp = (i < n) ? sg.pos[i] : 0;
+    if (sp & KD_DONE) sp = 0;
     uint32_t lo[3] = { 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu }, hi[3] = { 0, 0, 0 };
     if (sp) {
       const float *p = pos3 + (size_t)idx[i] * 3;
@@ -124,24 +131,34 @@ __global__ void __launch_bounds__(256) k_kd_bbox(uint32_t n, const float *pos3, 
 }
 
 // widest axis in fp64, `>` strict so ties go to the lowest axis (kdtree.js:93-100)
-__device__ __forceinline__ int widest_dim(const uint32_t *bbmin, const uint32_t *bbmax, uint32_t sp) {
+__device__ __forceinline__ int widest_dim3(const uint32_t *lo, const uint32_t *hi) {
   double w[3];
-  for (int d = 0; d < 3; d++)
-    w[d] = (double)unsortable(bbmax[(size_t)sp * 3 + d]) - (double)unsortable(bbmin[(size_t)sp * 3 + d]);
+  for (int d = 0; d < 3; d++) w[d] = (double)unsortable(hi[d]) - (double)unsortable(lo[d]);
   int best = 0; double mw = w[0];
   for (int d = 1; d < 3; d++) if (w[d] > mw) { best = d; mw = w[d]; }
   return best;
 }
 
-__global__ void __launch_bounds__(256) k_kd_keys(uint32_t n, const float *pos3, const uint32_t *idx, SegState sg,
+// Sort keys of one level (heap positions [first, 2 first), first = 2^level).  The array holds the level's segments in
+// heap order with exactly one finished node between neighbours, so the high part of a key only has to number them:
+// segment j of the level gets 2 j, the finished node in front of segment j gets 2 j - 1 -- level + 1 bits instead of a
+// full array position, which saves the radix sort two of its seven passes.  Low part: the coordinate along the
+// segment's widest axis (finished nodes: 0; they are alone in their group).
+__global__ void __launch_bounds__(256) k_kd_keys(uint32_t n, const float *pos3, const uint32_t *idx, SegState sg, uint32_t first, int level,
                                                  const uint32_t *bbmin, const uint32_t *bbmax, uint8_t *segdim, uint64_t *keys) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  uint32_t sp = sg.pos[i];
-  if (!sp) { keys[i] = (uint64_t)i << 32; return; }
-  int d = widest_dim(bbmin, bbmax, sp);
+  const uint32_t sp = sg.pos[i];
+  if (sp & KD_DONE) {
+    const uint32_t q = sp & ~KD_DONE;
+    const int dq = 31 - __clz((int)q);                      // depth of node q; its right subtree starts at segment k of this level
+    const uint32_t k = ((2u * q + 1u) << (level - dq - 1)) - first;
+    keys[i] = (uint64_t)(2u * k - 1u) << 32;
+    return;
+  }
+  const int d = widest_dim3(bbmin + (size_t)sp * 3, bbmax + (size_t)sp * 3);
   if (i == sg.start[i]) segdim[sp] = (uint8_t)d;
-  keys[i] = ((uint64_t)sg.start[i] << 32) | sortable(pos3[(size_t)idx[i] * 3 + d]);
+  keys[i] = ((uint64_t)(2u * (sp - first)) << 32) | sortable(pos3[(size_t)idx[i] * 3 + d]);
 }
 
 __global__ void __launch_bounds__(256) k_kd_split(uint32_t n, const uint32_t *idx, SegState sg, const uint8_t *segdim,
@@ -149,12 +166,133 @@ __global__ void __launch_bounds__(256) k_kd_split(uint32_t n, const uint32_t *id
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   uint32_t sp = sg.pos[i];
-  if (!sp) return;
+  if (sp & KD_DONE) return;
   uint32_t s = sg.start[i], len = sg.len[i], m = find_median(len);
-  if (i == s + m) { perm[sp - 1] = (int32_t)idx[i]; dim[sp - 1] = segdim[sp]; sg.pos[i] = 0; }
+  if (i == s + m) { perm[sp - 1] = (int32_t)idx[i]; dim[sp - 1] = segdim[sp]; sg.pos[i] = sp | KD_DONE; }
   else if (i < s + m) { sg.pos[i] = 2 * sp; sg.len[i] = m; }
   else { sg.pos[i] = 2 * sp + 1; sg.start[i] = s + m + 1; sg.len[i] = len - m - 1; }
 }
+
+// ---- the lower levels: one workgroup finishes a whole subtree of up to KD_LDS_S photons in LDS
+// The same steps as above -- box, widest axis, stable sort along it, median -- level by level on the workgroup's own
+// copy of the coordinates.  The "stable sort" is a sort of unique keys (coordinate, current position): a full bitonic
+// network over the array while segments are long (group number in the key's top bits keeps every segment in place),
+// a rank count inside each segment once every segment has at most 64 photons.  Per position the segment it lies in
+// (heap position, start, length) is kept as in the global levels; the lengths of all segments of a level follow from the
+// subtree's size alone, and so does the longest one: findMedian of the previous level's longest.
+#define KD_LDS_S 2048
+#define KD_LDS_T 1024
+struct KdSeg { uint32_t pos, start, len; };
+__global__ void __launch_bounds__(KD_LDS_T) k_kd_lds(const KdSeg *segs, const float *pos3, const uint32_t *idx, uint32_t *bbmin_g, uint32_t *bbmax_g,
+                                                     int32_t *perm, uint8_t *dim_out) {
+  constexpr uint32_t S = KD_LDS_S, T = KD_LDS_T;
+  __shared__ float crd[3][S];                              // coordinates by local id (the photon's place in the segment on entry)
+  __shared__ uint16_t lid[2][S];                           // array position -> local id, double-buffered over the sorts
+  __shared__ uint32_t spos[S];
+  __shared__ uint16_t sstart[S], slen[S];
+  __shared__ uint8_t sdim[S];
+  __shared__ union { unsigned long long key[S]; uint32_t bb[(S / 2) * 6]; } u;   // boxes (by start / 2; segments of >= 2 photons) or sort keys
+  const KdSeg sg = segs[blockIdx.x];
+  const uint32_t L = sg.len, tid = threadIdx.x;
+  if (L == 0 || L > S) return;                             // (never: the host sizes the segments)
+  for (uint32_t i = tid; i < S; i += T) {
+    if (i < L) {
+      const float *p = pos3 + (size_t)idx[sg.start + i] * 3;
+      crd[0][i] = p[0]; crd[1][i] = p[1]; crd[2][i] = p[2];
+      spos[i] = sg.pos; sstart[i] = 0; slen[i] = (uint16_t)L;
+    } else { spos[i] = 0; sstart[i] = (uint16_t)i; slen[i] = 0; crd[0][i] = crd[1][i] = crd[2][i] = 0.f; }
+    lid[0][i] = (uint16_t)i; sdim[i] = 0;
+  }
+  int cur = 0;
+  bool top = true;
+  for (uint32_t maxlen = L; maxlen >= 1; maxlen = find_median(maxlen)) {
+    __syncthreads();
+    for (uint32_t k = tid; k < (S / 2) * 6; k += T) u.bb[k] = (k % 6 < 3) ? 0xFFFFFFFFu : 0u;
+    __syncthreads();
+    // boxes of the segments with at least two photons
+#pragma unroll
+    for (uint32_t r = 0; r < S / T; r++) {
+      const uint32_t i = tid + r * T;
+      const bool active = spos[i] != 0 && slen[i] >= 2;
+      const uint32_t s = sstart[i];
+      uint32_t lo[3] = { 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu }, hi[3] = { 0, 0, 0 };
+      if (active) { const uint32_t l = lid[cur][i]; for (int d = 0; d < 3; d++) { lo[d] = hi[d] = sortable(crd[d][l]); } }
+      const uint32_t s0 = __shfl(s, 0, 64);
+      if (__all(active && s == s0)) {
+        for (int off = 32; off > 0; off >>= 1)
+          for (int d = 0; d < 3; d++) {
+            const uint32_t a = __shfl_xor(lo[d], off, 64), b = __shfl_xor(hi[d], off, 64);
+            lo[d] = min(lo[d], a); hi[d] = max(hi[d], b);
+          }
+        if ((tid & 63) == 0) for (int d = 0; d < 3; d++) { atomicMin(&u.bb[(s0 >> 1) * 6 + d], lo[d]); atomicMax(&u.bb[(s0 >> 1) * 6 + 3 + d], hi[d]); }
+      } else if (active) {
+        for (int d = 0; d < 3; d++) { atomicMin(&u.bb[(s >> 1) * 6 + d], lo[d]); atomicMax(&u.bb[(s >> 1) * 6 + 3 + d], hi[d]); }
+      }
+    }
+    __syncthreads();
+    if (top && tid < 3) {                                   // the subtree's own box, for the caller (the root's is the map's)
+      const uint32_t one = sortable(crd[tid][0]);
+      bbmin_g[(size_t)sg.pos * 3 + tid] = L >= 2 ? u.bb[tid] : one; bbmax_g[(size_t)sg.pos * 3 + tid] = L >= 2 ? u.bb[3 + tid] : one;
+    }
+    top = false;
+    // widest axis and sort key of every position
+    unsigned long long mykey[S / T]; uint32_t myd[S / T];
+#pragma unroll
+    for (uint32_t r = 0; r < S / T; r++) {
+      const uint32_t i = tid + r * T, sp = spos[i];
+      const uint32_t d = (sp != 0 && slen[i] >= 2) ? (uint32_t)widest_dim3(&u.bb[(sstart[i] >> 1) * 6], &u.bb[(sstart[i] >> 1) * 6 + 3]) : 0u;
+      const uint32_t c = sp ? sortable(crd[d][lid[cur][i]]) : 0u, grp = sp ? sstart[i] : i;
+      myd[r] = d;
+      mykey[r] = ((unsigned long long)grp << 43) | ((unsigned long long)c << 11) | i;
+    }
+    __syncthreads();                                       // (the keys overwrite the boxes)
+#pragma unroll
+    for (uint32_t r = 0; r < S / T; r++) { const uint32_t i = tid + r * T; u.key[i] = mykey[r]; sdim[i] = (uint8_t)myd[r]; }
+    __syncthreads();
+    if (maxlen > 64) {
+      for (uint32_t k = 2; k <= S; k <<= 1)
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+#pragma unroll
+          for (uint32_t r = 0; r < S / 2 / T; r++) {
+            const uint32_t t = tid + r * T;
+            const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), p = i | j;
+            const unsigned long long a = u.key[i], b = u.key[p];
+            if ((a > b) == ((i & k) == 0)) { u.key[i] = b; u.key[p] = a; }
+          }
+          __syncthreads();
+        }
+#pragma unroll
+      for (uint32_t r = 0; r < S / T; r++) { const uint32_t i = tid + r * T; lid[cur ^ 1][i] = lid[cur][(uint32_t)(u.key[i] & 2047u)]; }
+    } else {
+#pragma unroll
+      for (uint32_t r = 0; r < S / T; r++) {
+        const uint32_t i = tid + r * T;
+        uint32_t np = i;
+        if (spos[i] != 0 && slen[i] >= 2) {
+          const uint32_t s = sstart[i], l = slen[i];
+          const unsigned long long k = u.key[i];
+          uint32_t rank = 0;
+          for (uint32_t j = 0; j < l; j++) rank += u.key[s + j] < k ? 1u : 0u;
+          np = s + rank;
+        }
+        lid[cur ^ 1][np] = lid[cur][i];
+      }
+    }
+    __syncthreads();
+    cur ^= 1;
+    // the medians become nodes, the sides become the next level's segments
+#pragma unroll
+    for (uint32_t r = 0; r < S / T; r++) {
+      const uint32_t i = tid + r * T, sp = spos[i];
+      if (!sp) continue;
+      const uint32_t s = sstart[i], l = slen[i], m = find_median(l);
+      if (i == s + m) { perm[sp - 1] = (int32_t)idx[sg.start + lid[cur][i]]; dim_out[sp - 1] = sdim[i]; spos[i] = 0; sstart[i] = (uint16_t)i; }
+      else if (i < s + m) { spos[i] = 2 * sp; slen[i] = (uint16_t)m; }
+      else { spos[i] = 2 * sp + 1; sstart[i] = (uint16_t)(s + m + 1); slen[i] = (uint16_t)(l - m - 1); }
+    }
+  }
+}
+static_assert(KD_LDS_S == 2048 && KD_LDS_S == 2 * KD_LDS_T, "the sort keys keep the position in 11 bits; one compare-exchange per thread and stage");
 
 static float unsortable_host(uint32_t u) { u ^= ((u >> 31) ? 0x80000000u : 0xFFFFFFFFu); float f; memcpy(&f, &u, 4); return f; }
 
@@ -162,41 +300,68 @@ static float unsortable_host(uint32_t u) { u ^= ((u >> 31) ? 0x80000000u : 0xFFF
 int rt_kd_build_device(rt_ctx *ctx, const float *d_pos, uint32_t n, int32_t *d_perm, uint8_t *d_dim, float *bbox6) {
   if (n == 0) return rt_fail(ctx, RT_ERR_EMPTY_TREE, "tried to build a k-d tree with no data!");   // kdtree.js:6
   if (n >= 0x7FFFFFFFu) return rt_fail(ctx, RT_ERR_TOO_LARGE, "photon map too large");
-  DevMem idxA, idxB, keyA, keyB, spos, sstart, slen, bbmin, bbmax, segdim, tmp;
-  RT_HIP(ctx, idxA.alloc((size_t)n * 4)); RT_HIP(ctx, idxB.alloc((size_t)n * 4));
-  RT_HIP(ctx, keyA.alloc((size_t)n * 8)); RT_HIP(ctx, keyB.alloc((size_t)n * 8));
-  RT_HIP(ctx, spos.alloc((size_t)n * 4)); RT_HIP(ctx, sstart.alloc((size_t)n * 4)); RT_HIP(ctx, slen.alloc((size_t)n * 4));
-  RT_HIP(ctx, bbmin.alloc(((size_t)n + 1) * 12)); RT_HIP(ctx, bbmax.alloc(((size_t)n + 1) * 12));
-  RT_HIP(ctx, segdim.alloc((size_t)n + 1));
-  SegState sg = { spos.as<uint32_t>(), sstart.as<uint32_t>(), slen.as<uint32_t>() };
-  const uint32_t grid = div_up(n, 256);
-  RT_LAUNCH(ctx, "kd_init", k_kd_init, grid, 256, n, idxA.as<uint32_t>(), sg);
-  int seg_bits = 1; while (((uint64_t)1 << seg_bits) < (uint64_t)n) seg_bits++;
-  const unsigned end_bit = 32 + seg_bits;
+  // the levels handled over the whole array: while the longest segment is too long for one workgroup
+  std::vector<KdSeg> segs = { { 1u, 0u, n } };
+  int global_levels = 0;
+  for (uint32_t maxlen = n; maxlen > KD_LDS_S; maxlen = find_median(maxlen)) {
+    std::vector<KdSeg> next; next.reserve(segs.size() * 2);
+    for (const KdSeg &g : segs) {
+      if (g.len == 0) { next.push_back({ 2 * g.pos, g.start, 0u }); next.push_back({ 2 * g.pos + 1, g.start, 0u }); continue; }
+      const uint32_t m = find_median(g.len);
+      next.push_back({ 2 * g.pos, g.start, m }); next.push_back({ 2 * g.pos + 1, g.start + m + 1, g.len - m - 1 });
+    }
+    segs.swap(next); global_levels++;
+  }
+  std::vector<KdSeg> work;
+  for (const KdSeg &g : segs) if (g.len) work.push_back(g);
+  const size_t n_bb = ((size_t)2 << global_levels) + 2;       // boxes by heap position, levels 0 .. global_levels
+  // one grow-only workspace per context
   size_t tmp_bytes = 0;
-  RT_HIP(ctx, rocprim::radix_sort_pairs(nullptr, tmp_bytes, keyA.as<uint64_t>(), keyB.as<uint64_t>(), idxA.as<uint32_t>(),
-                                        idxB.as<uint32_t>(), n, 0, end_bit, ctx->stream));
-  RT_HIP(ctx, tmp.alloc(tmp_bytes));
-  uint32_t *idx_cur = idxA.as<uint32_t>(), *idx_nxt = idxB.as<uint32_t>();
-  for (uint32_t first = 1; first <= n; first <<= 1) {                   // heap positions [first, 2*first) form one level
-    uint32_t count = (2 * (uint64_t)first - 1 <= n) ? first : n - first + 1;
-    RT_LAUNCH(ctx, "kd_bbox_clear", k_kd_bbox_clear, div_up((uint64_t)count * 3, 256), 256, first, count, bbmin.as<uint32_t>(), bbmax.as<uint32_t>());
-    RT_LAUNCH(ctx, "kd_bbox", k_kd_bbox, div_up(n, 256u * KD_BBOX_ITEMS), 256, n, d_pos, idx_cur, sg, bbmin.as<uint32_t>(), bbmax.as<uint32_t>());
-    RT_LAUNCH(ctx, "kd_keys", k_kd_keys, grid, 256, n, d_pos, idx_cur, sg, bbmin.as<uint32_t>(), bbmax.as<uint32_t>(),
-              segdim.as<uint8_t>(), keyA.as<uint64_t>());
+  int seg_bits = global_levels + 1;
+  if (global_levels)
+    RT_HIP(ctx, rocprim::radix_sort_pairs(nullptr, tmp_bytes, (uint64_t *)nullptr, (uint64_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, n, 0,
+                                          32 + seg_bits, ctx->stream));
+  size_t off = 0;
+  auto carve = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+  const bool glob = global_levels > 0;
+  const size_t o_idxA = carve((size_t)n * 4), o_idxB = carve(glob ? (size_t)n * 4 : 0), o_keyA = carve(glob ? (size_t)n * 8 : 0), o_keyB = carve(glob ? (size_t)n * 8 : 0);
+  const size_t o_pos = carve(glob ? (size_t)n * 4 : 0), o_start = carve(glob ? (size_t)n * 4 : 0), o_len = carve(glob ? (size_t)n * 4 : 0);
+  const size_t o_bbmin = carve(n_bb * 12), o_bbmax = carve(n_bb * 12), o_segdim = carve(n_bb), o_segs = carve(work.size() * sizeof(KdSeg)), o_tmp = carve(tmp_bytes);
+  RT_HIP(ctx, ctx->ws_kd.reserve(off));
+  char *base = (char *)ctx->ws_kd.p;
+  uint32_t *idx_cur = (uint32_t *)(base + o_idxA), *idx_nxt = (uint32_t *)(base + o_idxB);
+  uint64_t *keyA = (uint64_t *)(base + o_keyA), *keyB = (uint64_t *)(base + o_keyB);
+  SegState sg = { (uint32_t *)(base + o_pos), (uint32_t *)(base + o_start), (uint32_t *)(base + o_len) };
+  uint32_t *bbmin = (uint32_t *)(base + o_bbmin), *bbmax = (uint32_t *)(base + o_bbmax);
+  uint8_t *segdim = (uint8_t *)(base + o_segdim);
+  KdSeg *d_segs = (KdSeg *)(base + o_segs);
+  const uint32_t grid = div_up(n, 256);
+  if (glob) RT_LAUNCH(ctx, "kd_init", k_kd_init, grid, 256, n, idx_cur, sg);
+  else {
+    RT_LAUNCH(ctx, "kd_init", k_kd_iota, grid, 256, n, idx_cur);
+  }
+  RT_HIP(ctx, hipMemcpyAsync(d_segs, work.data(), work.size() * sizeof(KdSeg), hipMemcpyHostToDevice, ctx->stream));
+  uint32_t first = 1;
+  for (int level = 0; level < global_levels; level++, first <<= 1) {      // heap positions [first, 2 first) form one level
+    const uint32_t count = (2 * (uint64_t)first - 1 <= n) ? first : n - first + 1;
+    RT_LAUNCH(ctx, "kd_bbox_clear", k_kd_bbox_clear, div_up((uint64_t)count * 3, 256), 256, first, count, bbmin, bbmax);
+    RT_LAUNCH(ctx, "kd_bbox", k_kd_bbox, div_up(n, 256u * KD_BBOX_ITEMS), 256, n, d_pos, (const uint32_t *)idx_cur, sg, bbmin, bbmax);
+    RT_LAUNCH(ctx, "kd_keys", k_kd_keys, grid, 256, n, d_pos, (const uint32_t *)idx_cur, sg, first, level, (const uint32_t *)bbmin, (const uint32_t *)bbmax, segdim, keyA);
     {
       KernelTimer timer_(ctx, "kd_sort");
-      RT_HIP(ctx, rocprim::radix_sort_pairs(tmp.p, tmp_bytes, keyA.as<uint64_t>(), keyB.as<uint64_t>(), idx_cur, idx_nxt, n, 0,
-                                            end_bit, ctx->stream));
+      RT_HIP(ctx, rocprim::radix_sort_pairs(base + o_tmp, tmp_bytes, keyA, keyB, idx_cur, idx_nxt, n, 0, level == 0 ? 32 : 32 + level + 1, ctx->stream));
     }
     std::swap(idx_cur, idx_nxt);
-    RT_LAUNCH(ctx, "kd_split", k_kd_split, grid, 256, n, idx_cur, sg, segdim.as<uint8_t>(), d_perm, d_dim);
+    RT_LAUNCH(ctx, "kd_split", k_kd_split, grid, 256, n, (const uint32_t *)idx_cur, sg, (const uint8_t *)segdim, d_perm, d_dim);
   }
-  RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (!work.empty())
+    RT_LAUNCH(ctx, "kd_lds", k_kd_lds, (uint32_t)work.size(), KD_LDS_T, (const KdSeg *)d_segs, d_pos, (const uint32_t *)idx_cur, bbmin, bbmax, d_perm, d_dim);
+  RT_HIP(ctx, hipGetLastError());
+  RT_HIP(ctx, hipStreamSynchronize(ctx->stream));           // (`work` is read by the copy above until here)
   if (bbox6) {                                              // the root segment's box (heap position 1) is never cleared again
     uint32_t lo[3], hi[3];
-    RT_HIP(ctx, hipMemcpy(lo, bbmin.as<uint32_t>() + 3, 12, hipMemcpyDeviceToHost));
-    RT_HIP(ctx, hipMemcpy(hi, bbmax.as<uint32_t>() + 3, 12, hipMemcpyDeviceToHost));
+    RT_HIP(ctx, hipMemcpy(lo, bbmin + 3, 12, hipMemcpyDeviceToHost));
+    RT_HIP(ctx, hipMemcpy(hi, bbmax + 3, 12, hipMemcpyDeviceToHost));
     for (int d = 0; d < 3; d++) { bbox6[d] = unsortable_host(lo[d]); bbox6[3 + d] = unsortable_host(hi[d]); }
   }
   return RT_OK;
