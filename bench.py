@@ -355,7 +355,7 @@ def main():
                       "note": "algorithmic bytes = N x (12 B read + 12 B written) x ceil(log2 N) + 5 N; time = host clock around the whole call, best of 3"}
         pm.gather(hits, k=args.knn, out=rgb)                               # warm-up
         ctx.profile_enable(True)
-        ctx.profile_select("gather_knn,gather_knn_heap_fallback")
+        ctx.profile_select("gather_knn,gather_knn_split,gather_knn_single,gather_knn_heap_fallback")
         ctx.profile_reset()
         gsteps = max(2, min(args.steps, 5))
         barrier()
@@ -367,6 +367,8 @@ def main():
         gdt = time.perf_counter() - tg
         g_ms, g_launches = ctx.profile_get("gather_knn")
         fb_ms, fb_launches = ctx.profile_get("gather_knn_heap_fallback")
+        sp_ms, sp_launches = ctx.profile_get("gather_knn_split")
+        sg_ms, sg_launches = ctx.profile_get("gather_knn_single")
         ctx.profile_enable(False)
         gathers = hits.shape[0] * gsteps
         gps = torch.tensor([gathers / gdt], dtype=torch.float64, device=cdev)
@@ -375,10 +377,14 @@ def main():
         g_achieved = hits.shape[0] * BYTES_PER_GATHER / (g_ms / g_launches * 1e-3) / 1e9
         extra = {"knn_gathers_per_s": float(gps.item()), "knn_k": args.knn, "photons": args.photons,
                  "kd_build_s": build_s, "gather_ms_per_step": gdt / gsteps * 1e3,
+                 "split_units_ms_per_step": sp_ms / gsteps, "split_unit_launches": sp_launches,
+                 "single_query_ms_per_step": sg_ms / gsteps, "single_query_launches": sg_launches,
                  "heap_fallback_ms_per_step": fb_ms / gsteps, "heap_fallback_launches": fb_launches}
         roof_gather = {"kernel": "k_gather_knn_wave", "bound": "hbm", "achieved": g_achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                        "frac": g_achieved / PEAK_HBM_GBS, "traffic": measured_traffic("k_gather_knn_wave"),
-                       "algorithmic_bytes_per_gather": BYTES_PER_GATHER, "avg_launch_ms": g_ms / g_launches}
+                       "algorithmic_bytes_per_gather": BYTES_PER_GATHER, "avg_launch_ms": g_ms / g_launches,
+                       "whole_call": {"ms": gdt / gsteps * 1e3, "frac": hits.shape[0] * BYTES_PER_GATHER / (gdt / gsteps) / 1e9 / PEAK_HBM_GBS,
+                                      "note": "every launch of rt_gather_radiance (first pass, the units cut into quarters, single queries) and the host's counter read-backs between them"}}
         # the same gather on less friendly inputs: the queries in raster order instead of 8x8 tiles, and a real emitted map
         # (the default scene's caustic + diffuse photons) queried at the frame's own first-hit points
         order = np.arange(W * H).reshape(H // 8, 8, W // 8, 8).transpose(0, 2, 1, 3).reshape(-1) if (H % 8 == 0 and W % 8 == 0) else None

@@ -134,7 +134,7 @@ int rt_synchronize(rt_ctx *ctx);            /* host wait for everything the cont
  * instead of calling rt_synchronize().  No counterpart in the reference. */
 int rt_join(rt_ctx *ctx);
 /* Experiment / test switches, by name: tail_threshold, whole_frame, bounce_passes, no_lds, no_cull, raster_order,
- * bvh (-1 by scene size / 0 / 1; read by rt_scene_upload), knn_heap, knn_r0, knn_verbose, probe.  rt_init reads
+ * bvh (-1 by scene size / 0 / 1; read by rt_scene_upload), knn_heap, knn_radius_scale, knn_verbose, probe.  rt_init reads
  * RT355_<NAME> from the environment once; this call changes one switch of a live context.  The defaults are the
  * measured best; results do not depend on any of them (fp32 images: bit for bit).  No counterpart in the reference. */
 int rt_set_option(rt_ctx *ctx, const char *name, double value);
@@ -254,7 +254,7 @@ int rt_gather_radiance(rt_photon_map *map, const float *hits, uint32_t nq, doubl
  * loops, harnesses that forbid hipMalloc).  NO COUNTERPART IN THE REFERENCE.  Same results as rt_gather_radiance, but the
  * call allocates nothing: `hits_dev` and `rgb_dev` must already be device memory of the context's GPU (a host array is
  * rejected with RT_ERR_INVALID), and the k-nearest gather's scratch (fallback flags and work lists) lives in a static
- * device array of about 1.3 MB that each GPU the library runs on holds until the process ends.  nq may be at most
+ * device array of about 3.8 MB that each GPU the library runs on holds until the process ends.  nq may be at most
  * RT_GATHER_STATIC_MAX_QUERIES (RT_ERR_TOO_LARGE beyond: split the queries over several calls).  All calls on one GPU
  * share that array: calls that overlap in time on one GPU (two contexts, two host threads) race.  Returns when the
  * results are complete. */

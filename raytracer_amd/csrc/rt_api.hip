@@ -92,7 +92,7 @@ int rt_init(const int *device_ids, int n, rt_ctx **out) {
     }
   // the experiment switches: the environment is read here, once per context
   static const char *names[] = { "tail_threshold", "whole_frame", "bounce_passes", "no_lds", "no_cull", "raster_order", "bvh", "knn_heap",
-                                 "knn_verbose", "probe", "knn_r0" };
+                                 "knn_verbose", "probe", "knn_radius_scale" };
   for (const char *nm : names) {
     std::string env = "RT355_";
     for (const char *c = nm; *c; c++) env += (char)toupper((unsigned char)*c);
@@ -129,7 +129,7 @@ int rt_set_option(rt_ctx *ctx, const char *name, double value) {
   else if (n == "knn_heap") K.knn_heap = value != 0;
   else if (n == "knn_verbose") K.knn_verbose = value != 0;
   else if (n == "probe") K.probe = value != 0;
-  else if (n == "knn_r0") K.knn_r0 = value;
+  else if (n == "knn_radius_scale") K.knn_radius_scale = value;
   else return rt_fail(ctx, RT_ERR_INVALID, "unknown option '%s'", name);
   return RT_OK;
 }

@@ -40,7 +40,7 @@ struct RtKnobs {
   int knn_heap = 0;              // 1: k-nearest gathers use the per-lane heap kernel only
   int knn_verbose = 0;
   int probe = 0;
-  double knn_r0 = 0;             // > 0: first radius of the wave-cooperative k-nearest gather
+  double knn_radius_scale = 0;   // > 1: the wave-cooperative k-nearest gather searches balls this much larger than needed (tests)
 };
 struct rt_ctx {
   int device = 0;

@@ -660,16 +660,15 @@ __global__ void __launch_bounds__(256) k_gather_radius(DevMap M, const float *hi
   rgb[(size_t)q * 3 + 2] = sb * (h[8] / 255.0f) * inv_area;
 }
 
-// `units` (optional): the work units of k_gather_knn_wave (see knn_unit_query) that it left over, one per workgroup;
-// without it workgroup b serves queries [64 b, 64 b + 64)
-__global__ void __launch_bounds__(KNN_LANES) k_gather_knn(DevMap M, const float *hits, uint32_t nq, uint32_t k, float *rgb, const uint32_t *units,
-                                                          const uint32_t *groups, uint32_t sub) {
+// `list` (optional): the queries k_gather_knn_wave left over (list[0 .. *list_count)), 64 to a workgroup; without it
+// workgroup b serves queries [64 b, 64 b + 64)
+__global__ void __launch_bounds__(KNN_LANES) k_gather_knn(DevMap M, const float *hits, uint32_t nq, uint32_t k, float *rgb, const uint32_t *list,
+                                                          const uint32_t *list_count) {
   extern __shared__ double knn_lds[];
   uint32_t q = blockIdx.x * KNN_LANES + threadIdx.x;
-  if (units) {
-    const uint32_t u = units[blockIdx.x], per = 64 / sub;
-    if (threadIdx.x >= per) return;
-    q = groups[u / sub] * 64 + (u % sub) * per + threadIdx.x;
+  if (list) {
+    if (q >= *list_count) return;
+    q = list[q];
   }
   KnnHeap H; H.d2 = knn_lds; H.slot = (uint32_t *)(knn_lds + (size_t)k * KNN_LANES); H.perm = M.perm; H.k = k; H.size = 0; H.lane = threadIdx.x;
   if (q >= nq) return;
@@ -694,25 +693,29 @@ __global__ void __launch_bounds__(KNN_LANES) k_gather_knn(DevMap M, const float 
 // ------------------------------------------------------------------ k-nearest gather, one wave per 64 queries
 // Queries that arrive together are neighbours on a surface (the caller orders them by image tile), so their
 // k-nearest sets overlap almost completely.  A wave therefore
-//   1. takes the bounding box of its 64 query points, grows it by a radius R and collects every photon inside
-//      with ONE cooperative walk of the kd-tree (a frontier of nodes in LDS, one node per lane per step);
-//   2. checks that every query has at least k candidates closer than R -- then all of its k nearest photons are
-//      among the candidates, exactly -- and otherwise grows R and walks again;
+//   0. descends the tree towards the centre of its queries to a subtree of k .. 4k photons and takes its search radii
+//      from those photons: first from their density, then (if some query finds fewer than k photons inside its ball)
+//      from the k-th smallest distance to them, which bounds the k-th neighbour distance from above;
+//   1. takes the bounding box of its queries' balls and collects every photon inside with ONE cooperative walk of the
+//      kd-tree (a queue of nodes in LDS, one node per lane per step);
+//   2. checks that every query has at least k candidates inside its ball -- then all of its k nearest photons are
+//      among the candidates, exactly;
 //   3. lets every lane find the distance that separates its k nearest candidates from the rest by an
 //      interpolation search on "how many candidates are closer than t" (the candidates are read from LDS as
 //      wave-wide broadcasts; no per-lane storage at all, so occupancy is not limited by a top-k structure);
 //   4. sums the radiance of the selected candidates.
 // Distances are the same fp64 expression as everywhere else (sq_dist), ties at the k-th distance go to the lowest
-// input index, so the selected set is exactly the one rt_kd_knn returns.  A wave whose candidate list or frontier
-// would overflow its LDS buffers reports that in fallback[] and leaves its queries to k_gather_knn.
+// input index, so the selected set is exactly the one rt_kd_knn returns.  A wave whose candidates or node queue would
+// overflow its LDS buffers hands its queries on as four smaller units (16, then 4 queries, then single queries, which
+// k_gather_knn_single streams through the same buffers whatever their number of candidates).
 #ifndef KNN2_CAP
 #define KNN2_CAP 512
 #endif
 #ifndef KNN2_FRONT
-#define KNN2_FRONT 256
+#define KNN2_FRONT 512
 #endif
 #ifdef RT_KNN_PROBE
-__device__ unsigned long long knn_probe[8];          // cycles (lane 0 of every wave): walk, radius check, search, ties, sum; [5] waves, [6] passes, [7] candidates
+__device__ unsigned long long knn_probe[9];          // cycles (lane 0 of every wave): walk, radius check, search, ties, sum, [5] bound; [6] waves, [7] passes, [8] candidates
 #define KNN_PROBE(k) { if (lane == 0) { long long t1_ = clock64(); atomicAdd(&knn_probe[k], (unsigned long long)(t1_ - pt0)); pt0 = t1_; } }
 #else
 #define KNN_PROBE(k)
@@ -722,107 +725,241 @@ __device__ __forceinline__ double wave_min_d(double v) { for (int o = 32; o > 0;
 __device__ __forceinline__ double wave_max_d(double v) { for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64)); return v; }
 __device__ __forceinline__ uint32_t lanes_below(unsigned long long mask, int lane) { return (uint32_t)__popcll(mask & (((unsigned long long)1 << lane) - 1)); }
 
-// Work units: workgroup u serves queries [64 u, 64 u + 64) when `groups` is null; otherwise it serves the `sub`-th part
-// (64 / sub consecutive queries, sub a power of two) of group groups[u / sub] -- the second pass over groups whose
-// 64 queries were too spread out, with lanes beyond the part shadowing its queries.
-__device__ __forceinline__ bool knn_unit_query(const uint32_t *groups, uint32_t sub, uint32_t nq, int lane, uint32_t *q_out) {
-  if (!groups) { *q_out = blockIdx.x * 64 + lane; return *q_out < nq; }
-  const uint32_t per = 64 / sub;
-  const uint32_t q = groups[blockIdx.x / sub] * 64 + (blockIdx.x % sub) * per + ((uint32_t)lane % per);
-  *q_out = q;
-  return (uint32_t)lane < per && q < nq;
+// Work units: a unit is `count` consecutive queries starting at `first` (count = 64, 16, 4 or 1), served by one wave
+// with the lanes beyond count shadowing its queries.  Without a unit list workgroup u serves [64 u, 64 u + 64).  A unit
+// whose candidates do not fit the wave's LDS buffers is cut into four (appended to `next` for the next launch: other
+// waves serve them, in parallel) or, a single query, goes to the list of the per-lane heap kernel.  why[] counts the
+// units given up by cause: candidates, frontier, second try short, search.
+struct KnnQueues { uint2 *next; uint32_t *next_count; uint32_t *heap_list; uint32_t *heap_count; uint32_t *why; };
+__device__ __forceinline__ void knn_give_up(const KnnQueues &Q, uint32_t first, uint32_t count, uint32_t nq, int lane, int cause) {
+  if (lane != 0) return;
+  atomicAdd(&Q.why[cause], 1u);
+  if (count <= 1) { Q.heap_list[atomicAdd(Q.heap_count, 1u)] = first; return; }
+  const uint32_t part = count / 4;
+  uint32_t live = 0;
+  for (uint32_t j = 0; j < 4; j++) live += (first + j * part < nq) ? 1u : 0u;
+  const uint32_t base = atomicAdd(Q.next_count, live);
+  for (uint32_t j = 0, o = 0; j < 4; j++) if (first + j * part < nq) Q.next[base + o++] = make_uint2(first + j * part, part);
 }
 
-__global__ void __launch_bounds__(64) k_gather_knn_wave(DevMap M, const float *hits, uint32_t nq, uint32_t k, double r0, float *rgb,
-                                                        uint8_t *fallback, const uint32_t *groups, uint32_t sub) {
-  __shared__ float4 cand[KNN2_CAP];                  // x y z, slot (as bits)
-  __shared__ uint32_t front[2][KNN2_FRONT];
-  const int lane = threadIdx.x;
-  uint32_t q;
-  const bool valid = knn_unit_query(groups, sub, nq, lane, &q);
-  const uint32_t qq = q < nq ? q : nq - 1;           // surplus lanes shadow a query (no output)
-  const float *h = hits + (size_t)qq * 9;
-  const double x0 = h[0], x1 = h[1], x2 = h[2];
-  const float nx = h[3], ny = h[4], nz = h[5];
-  const double bl0 = wave_min_d(x0), bl1 = wave_min_d(x1), bl2 = wave_min_d(x2);
-  const double bh0 = wave_max_d(x0), bh1 = wave_max_d(x1), bh2 = wave_max_d(x2);
+// number of nodes in the subtree rooted at heap position pos of a left-balanced tree of n nodes
+__device__ __forceinline__ uint32_t kd_subtree_size(uint32_t pos, uint32_t n) {
+  unsigned long long lo = pos, hi = pos; uint32_t c = 0;
+  while (lo <= n) { c += (uint32_t)((hi < n ? hi : (unsigned long long)n) - lo + 1); lo = 2 * lo; hi = 2 * hi + 1; }
+  return c;
+}
+__device__ __forceinline__ float wave_min_f(float v) { for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64)); return v; }
+__device__ __forceinline__ float wave_max_f(float v) { for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64)); return v; }
+
+// Descent towards the point c, t_depth levels down (the host picks the depth at which every subtree has k .. 4k photons),
+// six levels per global round trip: the 63 nodes of the next six levels under the current node are fetched at once, one
+// a lane, into `top` (64 nodes of LDS).  Returns the heap position reached, the split axes (two bits a level) and, in
+// lane L, the split coordinate of level L.
+__device__ __forceinline__ void knn_descend(const DevMap &M, float cx, float cy, float cz, uint32_t t_depth, float4 *top, int lane,
+                                            uint32_t &t_pos, unsigned long long &path, float &plane_val) {
   const uint32_t n = M.n;
-  double R = r0;
+  int depth = 0;
+  while (depth < (int)t_depth) {
+    const int L = min(6, (int)t_depth - depth);
+    if (lane >= 1 && lane < (1 << L)) {
+      const int j = 31 - __clz(lane);
+      const unsigned long long abs_pos = ((unsigned long long)t_pos << j) + (unsigned)(lane - (1 << j));
+      if (abs_pos <= n) top[lane] = M.node[abs_pos - 1];
+    }
+    __syncthreads();
+    uint32_t r = 1;
+    for (int sdx = 0; sdx < L; sdx++, depth++) {
+      const float4 nd = top[r];
+      const int dim = node_dim(nd);
+      // Which side?  By the split axis; where the point lies exactly on the plane (photons on an axis-aligned wall
+      // share that coordinate, and the median falls inside the run), by what ordered the run: the stable sorts
+      // of the levels above, i.e. the parent's axis, then the grandparent's, ...
+      int go = -1;
+      for (int j = depth; j >= 0 && go < 0; j--) {
+        const int dd = j == depth ? dim : (int)((path >> (2 * j)) & 3u);
+        const float cv = (dd == 0) ? cx : (dd == 1) ? cy : cz, nv = (dd == 0) ? nd.x : (dd == 1) ? nd.y : nd.z;
+        if (cv < nv) go = 0; else if (cv > nv) go = 1;
+      }
+      if (go < 0) go = 0;
+      path |= (unsigned long long)(dim & 3) << (2 * depth);
+      if (lane == depth) plane_val = (dim == 0) ? nd.x : (dim == 1) ? nd.y : nd.z;
+      r = 2 * r + (uint32_t)go;
+    }
+    t_pos = (t_pos << L) + (r - (1u << L));
+    __syncthreads();
+  }
+}
+
+// the photons of the subtree at t_pos into cand[] (level by level: contiguous heap positions); their number
+__device__ __forceinline__ uint32_t knn_load_subtree(const DevMap &M, uint32_t t_pos, float4 *cand, int lane) {
+  const uint32_t n = M.n;
+  uint32_t cnt = 0;
+  unsigned long long lo = t_pos, hi = t_pos;
+  while (lo <= n && cnt < KNN2_CAP) {
+    const unsigned long long end = hi < n ? hi : (unsigned long long)n;
+    for (unsigned long long p = lo + lane; p <= end && cnt + (uint32_t)(p - lo) < KNN2_CAP; p += 64) {
+      float4 nd = M.node[p - 1]; nd.w = __uint_as_float((uint32_t)(p - 1));
+      cand[cnt + (uint32_t)(p - lo)] = nd;
+    }
+    cnt += (uint32_t)(end - lo + 1);
+    lo = 2 * lo; hi = 2 * hi + 1;
+  }
+  return cnt > KNN2_CAP ? (uint32_t)KNN2_CAP : cnt;                        // (never cut: the host's depth keeps subtrees within the buffer)
+}
+
+__global__ void __launch_bounds__(64) k_gather_knn_wave(DevMap M, const float *hits, uint32_t nq, uint32_t k, float radius_scale, uint32_t t_depth, float *rgb,
+                                                        const uint2 *units, const uint32_t *n_units, KnnQueues Q) {
+  __shared__ float4 cand[KNN2_CAP];                  // x y z, slot (as bits)
+  __shared__ uint32_t front[KNN2_FRONT];             // the walk's queue of tree nodes (a ring)
+  const int lane = threadIdx.x;
+  uint32_t u_first = blockIdx.x * 64u, u_count = 64u;
+  if (units) {
+    if (blockIdx.x >= *n_units) return;              // (the grid is an upper bound)
+    const uint2 u = units[blockIdx.x];
+    u_first = u.x; u_count = u.y;
+  }
+  const uint32_t q = u_first + (uint32_t)lane % u_count;
+  const bool valid = (uint32_t)lane < u_count && q < nq;
+  const uint32_t qq = q < nq ? q : (u_first < nq ? u_first : nq - 1);     // surplus lanes shadow a query (no output)
+  const float *h = hits + (size_t)qq * 9;
+  const float qx = h[0], qy = h[1], qz = h[2];
+  const double x0 = qx, x1 = qy, x2 = qz;
+  const float nx = h[3], ny = h[4], nz = h[5];
+  const uint32_t n = M.n;
 #ifdef RT_KNN_PROBE
   long long pt0 = clock64();
 #endif
-  uint32_t m = 0, c = 0, pc1 = 0, pc2 = 0, pc3 = 0;
-  // pivots of the first counting pass: r0 is 1.2 x the expected k-th distance
-  const double pt2 = r0 * r0 / 1.44, pdt = pt2 / (double)k * (1.0 + 0.6 * sqrt((double)k));
-  const double pt1 = pt2 - pdt > 0.0 ? pt2 - pdt : 0.5 * pt2, pt3 = pt2 + pdt < r0 * r0 ? pt2 + pdt : 0.5 * (pt2 + r0 * r0);
-  bool ok = false, overflow = false, all_in = false;
-  for (int attempt = 0; attempt < 40 && !ok && !overflow; attempt++) {
-    const double g = R * (1.0 + 1e-9);               // (the box test must not lose a photon to the rounding of lo/hi)
-    const double lo0 = bl0 - g, lo1 = bl1 - g, lo2 = bl2 - g, hi0 = bh0 + g, hi1 = bh1 + g, hi2 = bh2 + g;
-    // ---- 1. cooperative box walk
-#ifdef RT_KNN_PROBE
-    pt0 = clock64();
-#endif
+  // ---- 0. where to look, from the tree itself.  Descend towards the centre of the queries' box to a subtree T of
+  // k .. 4k photons.  First try: the local density of T's photons (their number over the two largest extents of their
+  // box: photons lie on surfaces) gives the radius a query inside that box needs, 1.4 x for slack; a query outside it
+  // first has to reach it.  If some query then has fewer than k candidates inside its ball, second try: the k-th
+  // smallest distance from the query to T's photons, which bounds its k-th neighbour distance from above wherever
+  // the query lies (fp32 with a margin: any upper bound will do).
+  uint32_t m = 0, t_pos = 1;
+  float plane_val = 0.f;                             // split coordinates along the descent: lane L holds level L's
+  unsigned long long path = 0;                       // split axes along the descent, two bits a level
+  knn_descend(M, 0.5f * (wave_min_f(qx) + wave_max_f(qx)), 0.5f * (wave_min_f(qy) + wave_max_f(qy)), 0.5f * (wave_min_f(qz) + wave_max_f(qz)),
+              t_depth, (float4 *)&front[0], lane, t_pos, path, plane_val);
+  auto load_subtree = [&]() { return knn_load_subtree(M, t_pos, cand, lane); };
+  const uint32_t mt = load_subtree();
+  __syncthreads();
+  float rq;                                          // radius of this query's search ball
+  {
+    float l0 = 3.4e38f, l1 = 3.4e38f, l2 = 3.4e38f, h0 = -3.4e38f, h1 = -3.4e38f, h2 = -3.4e38f;
+    for (uint32_t j = lane; j < mt; j += 64) { const float4 c = cand[j]; l0 = fminf(l0, c.x); h0 = fmaxf(h0, c.x); l1 = fminf(l1, c.y); h1 = fmaxf(h1, c.y); l2 = fminf(l2, c.z); h2 = fmaxf(h2, c.z); }
+    l0 = wave_min_f(l0); l1 = wave_min_f(l1); l2 = wave_min_f(l2); h0 = wave_max_f(h0); h1 = wave_max_f(h1); h2 = wave_max_f(h2);
+    const float e0 = h0 - l0, e1 = h1 - l1, e2 = h2 - l2;
+    const float emax = fmaxf(e0, fmaxf(e1, e2)), emin = fminf(e0, fminf(e1, e2)), emid = e0 + e1 + e2 - emax - emin;
+    const float area = fmaxf(emax * fmaxf(emid, 1e-3f * emax), 1e-30f);
+    const float r_est = 1.4f * sqrtf((float)k * area / (3.14159265f * (float)mt));
+    const float dx = fmaxf(0.f, fmaxf(l0 - qx, qx - h0)), dy = fmaxf(0.f, fmaxf(l1 - qy, qy - h1)), dz = fmaxf(0.f, fmaxf(l2 - qz, qz - h2));
+    rq = (r_est + sqrtf(dx * dx + dy * dy + dz * dz)) * radius_scale;
+  }
+  KNN_PROBE(5)
+  bool overflow = false, ok = false, why_front = false;
+  uint32_t c = 0, pc1 = 0, pc2 = 0, pc3 = 0;
+  double b64 = 0.0, pt1 = 0.0, pt2 = 0.0, pt3 = 0.0;
+  for (int attempt = 0; attempt < 2 && !ok; attempt++) {
+    overflow = false;                                // (a first try that found too many candidates was too wide: the second may fit)
+    if (attempt == 1) {                              // the guaranteed radius: k-th smallest distance to T's photons
+      __syncthreads();
+      (void)load_subtree();
+      __syncthreads();
+      auto d2f = [&](float4 cd) { const float dx = qx - cd.x, dy = qy - cd.y, dz = qz - cd.z; return dx * dx + dy * dy + dz * dz; };
+      float dmax = 0.f;
+      for (uint32_t j = 0; j < mt; j++) dmax = fmaxf(dmax, d2f(cand[j]));
+      float a = 0.f, b = dmax * 1.000002f + 1e-30f; float fa = 0.f, fb = (float)mt;      // #(d2 < a) = fa < k <= fb = #(d2 < b)
+      const float kf = (float)k;
+      for (int it = 0; it < 3 && __any(fb > kf * 1.06f + 1.f); it++) {
+        // three pivots around the value where the count would reach a little over k if it grew linearly over the bracket
+        const float f2 = fminf(0.9f, fmaxf(0.02f, (kf * 1.03f + 1.f - fa) / (fb - fa)));
+        const float t2 = a + (b - a) * f2, t1 = a + (b - a) * f2 * 0.8f, t3 = a + (b - a) * fminf(0.95f, f2 * 1.3f);
+        float c1 = 0.f, c2 = 0.f, c3 = 0.f;
+        for (uint32_t j = 0; j < mt; j++) { const float d = d2f(cand[j]); c1 += d < t1 ? 1.f : 0.f; c2 += d < t2 ? 1.f : 0.f; c3 += d < t3 ? 1.f : 0.f; }
+        if (c1 >= kf) { b = t1; fb = c1; } else if (c2 >= kf) { b = t2; fb = c2; a = t1; fa = c1; } else if (c3 >= kf) { b = t3; fb = c3; a = t2; fa = c2; } else { a = t3; fa = c3; }
+      }
+      rq = sqrtf(b * 1.00001f) * 1.000001f * radius_scale;                   // (margins for the fp32 distance arithmetic: about 1e-6 relative)
+    }
+    b64 = (double)rq * (double)rq;
+    // pivots of the first counting pass: a first-try radius is 1.4 x the expected k-th distance; a guaranteed one is looser
+    pt2 = attempt == 0 ? b64 / 1.96 : 0.55 * b64;
+    { const double pdt = pt2 / (double)k * (1.0 + 0.6 * sqrt((double)k)); pt1 = pt2 - pdt > 0.0 ? pt2 - pdt : 0.5 * pt2; pt3 = pt2 + pdt < b64 ? pt2 + pdt : 0.5 * (pt2 + b64); }
+    // ---- 1. cooperative walk of the tree over the box of the queries' balls (fp32 bounds rounded outwards: the walk
+    // only has to find a superset, the distances below decide)
+    const float rw = rq * 1.000001f;
+    const float lo0 = wave_min_f(__double2float_rd((double)qx - (double)rw)), lo1 = wave_min_f(__double2float_rd((double)qy - (double)rw)),
+                lo2 = wave_min_f(__double2float_rd((double)qz - (double)rw));
+    const float hi0 = wave_max_f(__double2float_ru((double)qx + (double)rw)), hi1 = wave_max_f(__double2float_ru((double)qy + (double)rw)),
+                hi2 = wave_max_f(__double2float_ru((double)qz + (double)rw));
+    // ... and, of that box, only what lies within reach of the ball around the queries (cuts the box's corners)
+    const float gx = 0.5f * (wave_min_f(qx) + wave_max_f(qx)), gy = 0.5f * (wave_min_f(qy) + wave_max_f(qy)), gz = 0.5f * (wave_min_f(qz) + wave_max_f(qz));
+    const float reach = (sqrtf(wave_max_f((qx - gx) * (qx - gx) + (qy - gy) * (qy - gy) + (qz - gz) * (qz - gz))) + wave_max_f(rw)) * 1.00001f;
+    const float reach2 = reach * reach * 1.00001f;
+    __syncthreads();                                 // (T has been consumed)
     m = 0;
-    uint32_t ncur = 1; int cur = 0;
-    if (lane == 0) front[0][0] = 1;
-    __syncthreads();
-    while (ncur > 0 && !overflow) {
-      uint32_t nnext = 0;
-      for (uint32_t base = 0; base < ncur && !overflow; base += 64) {
-        const uint32_t i = base + lane;
-        const bool active = i < ncur;
-        const uint32_t pos = active ? front[cur][i] : 1u;                 // 1 <= pos <= n by construction
+    {
+      // start at the deepest node of the descent whose subtree certainly holds every photon of the box: at every level
+      // above it the box lay strictly on the side the descent took (photons ON a plane can sit on either side)
+      uint32_t start_level = 0;
+      for (; start_level < t_depth; start_level++) {
+        const int dd = (int)((path >> (2 * start_level)) & 3u);
+        const float v = __shfl(plane_val, (int)start_level, 64);
+        const bool went_right = (t_pos >> (t_depth - 1 - start_level)) & 1u;
+        const float blo = (dd == 0) ? lo0 : (dd == 1) ? lo1 : lo2, bhi = (dd == 0) ? hi0 : (dd == 1) ? hi1 : hi2;
+        if (!(went_right ? blo > v : bhi < v)) break;
+      }
+      if (lane == 0) front[0] = t_pos >> (t_depth - start_level);
+      __syncthreads();
+      // the queue is a ring: up to 64 nodes leave at the head, their children join at the tail (the order of the visits
+      // does not matter: the distances decide, and ties go by input index)
+      uint32_t head = 0, tail = 1;
+      while (head != tail) {
+        const uint32_t take = min(64u, tail - head);
+        const bool active = (uint32_t)lane < take;
+        const uint32_t pos = active ? front[(head + lane) % KNN2_FRONT] : 1u;      // 1 <= pos <= n by construction
+        head += take;
         const float4 nd = M.node[pos - 1];
-        const double px = nd.x, py = nd.y, pz = nd.z;
-        const bool inside = active && px >= lo0 && px <= hi0 && py >= lo1 && py <= hi1 && pz >= lo2 && pz <= hi2;
+        const float ddx = nd.x - gx, ddy = nd.y - gy, ddz = nd.z - gz;
+        const bool inside = active && nd.x >= lo0 && nd.x <= hi0 && nd.y >= lo1 && nd.y <= hi1 && nd.z >= lo2 && nd.z <= hi2 &&
+                            ddx * ddx + ddy * ddy + ddz * ddz <= reach2;
         const unsigned long long mi = __ballot(inside);
         const uint32_t ci = (uint32_t)__popcll(mi);
-        if (m + ci > KNN2_CAP) { overflow = true; break; }
+        if (m + ci > KNN2_CAP) { overflow = true; why_front = false; break; }
         if (inside) cand[m + lanes_below(mi, lane)] = make_float4(nd.x, nd.y, nd.z, __uint_as_float(pos - 1));
         m += ci;
         const int dim = node_dim(nd);
-        const double pd = (dim == 0) ? px : (dim == 1) ? py : pz;
-        const double lod = (dim == 0) ? lo0 : (dim == 1) ? lo1 : lo2, hid = (dim == 0) ? hi0 : (dim == 1) ? hi1 : hi2;
+        const float pd = (dim == 0) ? nd.x : (dim == 1) ? nd.y : nd.z;
+        const float lod = (dim == 0) ? lo0 : (dim == 1) ? lo1 : lo2, hid = (dim == 0) ? hi0 : (dim == 1) ? hi1 : hi2;
         // kdtree.js:69-71 for a box: left only if the box ends before the plane, right only if it starts after it
         const bool gl = active && 2ull * pos <= n && !(lod > pd);
         const bool gr = active && 2ull * pos + 1 <= n && !(hid < pd);
         const unsigned long long ml = __ballot(gl), mr = __ballot(gr);
         const uint32_t cl = (uint32_t)__popcll(ml), cr = (uint32_t)__popcll(mr);
-        if (nnext + cl + cr > KNN2_FRONT) { overflow = true; break; }
-        if (gl) front[cur ^ 1][nnext + lanes_below(ml, lane)] = 2 * pos;
-        if (gr) front[cur ^ 1][nnext + cl + lanes_below(mr, lane)] = 2 * pos + 1;
-        nnext += cl + cr;
+        if (tail - head + cl + cr > KNN2_FRONT) { overflow = true; why_front = true; break; }
+        if (gl) front[(tail + lanes_below(ml, lane)) % KNN2_FRONT] = 2 * pos;
+        if (gr) front[(tail + cl + lanes_below(mr, lane)) % KNN2_FRONT] = 2 * pos + 1;
+        tail += cl + cr;
+        __syncthreads();
       }
-      __syncthreads();
-      cur ^= 1; ncur = nnext;
     }
-    if (overflow) break;
+    __syncthreads();
+    if (overflow) continue;
     KNN_PROBE(0)
-    // ---- 2. does every query have k candidates within R?  (the same pass counts at three pivots around the k-th
-    // distance the first radius was derived from: the first step of the search below)
-    const double R2 = R * R;
+    // ---- 2. first counting pass: candidates inside the query's own ball and at three pivots
     c = 0; pc1 = 0; pc2 = 0; pc3 = 0;
     for (uint32_t j = 0; j < m; j++) {
       const float4 cd = cand[j];
       const double d2 = sq_dist(x0, x1, x2, (double)cd.x, (double)cd.y, (double)cd.z);
-      c += d2 < R2 ? 1u : 0u; pc1 += d2 < pt1 ? 1u : 0u; pc2 += d2 < pt2 ? 1u : 0u; pc3 += d2 < pt3 ? 1u : 0u;
+      c += d2 < b64 ? 1u : 0u; pc1 += d2 < pt1 ? 1u : 0u; pc2 += d2 < pt2 ? 1u : 0u; pc3 += d2 < pt3 ? 1u : 0u;
     }
     KNN_PROBE(1)
-    all_in = (m == n);                               // the box holds the whole map: exact whatever R is
-    if (__all(c >= k) || all_in) ok = true; else R *= 1.5;
-    __syncthreads();                                 // (the next walk overwrites cand / front)
+    ok = __all(c >= k);                              // then every query's k nearest photons are among the candidates, exactly
   }
-  if (!ok) { if (lane == 0) fallback[blockIdx.x] = 1; return; }
+  if (!ok) { knn_give_up(Q, u_first, u_count, nq, lane, overflow ? (why_front ? 1 : 0) : 2); return; }
   // ---- 3. per lane: t with exactly k candidates closer than t (or a tie group at the k-th distance)
-  double a = 0.0, b = R * R; uint32_t fa = 0, fb = c;           // #(d2 < a) = fa < k,  #(d2 < b) = fb >= k
-  if (all_in && c < k) {                                        // every photon is a candidate but fewer than k lie within R
-    double dmax = 0.0;
-    for (uint32_t j = 0; j < m; j++) { const float4 cd = cand[j]; dmax = fmax(dmax, sq_dist(x0, x1, x2, (double)cd.x, (double)cd.y, (double)cd.z)); }
-    b = dmax * 2.0 + 1e-300; fb = m;                             // m = n >= k (the host sends smaller maps to k_gather_knn)
-  }
+  double a = 0.0, b = b64; uint32_t fa = 0, fb = c;             // #(d2 < a) = fa < k,  #(d2 < b) = fb >= k
   bool done = (fb == k); double tau = b; bool tie = false; double tie_v = 0.0; uint32_t need = 0;
-  if (!done && !(all_in && c < k)) {                             // bracket from the first pass's pivots (0 < pt1 < pt2 < pt3 < R^2)
+  if (!done) {                                                   // bracket from the first pass's pivots (0 < pt1 < pt2 < pt3 < b)
     if (pc1 == k) { done = true; tau = pt1; }
     else if (pc2 == k) { done = true; tau = pt2; }
     else if (pc3 == k) { done = true; tau = pt3; }
@@ -890,10 +1027,10 @@ __global__ void __launch_bounds__(64) k_gather_knn_wave(DevMap M, const float *h
     else if (cnt - ties < k) { done = true; tie = true; tie_v = lmax; need = k - (cnt - ties); }
     else { b = lmax; fb = cnt - ties; }
   }
-  if (!__all(done)) { if (lane == 0) fallback[blockIdx.x] = 1; return; }
+  if (!__all(done)) { knn_give_up(Q, u_first, u_count, nq, lane, 3); return; }
   KNN_PROBE(2)
 #ifdef RT_KNN_PROBE
-  if (lane == 0) { atomicAdd(&knn_probe[5], 1ull); atomicAdd(&knn_probe[6], (unsigned long long)pass); atomicAdd(&knn_probe[7], (unsigned long long)m); }
+  if (lane == 0) { atomicAdd(&knn_probe[6], 1ull); atomicAdd(&knn_probe[7], (unsigned long long)pass); atomicAdd(&knn_probe[8], (unsigned long long)m); }
 #endif
   // ties at the k-th distance: the `need` lowest input indices among the candidates at distance tie_v
   int32_t idx_thr = -1;
@@ -915,8 +1052,8 @@ __global__ void __launch_bounds__(64) k_gather_knn_wave(DevMap M, const float *h
   // The candidates' payloads (direction, power * colour) come in through LDS, 64 at a time: one scattered load per
   // lane and chunk instead of one dependent global load per candidate.
   float sr = 0, sg = 0, sb = 0; double dk2 = 0.0;
-  float *pay_lds = (float *)&front[0][0];                        // 64 x 6 floats; the frontier buffers are free now
-  static_assert(sizeof(front) >= 64 * 6 * sizeof(float), "payload staging needs 1536 bytes");
+  float *pay_lds = (float *)&front[0];                        // 64 x 6 floats; the frontier buffers are free now
+  static_assert(KNN2_FRONT * sizeof(uint32_t) >= 64 * 6 * sizeof(float), "payload staging needs 1536 bytes");
   for (uint32_t base = 0; base < m; base += 64) {
     __syncthreads();                                             // the previous chunk has been consumed
     if (base + lane < m) {
@@ -940,7 +1077,6 @@ __global__ void __launch_bounds__(64) k_gather_knn_wave(DevMap M, const float *h
     }
   }
   KNN_PROBE(4)
-  if (lane == 0) fallback[blockIdx.x] = 0;
   if (valid) {
     const double r2 = dk2;                                       // squared distance of the k-th nearest
     const float inv_area = (float)(1.0 / (3.141592653589793 * r2));
@@ -950,29 +1086,185 @@ __global__ void __launch_bounds__(64) k_gather_knn_wave(DevMap M, const float *h
   }
 }
 
-// list of the set flags' positions, in order, and their number (one workgroup; the flag array is short)
-__global__ void __launch_bounds__(256) k_compact_flags(const uint8_t *flags, uint32_t n, uint32_t *list, uint32_t *out_count) {
-  __shared__ uint32_t part[256];
-  const uint32_t chunk = (n + 255) / 256, lo = threadIdx.x * chunk, hi = min(n, lo + chunk);
-  uint32_t c = 0;
-  for (uint32_t i = lo; i < hi; i++) c += flags[i] ? 1u : 0u;
-  part[threadIdx.x] = c;
-  __syncthreads();
-  uint32_t base = 0;
-  for (uint32_t t = 0; t < threadIdx.x; t++) base += part[t];
-  for (uint32_t i = lo; i < hi; i++) if (flags[i]) { if (base < n) list[base] = i; base++; }
-  if (threadIdx.x == 255) *out_count = base;
+// ---- one wave per query: the path for queries whose neighbourhood does not fit the buffers above in one piece
+// The 64 lanes walk the tree for ONE query, nearest side first (a stack of nodes in LDS, up to 64 popped per step),
+// keeping every photon within tau of the query in the candidate buffer.  tau starts as the k-th smallest distance to the
+// photons of the query's subtree (an upper bound of the k-th neighbour distance) and, whenever the buffer fills, drops
+// to the k-th smallest distance among the candidates, which are then cut down to those within it -- so any number of
+// photons inside the first ball can be streamed through a 512-entry buffer.  Distances that decide are the fp64
+// sq_dist; the fp32 tests of the walk only have to keep a superset.  Ties at the k-th distance go to the lowest
+// input index, as everywhere.  A query whose stack would overflow goes to the heap kernel's list.
+#define KNN1_PER_LANE (KNN2_CAP / 64)
+// k-th smallest (k >= 1) of the wave's 64 x KNN1_PER_LANE non-negative doubles (absent entries: +infinity), bit by bit
+// from the top: the largest v with fewer than k entries below it
+__device__ __forceinline__ double wave_kth_smallest(const double (&d)[KNN1_PER_LANE], uint32_t k) {
+  unsigned long long ans = 0;
+  for (int bit = 62; bit >= 0; bit--) {
+    const unsigned long long trial = ans | (1ull << bit);
+    uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < KNN1_PER_LANE; i++) c += (uint32_t)__popcll(__ballot((unsigned long long)__double_as_longlong(d[i]) < trial));
+    if (c < k) ans = trial;
+  }
+  return __longlong_as_double((long long)ans);
 }
 
-// ---- scratch of the k-nearest gather: per query group a fallback flag, the list of flagged groups, the same for the
-// second pass's parts, and two counters.  rt_gather_radiance keeps it in a grow-only buffer of the map;
+__global__ void __launch_bounds__(64) k_gather_knn_single(DevMap M, const float *hits, uint32_t nq, uint32_t k, uint32_t t_depth, float *rgb,
+                                                          const uint2 *units, const uint32_t *n_units, uint32_t *heap_list, uint32_t *heap_count) {
+  __shared__ float4 cand[KNN2_CAP];                  // x y z, slot (as bits)
+  __shared__ uint32_t stack[KNN2_FRONT];
+  const int lane = threadIdx.x;
+  if (blockIdx.x >= *n_units) return;                // (the grid is an upper bound)
+  const uint32_t q = units[blockIdx.x].x;
+  if (q >= nq) return;
+  const float *h = hits + (size_t)q * 9;
+  const float qx = h[0], qy = h[1], qz = h[2];
+  const double x0 = qx, x1 = qy, x2 = qz;
+  const uint32_t n = M.n;
+  uint32_t t_pos = 1; float plane_val = 0.f; unsigned long long path = 0;
+  static_assert(KNN2_FRONT * sizeof(uint32_t) >= 64 * sizeof(float4), "descent staging needs 1 KB");
+  knn_descend(M, qx, qy, qz, t_depth, (float4 *)&stack[0], lane, t_pos, path, plane_val);
+  uint32_t m = knn_load_subtree(M, t_pos, cand, lane);
+  __syncthreads();
+  double d[KNN1_PER_LANE];
+  auto load_d = [&](uint32_t cnt) {
+#pragma unroll
+    for (int i = 0; i < KNN1_PER_LANE; i++) {
+      const uint32_t j = (uint32_t)i * 64u + (uint32_t)lane;
+      const float4 cd = cand[j < cnt ? j : 0];
+      d[i] = j < cnt ? sq_dist(x0, x1, x2, (double)cd.x, (double)cd.y, (double)cd.z) : __builtin_huge_val();
+    }
+  };
+  load_d(m);
+  double tau = m >= k ? wave_kth_smallest(d, k) : __builtin_huge_val();      // (the host's depth gives every subtree k photons)
+  float tauf = 0.f, reach = 0.f;
+  auto set_tau = [&]() {                              // fp32 versions, rounded up, with room for the fp32 arithmetic of the walk
+    tauf = tau < 3.0e38 ? __double2float_ru(tau) * 1.000002f + 1e-37f : 3.4e38f;
+    reach = tau < 3.0e38 ? sqrtf(tauf) * 1.000001f : 3.4e38f;
+  };
+  set_tau();
+  // start at the deepest node of the descent whose subtree certainly holds the whole ball
+  uint32_t start_level = 0;
+  for (; start_level < t_depth; start_level++) {
+    const int dd = (int)((path >> (2 * start_level)) & 3u);
+    const float v = __shfl(plane_val, (int)start_level, 64);
+    const bool went_right = (t_pos >> (t_depth - 1 - start_level)) & 1u;
+    const float qd = (dd == 0) ? qx : (dd == 1) ? qy : qz;
+    if (!(went_right ? qd - reach > v : qd + reach < v)) break;
+  }
+  __syncthreads();                                   // (the subtree's photons have been consumed)
+  m = 0;
+  if (lane == 0) stack[0] = t_pos >> (t_depth - start_level);
+  __syncthreads();
+  uint32_t sp = 1; bool failed = false;
+  while (sp > 0) {
+    if (m + 64 > KNN2_CAP) {                          // no room for another step: lower tau to the k-th smallest so far
+      load_d(m);
+      float4 keep[KNN1_PER_LANE];
+#pragma unroll
+      for (int i = 0; i < KNN1_PER_LANE; i++) { const uint32_t j = (uint32_t)i * 64u + (uint32_t)lane; keep[i] = cand[j < m ? j : 0]; }
+      tau = wave_kth_smallest(d, k);
+      set_tau();
+      __syncthreads();
+      uint32_t m2 = 0;
+#pragma unroll
+      for (int i = 0; i < KNN1_PER_LANE; i++) {
+        const bool kp = d[i] <= tau;                  // (absent entries are +infinity)
+        const unsigned long long mk = __ballot(kp);
+        if (kp) cand[m2 + lanes_below(mk, lane)] = keep[i];
+        m2 += (uint32_t)__popcll(mk);
+      }
+      __syncthreads();
+      m = m2;
+      if (m + 64 > KNN2_CAP) { failed = true; break; }                       // (hundreds of photons at one and the same distance)
+    }
+    // (the fuller the stack, the fewer nodes a step takes off its top: those are the deepest, which soon end in leaves,
+    // and a step can add at most one entry per node it takes)
+    const uint32_t take = min(min(64u, sp), max(1u, (KNN2_FRONT - sp) / 8u));
+    const bool active = (uint32_t)lane < take;
+    const uint32_t pos = active ? stack[sp - take + lane] : 1u;              // 1 <= pos <= n by construction
+    sp -= take;
+    const float4 nd = M.node[pos - 1];
+    const float ddx = qx - nd.x, ddy = qy - nd.y, ddz = qz - nd.z;
+    const bool inside = active && ddx * ddx + ddy * ddy + ddz * ddz <= tauf;
+    const unsigned long long mi = __ballot(inside);
+    if (inside) cand[m + lanes_below(mi, lane)] = make_float4(nd.x, nd.y, nd.z, __uint_as_float(pos - 1));
+    m += (uint32_t)__popcll(mi);
+    const int dim = node_dim(nd);
+    const float delta = ((dim == 0) ? ddx : (dim == 1) ? ddy : ddz);        // query minus plane
+    const bool reachable = delta * delta <= tauf;
+    const bool gl = active && 2ull * pos <= n && (delta <= 0.f || reachable);
+    const bool gr = active && 2ull * pos + 1 <= n && (delta >= 0.f || reachable);
+    // far sides first, near sides on top of them
+    const bool far_l = gl && delta > 0.f, far_r = gr && delta < 0.f, near_l = gl && !(delta > 0.f), near_r = gr && !(delta < 0.f);
+    const unsigned long long b0 = __ballot(far_l), b1 = __ballot(far_r), b2 = __ballot(near_l), b3 = __ballot(near_r);
+    const uint32_t c0 = (uint32_t)__popcll(b0), c1 = (uint32_t)__popcll(b1), c2 = (uint32_t)__popcll(b2), c3 = (uint32_t)__popcll(b3);
+    if (sp + c0 + c1 + c2 + c3 > KNN2_FRONT) { failed = true; break; }
+    __syncthreads();                                 // (every lane has taken its node)
+    if (far_l) stack[sp + lanes_below(b0, lane)] = 2 * pos;
+    if (far_r) stack[sp + c0 + lanes_below(b1, lane)] = 2 * pos + 1;
+    if (near_l) stack[sp + c0 + c1 + lanes_below(b2, lane)] = 2 * pos;
+    if (near_r) stack[sp + c0 + c1 + c2 + lanes_below(b3, lane)] = 2 * pos + 1;
+    sp += c0 + c1 + c2 + c3;
+    __syncthreads();
+  }
+  if (failed || m < k) {                             // (m < k cannot happen on a map of k photons; the heap kernel copes with anything)
+    if (lane == 0) heap_list[atomicAdd(heap_count, 1u)] = q;
+    return;
+  }
+  // ---- the k nearest among the candidates
+  __syncthreads();
+  load_d(m);
+  const double vk = wave_kth_smallest(d, k);        // the k-th neighbour's squared distance
+  uint32_t below = 0, at = 0;
+#pragma unroll
+  for (int i = 0; i < KNN1_PER_LANE; i++) { below += (uint32_t)__popcll(__ballot(d[i] < vk)); at += (uint32_t)__popcll(__ballot(d[i] == vk)); }
+  int32_t idx_thr = 0x7FFFFFFF;                      // ties at vk: those with input index <= idx_thr are taken
+  if (below + at > k) {
+    int32_t pi[KNN1_PER_LANE];
+#pragma unroll
+    for (int i = 0; i < KNN1_PER_LANE; i++) pi[i] = d[i] == vk ? M.perm[__float_as_uint(cand[(uint32_t)i * 64u + (uint32_t)lane].w)] : 0x7FFFFFFF;
+    idx_thr = -1;
+    for (uint32_t left = k - below; left > 0; left--) {
+      int32_t best = 0x7FFFFFFF;
+#pragma unroll
+      for (int i = 0; i < KNN1_PER_LANE; i++) if (pi[i] > idx_thr && pi[i] < best) best = pi[i];
+      for (int o = 32; o > 0; o >>= 1) best = min(best, __shfl_xor(best, o, 64));
+      idx_thr = best;
+    }
+  }
+  const float nx = h[3], ny = h[4], nz = h[5];
+  float sr = 0, sg = 0, sb = 0;
+#pragma unroll
+  for (int i = 0; i < KNN1_PER_LANE; i++) {
+    const uint32_t j = (uint32_t)i * 64u + (uint32_t)lane;
+    if (j < m && d[i] <= vk) {
+      const uint32_t slot = __float_as_uint(cand[j].w);
+      if (d[i] < vk || idx_thr == 0x7FFFFFFF || M.perm[slot] <= idx_thr) {
+        const float2 *pp = (const float2 *)(M.pay + (size_t)slot * 6);
+        const float2 p0 = pp[0], p1 = pp[1], p2 = pp[2];
+        const float w = fmaxf(0.0f, p0.x * nx + p0.y * ny + p1.x * nz);
+        sr += p1.y * w; sg += p2.x * w; sb += p2.y * w;
+      }
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) { sr += __shfl_xor(sr, o, 64); sg += __shfl_xor(sg, o, 64); sb += __shfl_xor(sb, o, 64); }
+  if (lane == 0) {
+    const float inv_area = (float)(1.0 / (3.141592653589793 * vk));
+    rgb[(size_t)q * 3] = sr * (h[6] / 255.0f) * inv_area;
+    rgb[(size_t)q * 3 + 1] = sg * (h[7] / 255.0f) * inv_area;
+    rgb[(size_t)q * 3 + 2] = sb * (h[8] / 255.0f) * inv_area;
+  }
+}
+
+// ---- scratch of the k-nearest gather: counters, the unit queues of the three split levels (16-, 4- and 1-query
+// units) and the list of queries left to the heap kernel.  rt_gather_radiance keeps it in a grow-only buffer of the map;
 // rt_gather_radiance_static uses the array below, which exists once per GPU for the life of the process.
-#define KNN_SPLIT 64u                                       // parts of a flagged group in the second pass: one query per wave
 static size_t knn_scratch_bytes(uint32_t nq) {
   const size_t blocks = div_up(nq, KNN_LANES);
-  return (blocks + blocks * KNN_SPLIT) * 5 + 64;
+  return 256 + blocks * (4 + 16 + 64) * sizeof(uint2) + (size_t)nq * 4;
 }
-#define RT_STATIC_SCRATCH_BYTES ((((size_t)RT_GATHER_STATIC_MAX_QUERIES / KNN_LANES) * (1 + KNN_SPLIT) * 5 + 64 + 255) / 256 * 256)
+#define RT_STATIC_SCRATCH_BYTES ((256 + ((size_t)RT_GATHER_STATIC_MAX_QUERIES / KNN_LANES) * 84 * 8 + (size_t)RT_GATHER_STATIC_MAX_QUERIES * 4 + 255) / 256 * 256)
 static __device__ __align__(256) unsigned char scratch[RT_STATIC_SCRATCH_BYTES];
 // The array's name is only a host-side stand-in; the address of each GPU's copy is looked up once per device
 // (rt_static_scratch_setup, called by rt_init with that device current) and host code uses that pointer from then on.
@@ -990,8 +1282,8 @@ int rt_static_scratch_setup(rt_ctx *ctx) {
   return RT_OK;
 }
 
-// The k-nearest gather over device arrays, with its scratch in `ws` (knn_scratch_bytes(nq) bytes of device memory whose
-// old contents do not matter: every word that is read has been written by an earlier kernel of the same call).
+// The k-nearest gather over device arrays, with its scratch in `ws` (knn_scratch_bytes(nq) bytes of device memory; the
+// counters at its start are cleared here, everything else that is read has been written by an earlier kernel of the call).
 static int gather_knn_run(rt_photon_map *m, const float *dh, uint32_t nq, uint32_t k, float *dout, void *ws) {
   rt_ctx *ctx = m->ctx;
   const RtKnobs &K = ctx->knobs;
@@ -1001,55 +1293,64 @@ static int gather_knn_run(rt_photon_map *m, const float *dh, uint32_t nq, uint32
     RT_HIP(ctx, hipFuncSetAttribute((const void *)k_gather_knn, hipFuncAttributeMaxDynamicSharedMemorySize, knn_lds_bytes(k)));
     KernelTimer timer_(ctx, "gather_knn");
     hipLaunchKernelGGL(k_gather_knn, dim3(blocks), dim3(KNN_LANES), knn_lds_bytes(k), ctx->stream, m->view(),
-                       dh, nq, k, dout, (const uint32_t *)nullptr, (const uint32_t *)nullptr, 1u);
+                       dh, nq, k, dout, (const uint32_t *)nullptr, (const uint32_t *)nullptr);
     RT_HIP(ctx, hipGetLastError());
     return RT_OK;
   }
-  // first radius: the k-th neighbour distance if the photons were spread evenly over the faces of their bounding box
-  const double dx = (double)m->bbox[3] - m->bbox[0], dy = (double)m->bbox[4] - m->bbox[1], dz = (double)m->bbox[5] - m->bbox[2];
-  const double area = 2.0 * (dx * dy + dy * dz + dz * dx);
-  double r0 = area > 0 ? 1.2 * sqrt((double)k * area / (3.141592653589793 * (double)m->n)) : (dx + dy + dz) * (double)k / (double)m->n;
-  if (!(r0 > 0)) r0 = 1e-6;
-  if (K.knn_r0 > 0) r0 = K.knn_r0;
-  // pass 1: one wave per 64 consecutive queries.  pass 2: the groups whose queries were too spread out for the LDS
-  // buffers, again with the wave kernel, in KNN_SPLIT parts each.  pass 3: parts still left over, per-lane heaps.
-  const size_t units2_max = (size_t)blocks * KNN_SPLIT;
-  uint32_t *list1 = (uint32_t *)ws, *count1 = list1 + blocks;
-  uint32_t *list2 = count1 + 1, *count2 = list2 + units2_max;
-  uint8_t *flags1 = (uint8_t *)(count2 + 1), *flags2 = flags1 + blocks;
-  RT_LAUNCH(ctx, "gather_knn", k_gather_knn_wave, blocks, 64, m->view(), dh, nq, k, r0, dout, flags1, (const uint32_t *)nullptr, 1u);
-  RT_LAUNCH(ctx, "gather_knn_flags", k_compact_flags, 1, 256, flags1, blocks, list1, count1);
-  RT_HIP(ctx, hipMemcpyAsync(ctx->pinned, count1, 4, hipMemcpyDeviceToHost, ctx->stream));
-  RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  const uint32_t left1 = ctx->pinned[0] <= blocks ? ctx->pinned[0] : blocks;
-  uint32_t left2 = 0;
-  if (left1 > 0) {
-    const uint32_t units2 = left1 * KNN_SPLIT;
-    RT_LAUNCH(ctx, "gather_knn_split", k_gather_knn_wave, units2, 64, m->view(), dh, nq, k, r0, dout, flags2, (const uint32_t *)list1, KNN_SPLIT);
-    RT_LAUNCH(ctx, "gather_knn_flags", k_compact_flags, 1, 256, flags2, units2, list2, count2);
-    RT_HIP(ctx, hipMemcpyAsync(ctx->pinned, count2, 4, hipMemcpyDeviceToHost, ctx->stream));
-    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    left2 = ctx->pinned[0] <= units2 ? ctx->pinned[0] : units2;
-    if (left2 > 0) {
-      RT_HIP(ctx, hipFuncSetAttribute((const void *)k_gather_knn, hipFuncAttributeMaxDynamicSharedMemorySize, knn_lds_bytes(k)));
-      KernelTimer timer_(ctx, "gather_knn_heap_fallback");
-      hipLaunchKernelGGL(k_gather_knn, dim3(left2), dim3(KNN_LANES), knn_lds_bytes(k), ctx->stream, m->view(),
-                         dh, nq, k, dout, (const uint32_t *)list2, (const uint32_t *)list1, KNN_SPLIT);
+  // (test switch: the search balls of every unit scaled up, which drives units into the split levels and the heap kernel)
+  const float scale = K.knn_radius_scale > 1 ? (float)K.knn_radius_scale : 1.0f;
+  // depth at which the wave kernel takes its reference subtree: the first one where every subtree has at most 4k photons
+  // (and what fits the candidate buffer); the smallest subtree of that depth then still has k
+  auto subtree_size = [&](uint64_t pos) { uint64_t lo = pos, hi = pos, c = 0; while (lo <= m->n) { c += std::min<uint64_t>(hi, m->n) - lo + 1; lo *= 2; hi = 2 * hi + 1; } return c; };
+  uint32_t t_depth = 0;
+  while (t_depth < 30 && subtree_size((uint64_t)1 << t_depth) > std::min<uint64_t>(4ull * k, KNN2_CAP)) t_depth++;
+  while (t_depth > 0 && subtree_size(((uint64_t)2 << t_depth) - 1) < k) t_depth--;
+  // level 0: one wave per 64 consecutive queries.  Levels 1-3: the units whose candidates did not fit, cut into four
+  // each time (16, 4, 1 queries).  What is left then goes to the per-lane heap kernel.
+  uint32_t *counters = (uint32_t *)ws;                                     // [0..2] units queued for level 1..3, [3] queries for the heap kernel, [4..7] units given up by cause
+  uint2 *queue[3] = { (uint2 *)((char *)ws + 256), nullptr, nullptr };
+  queue[1] = queue[0] + (size_t)blocks * 4; queue[2] = queue[1] + (size_t)blocks * 16;
+  uint32_t *heap_list = (uint32_t *)(queue[2] + (size_t)blocks * 64);
+  RT_HIP(ctx, hipMemsetAsync(counters, 0, 32, ctx->stream));
+  uint32_t launched[4] = { blocks, 0, 0, 0 };
+  for (int level = 0; level < 4; level++) {
+    if (launched[level] == 0) break;
+    KnnQueues Q; Q.next = level < 3 ? queue[level] : nullptr; Q.next_count = level < 3 ? counters + level : nullptr;
+    Q.heap_list = heap_list; Q.heap_count = counters + 3; Q.why = counters + 4;
+    if (level < 3) {
+      RT_LAUNCH(ctx, level == 0 ? "gather_knn" : "gather_knn_split", k_gather_knn_wave, launched[level], 64, m->view(), dh, nq, k, scale, t_depth, dout,
+                level == 0 ? (const uint2 *)nullptr : (const uint2 *)queue[level - 1], level == 0 ? (const uint32_t *)nullptr : (const uint32_t *)(counters + level - 1), Q);
+    } else {                                                               // single queries: one wave each, streaming
+      RT_LAUNCH(ctx, "gather_knn_single", k_gather_knn_single, launched[level], 64, m->view(), dh, nq, k, t_depth, dout,
+                (const uint2 *)queue[2], (const uint32_t *)(counters + 2), heap_list, counters + 3);
     }
+    RT_HIP(ctx, hipMemcpyAsync(ctx->pinned, counters, 32, hipMemcpyDeviceToHost, ctx->stream));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (level == 3) break;
+    const uint32_t cap_next = launched[level] * 4;
+    launched[level + 1] = ctx->pinned[level] <= cap_next ? ctx->pinned[level] : cap_next;
+  }
+  const uint32_t left = ctx->pinned[3] <= nq ? ctx->pinned[3] : nq;
+  if (left > 0) {
+    RT_HIP(ctx, hipFuncSetAttribute((const void *)k_gather_knn, hipFuncAttributeMaxDynamicSharedMemorySize, knn_lds_bytes(k)));
+    KernelTimer timer_(ctx, "gather_knn_heap_fallback");
+    hipLaunchKernelGGL(k_gather_knn, dim3(div_up(left, KNN_LANES)), dim3(KNN_LANES), knn_lds_bytes(k), ctx->stream, m->view(),
+                       dh, nq, k, dout, (const uint32_t *)heap_list, (const uint32_t *)(counters + 3));
   }
   RT_HIP(ctx, hipGetLastError());
 #ifdef RT_KNN_PROBE
   if (K.knn_verbose) {
-    unsigned long long hp[8], zero[8] = { 0 };
+    unsigned long long hp[9], zero[9] = { 0 };
     RT_HIP(ctx, hipMemcpyFromSymbol(hp, HIP_SYMBOL(knn_probe), sizeof hp));
     RT_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(knn_probe), zero, sizeof zero));
-    const double w = hp[5] ? (double)hp[5] : 1.0;
-    fprintf(stderr, "knn probe per wave: walk %.0f check %.0f search %.0f ties %.0f sum %.0f cycles; passes %.2f candidates %.1f (%llu waves)\n",
-            hp[0] / w, hp[1] / w, hp[2] / w, hp[3] / w, hp[4] / w, hp[6] / w, hp[7] / w, hp[5]);
+    const double w = hp[6] ? (double)hp[6] : 1.0;
+    fprintf(stderr, "knn probe per wave: bound %.0f walk %.0f check %.0f search %.0f ties %.0f sum %.0f cycles; passes %.2f candidates %.1f (%llu waves)\n",
+            hp[5] / w, hp[0] / w, hp[1] / w, hp[2] / w, hp[3] / w, hp[4] / w, hp[7] / w, hp[8] / w, hp[6]);
   }
 #endif
   if (K.knn_verbose)
-    fprintf(stderr, "rt_gather_radiance: %u query groups; %u split into %u parts each; %u parts left to the heap kernel\n", blocks, left1, KNN_SPLIT, left2);
+    fprintf(stderr, "rt_gather_radiance: %u units of 64 queries, then %u of 16, %u of 4, %u of 1; given up for candidates %u, frontier %u, short %u, search %u; %u queries left to the heap kernel\n",
+            launched[0], launched[1], launched[2], launched[3], ctx->pinned[4], ctx->pinned[5], ctx->pinned[6], ctx->pinned[7], left);
   return RT_OK;
 }
 

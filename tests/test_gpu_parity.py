@@ -503,11 +503,16 @@ def test_knn_gather_wave_kernel_equals_heap_kernel_and_brute_force(rt):
     rows = np.random.default_rng(3).choice(hits.shape[0], 300, replace=False)
     exp = _brute_knn_gather(rec, hits[rows], K)
     assert np.allclose(got[rows], exp, rtol=2e-5, atol=1e-6 * scale)
-    # a far too small and a far too large first radius end in the same sets (growth loop / fallback to the heap kernel)
-    for r0 in (1e-4, 3.0):
-        with ctx.option("knn_r0", r0, 0):
+    # search balls three and eight times too large end in the same sets (candidate lists overflow: units cut into quarters,
+    # single queries streamed by one wave each); a thousand times too large sends every query down the single-query path
+    for sc_ in (3.0, 8.0, 1000.0):
+        with ctx.option("knn_radius_scale", sc_, 0):
             again = m.gather(hits, k=K)
-        assert np.allclose(again, heap, rtol=2e-5, atol=1e-6 * scale), r0
+        assert np.allclose(again, heap, rtol=2e-5, atol=1e-6 * scale), sc_
+    # queries in random order (a wave's 64 queries are far apart: nearly all of them end as single queries)
+    perm = np.random.default_rng(4).permutation(hits.shape[0])[:20000]
+    shuffled = m.gather(np.ascontiguousarray(hits[perm]), k=K)
+    assert np.allclose(shuffled, heap[perm], rtol=2e-5, atol=1e-6 * scale)
     # ragged tail (nq not a multiple of 64), k = 1 and k = 192
     for k in (1, 192):
         a = m.gather(hits[:1000], k=k)
@@ -532,9 +537,11 @@ def test_knn_gather_ties_at_the_kth_distance(rt):
     qpos = np.stack([qx.ravel() * 0.125 + 2.0, qy.ravel() * 0.125 + 2.0, np.full(256, 0.25)], -1)
     hits = np.concatenate([qpos, np.tile([0, 0, 1.0], (256, 1)), np.full((256, 3), 255.0)], axis=1).astype(np.float32)
     for k in (5, 7, 27, 64):
-        got = m.gather(hits, k=k)
         exp = _brute_knn_gather(rec, hits, k)
-        assert np.allclose(got, exp, rtol=2e-5, atol=1e-6 * max(1.0, float(np.abs(exp).max()))), k
+        for sc_ in (0, 1000.0):                  # the 64-query path; every query through the single-query path
+            with ctx.option("knn_radius_scale", sc_, 0):
+                got = m.gather(hits, k=k)
+            assert np.allclose(got, exp, rtol=2e-5, atol=1e-6 * max(1.0, float(np.abs(exp).max()))), (k, sc_)
 
 
 # ------------------------------------------------------------------ hierarchy scans (large scenes)
