@@ -54,9 +54,12 @@ def main():
     open(os.path.join(out, f"{tag}_pmc.md"), "w").write("\n".join(pmc))
     fetch, write = largest(db("fetch"), "FETCH_SIZE"), largest(db("write"), "WRITE_SIZE")
     traffic = {}
-    for key in ("k_primary", "k_tail", "k_gather_knn_wave", "k_emit", "k_kd_lds"):
-        f = [v for n, v in fetch.items() if key + "<" in n or key + "(" in n]
-        w = [v for n, v in write.items() if key + "<" in n or key + "(" in n]
+    # (the frame kernels by the instantiation the headline workload runs: fp32, culled primitive lists, no photon maps)
+    pick = {"k_primary": "k_primary<float, true, false, false>", "k_tail": "k_tail<float, true, false, false, 0>",
+            "k_gather_knn_wave": "k_gather_knn_wave(", "k_gather_knn_single": "k_gather_knn_single(", "k_emit": "k_emit<float", "k_kd_lds": "k_kd_lds("}
+    for key, pat in pick.items():
+        f = [v for n, v in fetch.items() if pat in n]
+        w = [v for n, v in write.items() if pat in n]
         if f and w:
             traffic[key] = {"fetch_size_kib": max(f), "write_size_kib": max(w), "traffic_bytes_per_launch": int((2 * max(f) + max(w)) * 1024)}
     traffic["_note"] = (f"rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes of `{CMD}` (tools/profile_round.sh); largest dispatch "
