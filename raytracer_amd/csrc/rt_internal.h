@@ -33,6 +33,8 @@ struct RtKnobs {
   long tail_threshold = -1;      // paths left at which the tail kernel takes over (< 0: the built-in default)
   int whole_frame = 0;           // 1: the whole frame in one launch
   int bounce_passes = 0;         // single-bounce passes between the first pass and the tail kernel
+  int tail_handoff = 0;          // > 0: tail workgroups down to this many paths (<= 64) hand them on to a further launch
+  int tail_rounds = 1;           // how many such further launches (1 .. 3)
   int no_lds = 0;                // 1: scans read the primitives through scalar loads instead of the LDS copy
   int no_cull = 0;               // 1: the first pass scans every primitive (no per-workgroup culling)
   int raster_order = 0;          // 1: paths numbered row by row even where 32x8 tiles would fit

@@ -183,8 +183,8 @@ static int trace_tile_mode(rt_scene *sc, int slot, const rt_params *p, DevMap md
   C.iter_base = bounce_passes;
   if (whole_frame) {
     const uint32_t tblocks = div_up(n_paths, RT_TAIL_THREADS);
-    if (lds_tail) RT_LAUNCH_SMEM(ctx, "trace", (k_tail<T, true, WHITTED, FULL, RT_TAIL_PRIMARY>), tblocks, RT_TAIL_THREADS, smem, S, P, C, md, mc, levels, (const uint32_t *)nullptr, (const uint32_t *)nullptr, 0u, 0u, ctr, 0);
-    else RT_LAUNCH_SMEM(ctx, "trace", (k_tail<T, false, WHITTED, FULL, RT_TAIL_PRIMARY>), tblocks, RT_TAIL_THREADS, 0, S, P, C, md, mc, levels, (const uint32_t *)nullptr, (const uint32_t *)nullptr, 0u, 0u, ctr, 0);
+    if (lds_tail) RT_LAUNCH_SMEM(ctx, "trace", (k_tail<T, true, WHITTED, FULL, RT_TAIL_PRIMARY>), tblocks, RT_TAIL_THREADS, smem, S, P, C, md, mc, levels, (const uint32_t *)nullptr, (const uint32_t *)nullptr, 0u, 0u, ctr, 0, 0u, (uint32_t *)nullptr, (uint32_t *)nullptr, 0);
+    else RT_LAUNCH_SMEM(ctx, "trace", (k_tail<T, false, WHITTED, FULL, RT_TAIL_PRIMARY>), tblocks, RT_TAIL_THREADS, 0, S, P, C, md, mc, levels, (const uint32_t *)nullptr, (const uint32_t *)nullptr, 0u, 0u, ctr, 0, 0u, (uint32_t *)nullptr, (uint32_t *)nullptr, 0);
   } else
   for (;;) {
     const uint32_t blocks = div_up(ub, 256);
@@ -202,9 +202,23 @@ static int trace_tile_mode(rt_scene *sc, int slot, const rt_params *p, DevMap md
         }
       }
       const uint32_t *lens = direct ? ctr->subq_count[bounce_passes] : cnt;
-      const uint32_t tblocks = div_up(ub, RT_TAIL_THREADS) + (direct ? RT_SUBQ : 0);
-      if (lds_tail) RT_LAUNCH_SMEM(ctx, "tail", (k_tail<T, true, WHITTED, FULL, RT_TAIL_QUEUE>), tblocks, RT_TAIL_THREADS, smem, S, P, C, md, mc, levels, (const uint32_t *)q_cur, lens, n_subq, cap, ctr, (int)wave_bounces);
-      else RT_LAUNCH_SMEM(ctx, "tail", (k_tail<T, false, WHITTED, FULL, RT_TAIL_QUEUE>), tblocks, RT_TAIL_THREADS, 0, S, P, C, md, mc, levels, (const uint32_t *)q_cur, lens, n_subq, cap, ctr, (int)wave_bounces);
+      uint32_t tblocks = div_up(ub, RT_TAIL_THREADS) + (direct ? RT_SUBQ : 0);
+      // Workgroups that are down to a thinly filled wave hand their paths on to a further, much smaller launch (see
+      // k_tail): `rounds` such launches follow the first, the last of which keeps its paths to their end.
+      const uint32_t handoff = (direct && K.tail_handoff > 0) ? std::min<uint32_t>((uint32_t)K.tail_handoff, 64u) : 0u;
+      const uint32_t rounds = handoff ? std::min<uint32_t>((uint32_t)std::max(K.tail_rounds, 1), RT_MAX_TAIL_ROUNDS) : 0u;
+      for (uint32_t r = 0; r <= rounds; r++) {
+        const uint32_t ho = r < rounds ? handoff : 0u;
+        uint32_t *c_out = ho ? ctr->subq_count[RT_MAX_BOUNCE_PASSES + 1 + r] : nullptr;
+        uint32_t *q_out = ho ? q_nxt : nullptr;
+        const uint32_t ns = r == 0 ? n_subq : RT_SUBQ, cp = r == 0 ? cap : C.subq_cap;
+        const char *name = r == 0 ? "tail" : "tail_rest";
+        if (lds_tail) RT_LAUNCH_SMEM(ctx, name, (k_tail<T, true, WHITTED, FULL, RT_TAIL_QUEUE>), tblocks, RT_TAIL_THREADS, smem, S, P, C, md, mc, levels, (const uint32_t *)q_cur, lens, ns, cp, ctr, (int)wave_bounces, ho, q_out, c_out, r > 0 ? 1 : 0);
+        else RT_LAUNCH_SMEM(ctx, name, (k_tail<T, false, WHITTED, FULL, RT_TAIL_QUEUE>), tblocks, RT_TAIL_THREADS, 0, S, P, C, md, mc, levels, (const uint32_t *)q_cur, lens, ns, cp, ctr, (int)wave_bounces, ho, q_out, c_out, r > 0 ? 1 : 0);
+        if (!ho) break;
+        lens = c_out; std::swap(q_cur, q_nxt);
+        tblocks = div_up(tblocks * handoff, RT_TAIL_THREADS) + RT_SUBQ;     // (every workgroup hands on at most `handoff` paths)
+      }
       break;
     }
     if (wave_bounces == 0) {

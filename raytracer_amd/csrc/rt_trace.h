@@ -99,12 +99,14 @@ RT_D uint32_t band_row(const TraceCfg &C, uint32_t row) {
 // device-side bookkeeping of one rt_trace_tile call; counts[b] = queue length of wavefront pass b
 #define RT_CTR_SLOTS 64
 #define RT_MAX_BOUNCE_PASSES 2
+#define RT_MAX_TAIL_ROUNDS 3
 struct TraceCounters {
   unsigned long long shadow_rays, gathers, stack_overflows, tail_rays[RT_CTR_SLOTS];
   unsigned long long prim_tests[RT_CTR_SLOTS * 16];   // ray-primitive tests counted by the scans that skip primitives; slot s at [16 s]
   uint32_t max_iter[RT_CTR_SLOTS];          // iterations the longest-lived workgroup of k_tail ran
   // lengths of the sub-queues the first pass ([0]) and the bounce passes after it ([1], [2]) leave (s at [16 s])
-  uint32_t subq_count[RT_MAX_BOUNCE_PASSES + 1][RT_SUBQ * 16];
+  // ([RT_MAX_BOUNCE_PASSES + 1 + r]: paths that launch r of k_tail handed on to launch r + 1)
+  uint32_t subq_count[RT_MAX_BOUNCE_PASSES + 1 + RT_MAX_TAIL_ROUNDS][RT_SUBQ * 16];
   uint32_t counts[RT_MAX_WAVE_BOUNCES + 2];
 #ifdef RT_TAIL_PROBE
   unsigned long long probe[3][6];           // [first / second / later iterations][phase] cycles seen by lane 0 of each workgroup; [..][5] = iterations
@@ -685,6 +687,11 @@ __global__ void __launch_bounds__(256) k_shade(DevScene<T> S, PathSoA<T> P, Trac
 //                    first iteration is the fused primary pass (camera ray in registers, staged origin terms).
 //                    Workgroups in their latency-bound late bounces share the CUs with workgroups in their
 //                    arithmetic-bound first pass, and no queue is built at all.
+// Hand-off (handoff > 0, at most 64): a workgroup that is down to `handoff` paths or fewer -- one thinly filled wave that
+// would hold the workgroup's LDS for the rest of the longest path -- writes their states to the path arrays, appends
+// them to the sub-queues q_out / c_out (capacity cap) and ends; the host follows with another, much smaller launch
+// over those sub-queues, where the paths fill whole waves again.  Such a launch gets per_path = 1: its paths are at
+// different bounces, which each lane takes from its path's depth (depth and bounce number advance together).
 // Segments traced here are counted in ctr->tail_rays[], the longest path in ctr->max_iter[] (spread over
 // RT_CTR_SLOTS addresses: same-address atomics from thousands of workgroups serialise).
 #ifndef RT_TAIL_THREADS
@@ -697,7 +704,7 @@ enum { RT_TAIL_QUEUE = 0, RT_TAIL_PRIMARY = 1 };
 template <typename T, bool LDS, bool WHITTED, bool FULL, int SRC>
 __global__ void __launch_bounds__(RT_TAIL_THREADS, RT_TAIL_MIN_WAVES) k_tail(DevScene<T> S, PathSoA<T> P, TraceCfg C, DevMap Md, DevMap Mc, T *levels,
                                                           const uint32_t *queue, const uint32_t *counts, uint32_t n_subq, uint32_t cap,
-                                                          TraceCounters *ctr, int bounce0) {
+                                                          TraceCounters *ctr, int bounce0, uint32_t handoff, uint32_t *q_out, uint32_t *c_out, int per_path) {
   extern __shared__ __align__(16) unsigned char rt_lds[];
   __shared__ uint32_t live[2][RT_TAIL_THREADS];
   __shared__ uint32_t wave_cnt[RT_TAIL_THREADS / 64];
@@ -739,7 +746,28 @@ __global__ void __launch_bounds__(RT_TAIL_THREADS, RT_TAIL_MIN_WAVES) k_tail(Dev
 #else
 #define RT_PROBE(k)
 #endif
+  int last_b = -1;                                         // per_path: bounce number of the last segment this lane traced
+  bool handed = false;
   for (int b = bounce0; n_live > 0 && b < C.max_bounces; b++) {
+    if (SRC == RT_TAIL_QUEUE && handoff && iters > 0 && n_live <= handoff && b + 1 < C.max_bounces) {
+      // (only wave 0 is left: handoff <= 64)
+      uint32_t p = 0;
+      const bool mine = threadIdx.x < n_live;
+      if (mine) {
+        if constexpr (LST) {
+          const uint32_t hd = min(live[cur][threadIdx.x], N - 1);
+          p = lstate[RT_LSTATE_WORDS * N + hd];
+          if (p < C.n_paths) { const PathState<T> st = load_path_lds(lstate, N, hd); store_path<T>(P, p, st); }
+        } else p = live[cur][threadIdx.x];
+      }
+      const uint32_t sq = blockIdx.x % RT_SUBQ;
+      uint32_t base = 0;
+      if (threadIdx.x == 0) base = atomicAdd(&c_out[sq * 16], n_live);
+      base = __shfl(base, 0, 64);
+      if (mine && base + threadIdx.x < cap) q_out[(size_t)sq * cap + base + threadIdx.x] = p;
+      handed = true;
+      break;
+    }
     rays += n_live; iters++;
     RT_PROBE(4)
     // waves 0 .. nw-1 are still running this iteration; the others have retired and their wave_cnt slots are stale
@@ -770,7 +798,9 @@ __global__ void __launch_bounds__(RT_TAIL_THREADS, RT_TAIL_MIN_WAVES) k_tail(Dev
           idx = scan_scene<T, WHITTED ? 3 : 0>(S, G, st.o, st.d, T(C.epsilon), T(0), t, &tally.tests);
         }
         RT_PROBE(1)
-        alive = shade_step<T, WHITTED, FULL>(S, G, P, C, Md, Mc, levels, p, st, t, idx, b, tally);
+        const int bl = per_path ? (int)(st.depth & 0xFFFF) : b;
+        last_b = bl;
+        alive = shade_step<T, WHITTED, FULL>(S, G, P, C, Md, Mc, levels, p, st, t, idx, bl, tally);
         if (alive) {
           if constexpr (LST) store_path_lds(lstate, N, hd, st); else store_path<T>(P, p, st);
         }
@@ -792,10 +822,15 @@ __global__ void __launch_bounds__(RT_TAIL_THREADS, RT_TAIL_MIN_WAVES) k_tail(Dev
     RT_PROBE(3)
     if ((uint32_t)(wv * 64) >= n_live) break;              // this wave has no path left (retired waves do not hold up barriers)
   }
+  (void)handed;
+  if (per_path) {                                           // iterations the first launch would have run for this wave's longest path
+    for (int off = 32; off > 0; off >>= 1) last_b = max(last_b, __shfl_xor(last_b, off, 64));
+    if (lane == 0 && last_b >= 0) atomicMax(&ctr->max_iter[(blockIdx.x + wv) % RT_CTR_SLOTS], (uint32_t)(last_b - bounce0 + 1) + C.iter_base);
+  }
   if (threadIdx.x == 0) {                                   // wave 0 is the last to retire: it has seen every iteration
     const uint32_t slot = blockIdx.x % RT_CTR_SLOTS;
     if (rays) atomicAdd(&ctr->tail_rays[slot], rays);
-    atomicMax(&ctr->max_iter[slot], iters ? iters + C.iter_base : 0u);
+    if (!per_path) atomicMax(&ctr->max_iter[slot], iters ? iters + C.iter_base : 0u);
 #ifdef RT_TAIL_PROBE
     pr[0][5] = iters > 0; pr[1][5] = iters > 1 ? (iters > 3 ? 2 : iters - 1) : 0; pr[2][5] = iters > 3 ? iters - 3 : 0;
     for (int a = 0; a < 3; a++) for (int k = 0; k < 6; k++) if (pr[a][k]) atomicAdd(&ctr->probe[a][k], pr[a][k]);

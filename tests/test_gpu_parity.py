@@ -460,6 +460,13 @@ def test_wavefront_and_whole_frame_pipelines_agree(rt, precision):
             assert same(wave["pre"], whole["pre"]) and same(wave["post"], whole["post"])
             for k in ("rays", "shadow_rays", "gathers"):
                 assert wave["stats"][k] == whole["stats"][k], (k, thr)
+        # tail workgroups that hand their last paths on to further launches
+        for ho, rounds in ((8, 1), (32, 2), (64, 3)):
+            with ctx.option("tail_handoff", ho, 0), ctx.option("tail_rounds", rounds, 1):
+                got = sc.trace_tile(p, md, mc)
+            assert same(got["pre"], whole["pre"]) and same(got["post"], whole["post"]), (ho, rounds)
+            for k in ("rays", "shadow_rays", "gathers", "bounces"):
+                assert got["stats"][k] == whole["stats"][k], (k, ho, rounds)
         # single-bounce passes between the first pass and the tail kernel
         for n in (0, 1, 2):
             with ctx.option("bounce_passes", n, 0):
