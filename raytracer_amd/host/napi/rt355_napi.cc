@@ -1,10 +1,11 @@
 // N-API shim: exposes the C ABI of librt355.so (include/rt355.h) to the Node host.
 // Thin by design: argument unpacking, typed-array borrowing for the duration of a call,
-// opaque handles as napi_external with finalisers, and status -> thrown JS Error (the
+// opaque handles as napi_external with finalisers (tagged boxes that share their context), and status -> thrown JS Error (the
 // reference's convention: `throw new Error`, kdtree.js:6, rayphoton.js:640, :1489).
 #include <node_api.h>
 #include <stdint.h>
 #include <string.h>
+#include <set>
 #include <string>
 #include <vector>
 #include "../../../include/rt355.h"
@@ -27,7 +28,18 @@ struct Args {
     return t != napi_undefined && t != napi_null;
   }
   double num(size_t i, double dflt = 0) const { double v = dflt; if (has(i)) napi_get_value_double(env, argv[i], &v); return v; }
-  template <typename T> T *ext(size_t i) const { void *p = nullptr; if (has(i)) napi_get_value_external(env, argv[i], &p); return (T *)p; }
+  // A handle of this addon: every box starts with the tag of its kind, so a context passed where a scene is expected
+  // (or a handle whose context has been shut down) is a TypeError, not a reinterpreted pointer.
+  template <typename T> T *ext(size_t i) const {
+    void *p = nullptr;
+    if (!has(i)) return nullptr;
+    napi_valuetype t; napi_typeof(env, argv[i], &t);
+    if (t != napi_external || napi_get_value_external(env, argv[i], &p) != napi_ok || !p) { napi_throw_type_error(env, nullptr, T::what()); return nullptr; }
+    T *box = (T *)p;
+    if (box->tag != T::TAG) { napi_throw_type_error(env, nullptr, T::what()); return nullptr; }
+    if (!box->live()) { napi_throw_error(env, nullptr, "rt355: the handle's context has been shut down"); return nullptr; }
+    return box;
+  }
   // typed array -> pointer + element count (borrowed for this call only)
   void *typed(size_t i, napi_typedarray_type want, size_t *len = nullptr) const {
     if (!has(i)) { if (len) *len = 0; return nullptr; }
@@ -85,8 +97,37 @@ static void read_params(napi_env env, napi_value o, rt_params *p) {
 
 static void set_num(napi_env env, napi_value obj, const char *name, double v) { napi_value n; napi_create_double(env, v, &n); napi_set_named_property(env, obj, name, n); }
 
-struct SceneBox { rt_ctx *ctx; rt_scene *scene; };
-struct MapBox { rt_ctx *ctx; rt_photon_map *map; };
+// Handles.  Scenes and maps point into their context, and the collector orders nothing: a scene may be finalised long
+// after shutdown(ctx).  So the context's box is shared: it knows its live scenes and maps, shutdown() frees them first
+// and marks them dead, and the box itself lives until the last handle that refers to it has been finalised.
+struct SceneBox; struct MapBox;
+struct CtxBox {
+  uint64_t tag; rt_ctx *ctx; int refs; std::set<SceneBox *> scenes; std::set<MapBox *> maps;
+  static constexpr uint64_t TAG = 0x7274333535637478ull;
+  static const char *what() { return "rt355: a context handle (from init) is expected"; }
+  bool live() const { return ctx != nullptr; }
+};
+struct SceneBox {
+  uint64_t tag; CtxBox *cb; rt_scene *scene;
+  static constexpr uint64_t TAG = 0x7274333535736365ull;
+  static const char *what() { return "rt355: a scene handle (from sceneUpload) is expected"; }
+  bool live() const { return scene != nullptr; }
+};
+struct MapBox {
+  uint64_t tag; CtxBox *cb; rt_photon_map *map;
+  static constexpr uint64_t TAG = 0x72743335356d6170ull;
+  static const char *what() { return "rt355: a photon map handle (from photonMapBuild) is expected"; }
+  bool live() const { return map != nullptr; }
+};
+static void ctx_close(CtxBox *cb) {                          // frees everything made from the context, then the context
+  if (!cb->ctx) return;
+  for (SceneBox *b : cb->scenes) { rt_scene_free(b->scene); b->scene = nullptr; }
+  for (MapBox *b : cb->maps) { rt_photon_map_free(b->map); b->map = nullptr; }
+  cb->scenes.clear(); cb->maps.clear();
+  rt_shutdown(cb->ctx);
+  cb->ctx = nullptr;
+}
+static void ctx_release(CtxBox *cb) { if (--cb->refs == 0) { ctx_close(cb); cb->tag = 0; delete cb; } }
 
 // init([deviceId]) -> ctx
 static napi_value Init(napi_env env, napi_callback_info info) {
@@ -95,35 +136,52 @@ static napi_value Init(napi_env env, napi_callback_info info) {
   rt_ctx *ctx = nullptr;
   int rc = rt_init(&dev, 1, &ctx);
   if (rc != RT_OK) return fail(env, nullptr, rc);
+  CtxBox *cb = new CtxBox{ CtxBox::TAG, ctx, 1, {}, {} };
   napi_value out;
-  // No finaliser: scenes and maps hold a pointer to their context and the GC orders nothing, so a
-  // context lives until shutdown(ctx) or process exit.
-  NAPI_OK(napi_create_external(env, ctx, nullptr, nullptr, &out));
+  if (napi_create_external(env, cb, [](napi_env, void *p, void *) { ctx_release((CtxBox *)p); }, nullptr, &out) != napi_ok) {
+    ctx_release(cb);
+    napi_throw_error(env, nullptr, "N-API call failed: napi_create_external");
+    return nullptr;
+  }
   return out;
 }
 
-// shutdown(ctx): only after every scene / map made from it has been dropped
+// shutdown(ctx): frees the context and every scene and map made from it; their handles become unusable (a later call
+// with one throws) and their finalisers have nothing left to free
 static napi_value Shutdown(napi_env env, napi_callback_info info) {
   Args a(env, info);
-  rt_shutdown(a.ext<rt_ctx>(0));
+  CtxBox *cb = a.ext<CtxBox>(0);
+  if (cb) ctx_close(cb);
   return nullptr;
 }
 
 // sceneUpload(ctx, flat) -> scene      flat = what host/scene.js flatten() returns
 static napi_value SceneUpload(napi_env env, napi_callback_info info) {
   Args a(env, info);
-  rt_ctx *ctx = a.ext<rt_ctx>(0);
-  if (!ctx || !a.has(1)) { napi_throw_type_error(env, nullptr, "sceneUpload(ctx, flat)"); return nullptr; }
+  CtxBox *cb = a.ext<CtxBox>(0);
+  if (!cb) return nullptr;
+  if (!a.has(1)) { napi_throw_type_error(env, nullptr, "sceneUpload(ctx, flat)"); return nullptr; }
+  rt_ctx *ctx = cb->ctx;
   napi_value f = a.argv[1];
   rt_scene_desc d; memset(&d, 0, sizeof d);
-  size_t n;
+  size_t n_meta, n_geom, n_col, n_ls, n_ld, n_surf, n;
   d.n_shapes = (uint32_t)prop_num(env, f, "nShapes", 0);
-  d.shape_meta = (const uint8_t *)prop_typed(env, f, "shapeMeta", napi_uint8_array, &n);
-  d.shape_geom = (const double *)prop_typed(env, f, "shapeGeom", napi_float64_array, &n);
-  d.shape_colour = (const double *)prop_typed(env, f, "shapeColour", napi_float64_array, &n);
+  d.shape_meta = (const uint8_t *)prop_typed(env, f, "shapeMeta", napi_uint8_array, &n_meta);
+  d.shape_geom = (const double *)prop_typed(env, f, "shapeGeom", napi_float64_array, &n_geom);
+  d.shape_colour = (const double *)prop_typed(env, f, "shapeColour", napi_float64_array, &n_col);
   d.n_lights = (uint32_t)prop_num(env, f, "nLights", 0);
-  d.light_shape = (const uint32_t *)prop_typed(env, f, "lightShape", napi_uint32_array, &n);
-  d.light_data = (const double *)prop_typed(env, f, "lightData", napi_float64_array, &n);
+  d.light_shape = (const uint32_t *)prop_typed(env, f, "lightShape", napi_uint32_array, &n_ls);
+  d.light_data = (const double *)prop_typed(env, f, "lightData", napi_float64_array, &n_ld);
+  d.shape_surface = (const double *)prop_typed(env, f, "shapeSurface", napi_float64_array, &n_surf);   // ray.js shape model, optional
+  // the C ABI sees raw pointers only: the arrays must be as long as the counts say
+  const size_t ns = d.n_shapes, nl = d.n_lights;
+  if (!d.shape_meta || !d.shape_geom || !d.shape_colour || n_meta != ns * 4 || n_geom != ns * 12 || n_col != ns * 4 ||
+      (nl > 0 && (!d.light_shape || !d.light_data)) || (d.light_shape && n_ls != nl) || (d.light_data && n_ld != nl * 8) ||
+      (d.shape_surface && n_surf != ns * 2)) {
+    napi_throw_range_error(env, nullptr, "sceneUpload: flat.shapeMeta / shapeGeom / shapeColour / lightShape / lightData / shapeSurface must hold "
+                                         "nShapes*4 / *12 / *4, nLights / nLights*8 and nShapes*2 elements");
+    return nullptr;
+  }
   const double *cam = (const double *)prop_typed(env, f, "camera", napi_float64_array, &n);
   if (!cam || n < 14) { napi_throw_type_error(env, nullptr, "flat.camera must be a Float64Array(16)"); return nullptr; }
   memcpy(d.camera, cam, sizeof(double) * (n < 16 ? n : 16));
@@ -131,26 +189,33 @@ static napi_value SceneUpload(napi_env env, napi_callback_info info) {
   const double *mats = (const double *)prop_typed(env, f, "materials", napi_float64_array, &n);
   if (!mats || n != 32) { napi_throw_type_error(env, nullptr, "flat.materials must be a Float64Array(32)"); return nullptr; }
   memcpy(d.materials, mats, sizeof d.materials);
-  d.shape_surface = (const double *)prop_typed(env, f, "shapeSurface", napi_float64_array, &n);   // ray.js shape model, optional
   rt_scene *sc = nullptr;
   int rc = rt_scene_upload(ctx, &d, &sc);
   if (rc != RT_OK) return fail(env, ctx, rc);
-  SceneBox *box = new SceneBox{ ctx, sc };
+  SceneBox *box = new SceneBox{ SceneBox::TAG, cb, sc };
+  cb->scenes.insert(box); cb->refs++;
   napi_value out;
-  NAPI_OK(napi_create_external(env, box, [](napi_env, void *p, void *) { SceneBox *b = (SceneBox *)p; rt_scene_free(b->scene); delete b; }, nullptr, &out));
+  auto fin = [](napi_env, void *p, void *) {
+    SceneBox *b = (SceneBox *)p;
+    if (b->scene) { rt_scene_free(b->scene); b->cb->scenes.erase(b); }
+    ctx_release(b->cb); b->tag = 0; delete b;
+  };
+  if (napi_create_external(env, box, fin, nullptr, &out) != napi_ok) { fin(env, box, nullptr); napi_throw_error(env, nullptr, "N-API call failed: napi_create_external"); return nullptr; }
   return out;
 }
 
 // intersectPairs(ctx, params, rayO, rayD, normalizeDir, shapeMeta, shapeGeom) -> Float64Array t (NaN = undefined)
 static napi_value IntersectPairs(napi_env env, napi_callback_info info) {
   Args a(env, info);
-  rt_ctx *ctx = a.ext<rt_ctx>(0);
+  CtxBox *cb = a.ext<CtxBox>(0);
+  if (!cb) return nullptr;
+  rt_ctx *ctx = cb->ctx;
   rt_params p; read_params(env, a.argv[1], &p);
   size_t no, nd, nm, ng;
   const double *o = (const double *)a.typed(2, napi_float64_array, &no), *d = (const double *)a.typed(3, napi_float64_array, &nd);
   const uint8_t *meta = (const uint8_t *)a.typed(5, napi_uint8_array, &nm);
   const double *geom = (const double *)a.typed(6, napi_float64_array, &ng);
-  if (!ctx || !o || !d || !meta || !geom) { napi_throw_type_error(env, nullptr, "intersectPairs: bad arguments"); return nullptr; }
+  if (!o || !d || !meta || !geom) { napi_throw_type_error(env, nullptr, "intersectPairs: bad arguments"); return nullptr; }
   uint32_t n = (uint32_t)(no / 3);
   if (nd != no || nm != (size_t)n * 4 || ng != (size_t)n * 12) { napi_throw_range_error(env, nullptr, "intersectPairs: array sizes disagree"); return nullptr; }
   napi_value ab, out; void *data;
@@ -169,14 +234,15 @@ static napi_value Intersect(napi_env env, napi_callback_info info) {
   size_t no, nd, ns = 0;
   const double *o = (const double *)a.typed(3, napi_float64_array, &no), *d = (const double *)a.typed(4, napi_float64_array, &nd);
   const double *sd = (const double *)a.typed(5, napi_float64_array, &ns);
-  if (!sb || !o || !d || no != nd) { napi_throw_type_error(env, nullptr, "intersect: bad arguments"); return nullptr; }
+  if (!sb) return nullptr;
+  if (!o || !d || no != nd) { napi_throw_type_error(env, nullptr, "intersect: bad arguments"); return nullptr; }
   uint32_t n = (uint32_t)(no / 3);
   if (sd && ns != n) { napi_throw_range_error(env, nullptr, "intersect: sourceDist size"); return nullptr; }
   napi_value abt, abi, t, idx, out; void *td, *id;
   NAPI_OK(napi_create_arraybuffer(env, (size_t)n * 8, &td, &abt)); NAPI_OK(napi_create_typedarray(env, napi_float64_array, n, abt, 0, &t));
   NAPI_OK(napi_create_arraybuffer(env, (size_t)n * 4, &id, &abi)); NAPI_OK(napi_create_typedarray(env, napi_int32_array, n, abi, 0, &idx));
   int rc = rt_intersect(sb->scene, &p, (int)a.num(2, 0), n, o, d, sd, (double *)td, (int32_t *)id);
-  if (rc != RT_OK) return fail(env, sb->ctx, rc);
+  if (rc != RT_OK) return fail(env, sb->cb->ctx, rc);
   NAPI_OK(napi_create_object(env, &out));
   napi_set_named_property(env, out, "t", t); napi_set_named_property(env, out, "idx", idx);
   return out;
@@ -186,14 +252,14 @@ static napi_value Intersect(napi_env env, napi_callback_info info) {
 static napi_value EmitMany(napi_env env, napi_callback_info info) {
   Args a(env, info);
   SceneBox *sb = a.ext<SceneBox>(0);
-  if (!sb) { napi_throw_type_error(env, nullptr, "emitMany(scene, params)"); return nullptr; }
+  if (!sb) return nullptr;
   rt_params p; read_params(env, a.argv[1], &p);
   const uint32_t ND = p.num_photons_diffuse, NC = p.num_photons_caustic;
   std::vector<double> d((size_t)ND * 11), c((size_t)NC * 11);
   std::vector<int64_t> da((size_t)ND * 2), ca((size_t)NC * 2);
   rt_emit_stats st;
   int rc = rt_emit_many(sb->scene, &p, d.data(), da.data(), c.data(), ca.data(), &st);
-  if (rc != RT_OK && rc != RT_ERR_ATTEMPT_CAP) return fail(env, sb->ctx, rc);     // the cap only logs in the reference (rayphoton.js:1366)
+  if (rc != RT_OK && rc != RT_ERR_ATTEMPT_CAP) return fail(env, sb->cb->ctx, rc);     // the cap only logs in the reference (rayphoton.js:1366)
   napi_value out, stats; NAPI_OK(napi_create_object(env, &out)); NAPI_OK(napi_create_object(env, &stats));
   auto f64 = [&](const char *name, const double *src, size_t n) {
     napi_value ab, ta; void *data; napi_create_arraybuffer(env, n * 8, &data, &ab); memcpy(data, src, n * 8);
@@ -213,16 +279,24 @@ static napi_value EmitMany(napi_env env, napi_callback_info info) {
 // photonMapBuild(ctx, rec Float64Array(n*11)) -> map
 static napi_value PhotonMapBuild(napi_env env, napi_callback_info info) {
   Args a(env, info);
-  rt_ctx *ctx = a.ext<rt_ctx>(0);
+  CtxBox *cb = a.ext<CtxBox>(0);
+  if (!cb) return nullptr;
+  rt_ctx *ctx = cb->ctx;
   size_t n = 0;
   const double *rec = (const double *)a.typed(1, napi_float64_array, &n);
-  if (!ctx) { napi_throw_type_error(env, nullptr, "photonMapBuild(ctx, rec)"); return nullptr; }
+  if (n % 11 != 0) { napi_throw_range_error(env, nullptr, "photonMapBuild: rec must hold 11 values per photon"); return nullptr; }
   rt_photon_map *m = nullptr;
   int rc = rt_photon_map_build(ctx, rec, (uint32_t)(n / 11), &m);
   if (rc != RT_OK) return fail(env, ctx, rc);
-  MapBox *box = new MapBox{ ctx, m };
+  MapBox *box = new MapBox{ MapBox::TAG, cb, m };
+  cb->maps.insert(box); cb->refs++;
   napi_value out;
-  NAPI_OK(napi_create_external(env, box, [](napi_env, void *p, void *) { MapBox *b = (MapBox *)p; rt_photon_map_free(b->map); delete b; }, nullptr, &out));
+  auto fin = [](napi_env, void *p, void *) {
+    MapBox *b = (MapBox *)p;
+    if (b->map) { rt_photon_map_free(b->map); b->cb->maps.erase(b); }
+    ctx_release(b->cb); b->tag = 0; delete b;
+  };
+  if (napi_create_external(env, box, fin, nullptr, &out) != napi_ok) { fin(env, box, nullptr); napi_throw_error(env, nullptr, "N-API call failed: napi_create_external"); return nullptr; }
   return out;
 }
 
@@ -230,13 +304,13 @@ static napi_value PhotonMapBuild(napi_env env, napi_callback_info info) {
 static napi_value PhotonMapNodes(napi_env env, napi_callback_info info) {
   Args a(env, info);
   MapBox *mb = a.ext<MapBox>(0);
-  if (!mb) { napi_throw_type_error(env, nullptr, "photonMapNodes(map)"); return nullptr; }
+  if (!mb) return nullptr;
   uint32_t n = rt_photon_map_size(mb->map);
   napi_value abp, abd, perm, dim, out; void *pd, *dd;
   NAPI_OK(napi_create_arraybuffer(env, (size_t)n * 4, &pd, &abp)); NAPI_OK(napi_create_typedarray(env, napi_int32_array, n, abp, 0, &perm));
   NAPI_OK(napi_create_arraybuffer(env, n, &dd, &abd)); NAPI_OK(napi_create_typedarray(env, napi_uint8_array, n, abd, 0, &dim));
   int rc = rt_photon_map_nodes(mb->map, (int32_t *)pd, (uint8_t *)dd);
-  if (rc != RT_OK) return fail(env, mb->ctx, rc);
+  if (rc != RT_OK) return fail(env, mb->cb->ctx, rc);
   NAPI_OK(napi_create_object(env, &out));
   napi_set_named_property(env, out, "perm", perm); napi_set_named_property(env, out, "dim", dim);
   return out;
@@ -248,13 +322,14 @@ static napi_value KdRadius(napi_env env, napi_callback_info info) {
   MapBox *mb = a.ext<MapBox>(0);
   size_t nq3 = 0;
   const float *q = (const float *)a.typed(1, napi_float32_array, &nq3);
-  if (!mb || !q) { napi_throw_type_error(env, nullptr, "kdRadius(map, queries, r, cap)"); return nullptr; }
+  if (!mb) return nullptr;
+  if (!q) { napi_throw_type_error(env, nullptr, "kdRadius(map, queries, r, cap)"); return nullptr; }
   uint32_t nq = (uint32_t)(nq3 / 3), cap = (uint32_t)a.num(3, 64);
   napi_value abc, abi, cnt, idx, out; void *cd, *id;
   NAPI_OK(napi_create_arraybuffer(env, (size_t)nq * 4, &cd, &abc)); NAPI_OK(napi_create_typedarray(env, napi_uint32_array, nq, abc, 0, &cnt));
   NAPI_OK(napi_create_arraybuffer(env, (size_t)nq * cap * 4, &id, &abi)); NAPI_OK(napi_create_typedarray(env, napi_int32_array, (size_t)nq * cap, abi, 0, &idx));
   int rc = rt_kd_radius(mb->map, q, nq, a.num(2, 0), cap, (uint32_t *)cd, (int32_t *)id);
-  if (rc != RT_OK) return fail(env, mb->ctx, rc);
+  if (rc != RT_OK) return fail(env, mb->cb->ctx, rc);
   NAPI_OK(napi_create_object(env, &out));
   napi_set_named_property(env, out, "count", cnt); napi_set_named_property(env, out, "idx", idx);
   return out;
@@ -266,13 +341,14 @@ static napi_value KdKnn(napi_env env, napi_callback_info info) {
   MapBox *mb = a.ext<MapBox>(0);
   size_t nq3 = 0;
   const float *q = (const float *)a.typed(1, napi_float32_array, &nq3);
-  if (!mb || !q) { napi_throw_type_error(env, nullptr, "kdKnn(map, queries, k)"); return nullptr; }
+  if (!mb) return nullptr;
+  if (!q) { napi_throw_type_error(env, nullptr, "kdKnn(map, queries, k)"); return nullptr; }
   uint32_t nq = (uint32_t)(nq3 / 3), k = (uint32_t)a.num(2, 64);
   napi_value abi, abd, idx, d2, out; void *id, *dd;
   NAPI_OK(napi_create_arraybuffer(env, (size_t)nq * k * 4, &id, &abi)); NAPI_OK(napi_create_typedarray(env, napi_int32_array, (size_t)nq * k, abi, 0, &idx));
   NAPI_OK(napi_create_arraybuffer(env, (size_t)nq * k * 8, &dd, &abd)); NAPI_OK(napi_create_typedarray(env, napi_float64_array, (size_t)nq * k, abd, 0, &d2));
   int rc = rt_kd_knn(mb->map, q, nq, k, (int32_t *)id, (double *)dd);
-  if (rc != RT_OK) return fail(env, mb->ctx, rc);
+  if (rc != RT_OK) return fail(env, mb->cb->ctx, rc);
   NAPI_OK(napi_create_object(env, &out));
   napi_set_named_property(env, out, "idx", idx); napi_set_named_property(env, out, "d2", d2);
   return out;
@@ -284,12 +360,13 @@ static napi_value GatherRadiance(napi_env env, napi_callback_info info) {
   MapBox *mb = a.ext<MapBox>(0);
   size_t n9 = 0;
   const float *h = (const float *)a.typed(1, napi_float32_array, &n9);
-  if (!mb || !h) { napi_throw_type_error(env, nullptr, "gatherRadiance(map, hits, r, k)"); return nullptr; }
+  if (!mb) return nullptr;
+  if (!h) { napi_throw_type_error(env, nullptr, "gatherRadiance(map, hits, r, k)"); return nullptr; }
   uint32_t nq = (uint32_t)(n9 / 9);
   napi_value ab, out; void *data;
   NAPI_OK(napi_create_arraybuffer(env, (size_t)nq * 12, &data, &ab)); NAPI_OK(napi_create_typedarray(env, napi_float32_array, (size_t)nq * 3, ab, 0, &out));
   int rc = rt_gather_radiance(mb->map, h, nq, a.num(2, 0), (uint32_t)a.num(3, 0), (float *)data);
-  if (rc != RT_OK) return fail(env, mb->ctx, rc);
+  if (rc != RT_OK) return fail(env, mb->cb->ctx, rc);
   return out;
 }
 
@@ -299,14 +376,15 @@ static napi_value GatherRadianceAdaptive(napi_env env, napi_callback_info info) 
   MapBox *mb = a.ext<MapBox>(0);
   size_t n9 = 0;
   const float *h = (const float *)a.typed(1, napi_float32_array, &n9);
-  if (!mb || !h) { napi_throw_type_error(env, nullptr, "gatherRadianceAdaptive(map, hits, r0, grow, minCount, minKeep, maxAttempts)"); return nullptr; }
+  if (!mb) return nullptr;
+  if (!h) { napi_throw_type_error(env, nullptr, "gatherRadianceAdaptive(map, hits, r0, grow, minCount, minKeep, maxAttempts)"); return nullptr; }
   uint32_t nq = (uint32_t)(n9 / 9);
   napi_value ab, ab2, rgb, rad, out; void *data, *data2;
   NAPI_OK(napi_create_arraybuffer(env, (size_t)nq * 12, &data, &ab)); NAPI_OK(napi_create_typedarray(env, napi_float32_array, (size_t)nq * 3, ab, 0, &rgb));
   NAPI_OK(napi_create_arraybuffer(env, (size_t)nq * 4, &data2, &ab2)); NAPI_OK(napi_create_typedarray(env, napi_float32_array, (size_t)nq, ab2, 0, &rad));
   int rc = rt_gather_radiance_adaptive(mb->map, h, nq, a.num(2, 0.1), a.num(3, 3), (uint32_t)a.num(4, 10), (uint32_t)a.num(5, 3), (uint32_t)a.num(6, 10),
                                        (float *)data, (float *)data2);
-  if (rc != RT_OK) return fail(env, mb->ctx, rc);
+  if (rc != RT_OK) return fail(env, mb->cb->ctx, rc);
   NAPI_OK(napi_create_object(env, &out));
   napi_set_named_property(env, out, "rgb", rgb); napi_set_named_property(env, out, "radius", rad);
   return out;
@@ -316,9 +394,11 @@ static napi_value GatherRadianceAdaptive(napi_env env, napi_callback_info info) 
 static napi_value TraceTile(napi_env env, napi_callback_info info) {
   Args a(env, info);
   SceneBox *sb = a.ext<SceneBox>(0);
-  if (!sb) { napi_throw_type_error(env, nullptr, "traceTile(scene, params, diffuse, caustic, x0, y0, w, h)"); return nullptr; }
+  if (!sb) return nullptr;
   rt_params p; read_params(env, a.argv[1], &p);
   MapBox *md = a.ext<MapBox>(2), *mc = a.ext<MapBox>(3);
+  { bool pending = false; napi_is_exception_pending(env, &pending); if (pending) return nullptr; }
+  if ((md && md->cb != sb->cb) || (mc && mc->cb != sb->cb)) { napi_throw_error(env, nullptr, "traceTile: the maps belong to another context"); return nullptr; }
   int x0 = (int)a.num(4), y0 = (int)a.num(5), w = (int)a.num(6), h = (int)a.num(7);
   if (w <= 0 || h <= 0) { napi_throw_range_error(env, nullptr, "traceTile: empty tile"); return nullptr; }
   const int blk = p.super_sample_block > 1 ? p.super_sample_block : 1;
@@ -329,7 +409,7 @@ static napi_value TraceTile(napi_env env, napi_callback_info info) {
   NAPI_OK(napi_create_arraybuffer(env, npx * 4, &d3, &ab3)); NAPI_OK(napi_create_typedarray(env, napi_uint8_array, npx * 4, ab3, 0, &r8));
   rt_trace_stats st;
   int rc = rt_trace_tile(sb->scene, &p, md ? md->map : nullptr, mc ? mc->map : nullptr, x0, y0, w, h, (double *)d1, (double *)d2, (uint8_t *)d3, &st);
-  if (rc != RT_OK) return fail(env, sb->ctx, rc);
+  if (rc != RT_OK) return fail(env, sb->cb->ctx, rc);
   NAPI_OK(napi_create_object(env, &out)); NAPI_OK(napi_create_object(env, &stats));
   napi_set_named_property(env, out, "pre", pre); napi_set_named_property(env, out, "post", post); napi_set_named_property(env, out, "rgba8", r8);
   set_num(env, stats, "rays", (double)st.rays); set_num(env, stats, "shadowRays", (double)st.shadow_rays);

@@ -154,4 +154,29 @@ check('Scene.traceTile / traceOnCanvas -> fillRect', tileBad <= 2, `${tileBad} p
   fs.unlinkSync(ppm);
 }
 
+// handles: wrong kinds and inconsistent flat scenes are rejected before the C ABI sees them; after shutdown(ctx) the
+// scenes and maps made from the context are dead (a call throws, a late finaliser frees nothing twice)
+{
+  const path = require('path');
+  const native = require(path.join(__dirname, '..', 'napi', 'rt355.node'));
+  const throws = (fn, what) => { try { fn(); return false; } catch (e) { return what ? what.test(String(e && e.name) + ' ' + String(e && e.message)) : true; } };
+  const ctx2 = native.init(0);
+  const sc2 = new rt.Scene({ width: 64, height: 48 }, { numPhotonsDiffuse: 100, numPhotonsCaustic: 100 });
+  require('../presets')['10'](sc2, rt);
+  sc2.initLights();
+  const flat = sc2.flatten();
+  const dev2 = native.sceneUpload(ctx2, flat);
+  const rec = new Float64Array(11 * 64); for (let i = 0; i < 64; i++) { rec[i * 11] = i; rec[i * 11 + 5] = 1; rec[i * 11 + 6] = 1; }
+  const map2 = native.photonMapBuild(ctx2, rec);
+  check('handle kinds are checked', throws(() => native.sceneUpload(dev2, flat), /TypeError/) && throws(() => native.photonMapNodes(dev2), /TypeError/) &&
+        throws(() => native.traceTile(ctx2, {}, null, null, 0, 0, 8, 8), /TypeError/) && throws(() => native.photonMapBuild({}, rec), /TypeError/), '');
+  const short = Object.assign({}, flat, { shapeGeom: flat.shapeGeom.subarray(0, flat.shapeGeom.length - 12) });
+  check('sceneUpload checks array lengths', throws(() => native.sceneUpload(ctx2, short), /RangeError/) &&
+        throws(() => native.sceneUpload(ctx2, Object.assign({}, flat, { nLights: flat.nLights + 1 })), /RangeError/), '');
+  native.shutdown(ctx2);
+  check('handles die with their context', throws(() => native.photonMapNodes(map2), /shut down/) && throws(() => native.traceTile(dev2, {}, null, null, 0, 0, 8, 8), /shut down/) &&
+        throws(() => native.sceneUpload(ctx2, flat), /shut down/), '');
+  if (global.gc) global.gc();
+}
+
 process.exit(failures ? 1 : 0);
