@@ -42,16 +42,16 @@ function genScenes() {
   }
 }
 
-// every preset of rayphoton.js (:731-1305) as a flat scene description, for the host's loadPreset and the all-preset
-// parity tests.  The RNG-built presets (5, 6, 'giacometti') are the instances drawn from stream (AUX, 1000 + id).
+// every preset of rayphoton.js (:731-1305) as a flat scene description, for the host's constructor check and the
+// all-preset parity tests.  The RNG-built presets (5, 9, 'giacometti') are the instances drawn from stream
+// (AUX, 1000 + id; 1099 for the named ones).
 function genPresets() {
-  const dir = path.resolve(__dirname, '../../raytracer_amd/presets');
-  fs.mkdirSync(dir, { recursive: true });
+  const dir = OUT;
   for (const preset of [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 'rmt', 'giacometti']) {
     let built;
     try { built = buildScene(preset); } catch (e) { console.log(`preset ${preset}: reference threw ${e.message}`); continue; }
     const flat = flattenScene(built.scene, built.L.ex, preset);
-    fs.writeFileSync(path.join(dir, `preset_${preset}.json`), JSON.stringify(flat));
+    fs.writeFileSync(path.join(dir, `scene_preset${preset}_flat.json`), JSON.stringify(flat));
     console.log(`preset ${preset}: ${flat.shapes.length} shapes, ${flat.lights.length} lights`);
   }
 }

@@ -38,8 +38,6 @@ for (const preset of [2, 3, 0, 1]) {
     params: { maxTraceDist: ex.MAX_TRACE_DIST, maxDepth: ex.MAX_DEPTH },
   };
   fs.writeFileSync(path.join(OUT, `scene_rayjs${preset}_flat.json`), JSON.stringify(flat));
-  fs.mkdirSync(path.resolve(__dirname, '../../raytracer_amd/presets'), { recursive: true });
-  fs.writeFileSync(path.resolve(__dirname, `../../raytracer_amd/presets/rayjs_${preset}.json`), JSON.stringify(flat));   // for the host's loadPreset
 
   const img = new Float64Array(W * H * 4), draws = new Int32Array(W * H);
   let errors = 0;

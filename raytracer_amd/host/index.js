@@ -8,6 +8,8 @@
 const path = require('path');
 const S = require('./scene');
 const presets = require('./presets');
+const RNG = require('./rng');
+const W = require('./whitted');
 
 let native = null;
 function addon() {
@@ -161,20 +163,23 @@ class Scene {
     this._device = null;
   }
 
-  // Presets 0, 2, 4, 7, 10 are built with this host's constructors (presets.js); the others come from the flat scene
-  // files of raytracer_amd/presets (all 13 scenes of rayphoton.js:731-1305 are there, the RNG-built ones as one instance).
+  // All thirteen scenes of rayphoton.js:731-1305, built with this host's constructors (presets.js).  Those that place
+  // or colour things at random draw from random(): the keyed stream (seed, AUX, 1000 + id; 1099 for the named presets),
+  // so a preset is the same scene on every run and on every rank.
   loadPreset(def) {
     const build = presets[String(def)];
-    const file = path.join(__dirname, '..', 'presets', `preset_${def}.json`);
-    if (build) build(this, S);
-    else if (require('fs').existsSync(file)) {
-      const src = JSON.parse(require('fs').readFileSync(file, 'utf8'));
-      this.lights = src.lights.map((l) => l.shape);
-      this.flatten = () => S.flattenFromJSON(src, this.canvasWidth, this.canvasHeight);
-      this.initLights = () => { this._device = null; };
+    if (build && String(def) !== 'helpers') {
+      this.lights = [];
+      this._random = new RNG.Stream(this.params.seed, RNG.DOMAIN.AUX, 1000 + (typeof def === 'number' ? def : 99), 0);
+      build(this, S);
     } else { console.log('No such scene!'); }                                // rayphoton.js:1306
     this.initLights();
     this.emitManyPhotons();
+  }
+  // the next number of the scene's own random stream (what Math.random() is to the reference's scene code)
+  random() {
+    if (!this._random) this._random = new RNG.Stream(this.params.seed, RNG.DOMAIN.AUX, 999, 0);
+    return this._random.next();
   }
 
   initLights() {                                                              // rayphoton.js:1313-1324
@@ -344,10 +349,13 @@ class WhittedScene extends FlatFileScene {
   }
   flatten() { return this._fromFile ? super.flatten() : S.flatten(this); }
   emitManyPhotons() { /* ray.js has no photon pass */ }
-  // the four scenes of ray.js:560-766
+  // the four scenes of ray.js:573-762, built with the older tracer's constructors (whitted.js)
   loadPreset(def) {
-    this._flatSource = JSON.parse(require('fs').readFileSync(path.join(__dirname, '..', 'presets', `rayjs_${def}.json`), 'utf8'));
-    this._fromFile = true; this._device = null;
+    const build = W.presets[String(def)];
+    if (!build) return;                                                      // (ray.js:760: nothing happens)
+    this.lamps = [];
+    build(this);
+    this._fromFile = false; this._device = null;
   }
 }
 
@@ -360,5 +368,5 @@ function writePPM(file, rgba8, width, height) {
   fs.writeFileSync(file, Buffer.concat([head, body]));
 }
 
-module.exports = Object.assign({}, S, { Scene, FlatFileScene, WhittedScene, Ray, Photon, KdTree, PRECISION, DEFAULTS, WHITTED_DEFAULTS,
+module.exports = Object.assign({}, S, { Whitted: W, Scene, FlatFileScene, WhittedScene, Ray, Photon, KdTree, PRECISION, DEFAULTS, WHITTED_DEFAULTS,
   context, addon, photonsToRecords, recordsToPhotons, writePPM });

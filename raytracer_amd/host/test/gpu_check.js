@@ -147,6 +147,20 @@ check('Scene.traceTile / traceOnCanvas -> fillRect', tileBad <= 2, `${tileBad} p
   let badA = 0;
   for (let i = 0; i < wa * ha * 4; i++) if (!same(oa.pre[i], ga.rgba[i])) badA++;
   check('WhittedScene.render (ray.js preset 3)', badA === 0, `${badA} values differ, ${oa.stats.rays} rays`);
+  // the same scene built with the older tracer's constructors instead of read from the file
+  const sb = new rt.WhittedScene({ width: wa, height: ha }, null, { seed: ga.meta.seed, precision: rt.PRECISION.F64 });
+  sb.loadPreset(3);
+  const ob = sb.render(0, 0, wa, ha);
+  let badB = 0;
+  for (let i = 0; i < wa * ha * 4; i++) if (!same(ob.pre[i], ga.rgba[i])) badB++;
+  check('WhittedScene.loadPreset(3) by constructors', badB === 0, `${badB} values differ`);
+  // a preset of rayphoton.js that is built from random numbers renders (the scene is the fixture's: flatten_check.js)
+  const s9 = new rt.Scene({ width: 64, height: 48 }, { numPhotonsDiffuse: 500, numPhotonsCaustic: 500, subSample: 1, seed: 12345 });
+  const quiet = console.log; console.log = () => {};
+  s9.loadPreset(9);
+  console.log = quiet;
+  const o9 = s9.render(0, 0, 64, 48);
+  check("Scene.loadPreset(9) (random hues) renders", s9.shapes.length === 43 && o9.stats.rays >= 64 * 48 && o9.rgba8.some((v) => v > 0), `${o9.stats.rays} rays`);
   const os = require('os'), fs = require('fs');
   const ppm = path.join(os.tmpdir(), 'rt355_check.ppm');
   rt.writePPM(ppm, oa.rgba8, wa, ha);

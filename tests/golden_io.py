@@ -42,12 +42,11 @@ def load_rayjs_scene(preset):
 RAYJS_PARAMS = dict(max_trace_dist=100.0, max_depth=20, sub_sample=1)      # ray.js:8-12
 
 
-PRESETS_DIR = os.path.join(os.path.dirname(GOLDEN), "..", "raytracer_amd", "presets")
 ALL_PRESETS = ["0", "1", "2", "3", "4", "5", "6", "7", "8", "9", "10", "rmt", "giacometti"]      # rayphoton.js:731-1305
 
 
 def load_packaged_preset(name, width=None, height=None):
-    """one of the flat scene files the package ships for the host's loadPreset (raytracer_amd/presets)"""
+    """the reference's scene objects of one preset, flattened (the RNG-built presets as the instance the harness drew)"""
     from raytracer_amd.scene import FlatScene
-    sc = FlatScene.from_json(os.path.join(PRESETS_DIR, f"preset_{name}.json"))
+    sc = FlatScene.from_json(os.path.join(GOLDEN, f"scene_preset{name}_flat.json"))
     return sc.with_size(width, height) if width is not None else sc
