@@ -287,6 +287,43 @@ int rt_trace_tile(rt_scene *scene, const rt_params *p, rt_photon_map *diffuse, r
                   int x0, int y0, int w, int h, double *pre_rgba, double *post_rgba, uint8_t *rgba8,
                   rt_trace_stats *stats);
 
+/* ---- the scene's single-item methods, batched: explicit rays, points and photons ----
+ * The reference calls these one item at a time from script; here each takes n items, one GPU lane an item (no
+ * queues, no sorting: they are for callers that drive the tracer themselves, not for frames).  Item i draws from the
+ * keyed stream (p->seed, domain, first_stream + i) -- for rays and points the domain is RT_DOMAIN_RENDER, so
+ * first_stream = y * width + x continues the stream of pixel (x, y) of a frame with the same seed -- starting at draw
+ * first_draw[i] (0 when first_draw is NULL).
+ *
+ * rt_trace_rays: `Scene.traceRay(ray, maxDist, depth, importance, materialStack)` (rayphoton.js:1626-1838).
+ *   ray_o, ray_d : n*3 doubles; directions as the reference's Ray holds them, i.e. already of unit length
+ *   max_dist, depth, importance : per ray, or NULL for p->max_trace_dist, 0, 1 (what traceOnCanvas passes, :1606)
+ *   stacks       : n*16 bytes, host memory: byte 0 the length (1..15), then the material ids from the bottom of the
+ *                  stack; NULL for [MAT_AIR]
+ *   rgba_out     : n*4 doubles, the colour traceRay returns (alpha NaN-able)
+ * rt_direct_light: `Scene.directLight(point, normal, localColour)` (rayphoton.js:1841-1880); points, normals and
+ *   local_rgb are n*3 doubles, rgb_out n*3 doubles, draws_out (may be NULL) the stream position afterwards.
+ * rt_create_photons: `Scene.createPhoton(source)` (rayphoton.js:1326-1344) on the streams of emission phase `phase`
+ *   (1 or 2: the stream of attempt first_stream + i of that phase); source[i] >= 0 names a light, < 0 (or source ==
+ *   NULL) lets the draw choose.  photons_out: n*11 doubles, origin3 dir3 power rgba.  Always 5 draws.
+ * rt_walk_photons: `Scene.emitPhoton(photon, depth, trackOnlyCaustic, materialStack)` (rayphoton.js:1461-1557) for
+ *   the n photons in `photons` (n*11 doubles as above; caustic[i] = -1 / 0 / 1 is the photon's isCaustic: undefined,
+ *   false, true; NULL = all undefined).  kind_out[i] = 0: nothing stored, 1: a diffuse photon, 2: a caustic photon;
+ *   where something is stored, photons[i] is replaced by the stored record (what storePhoton receives, power already
+ *   divided by the list cap).  A createPhoton followed by emitPhoton on the same stream, first_draw = 5, is exactly
+ *   attempt first_stream + i of rt_emit_photons. */
+int rt_trace_rays(rt_scene *scene, const rt_params *p, rt_photon_map *diffuse, rt_photon_map *caustic, uint32_t n,
+                  const double *ray_o, const double *ray_d, const double *max_dist, const int32_t *depth,
+                  const double *importance, const uint8_t *stacks, uint32_t first_stream, const uint32_t *first_draw,
+                  double *rgba_out, rt_trace_stats *stats);
+int rt_direct_light(rt_scene *scene, const rt_params *p, uint32_t n, const double *points, const double *normals,
+                    const double *local_rgb, uint32_t first_stream, const uint32_t *first_draw, double *rgb_out,
+                    uint32_t *draws_out);
+int rt_create_photons(rt_scene *scene, const rt_params *p, uint32_t n, int phase, uint64_t first_stream,
+                      const int32_t *source, double *photons_out, uint32_t *draws_out);
+int rt_walk_photons(rt_scene *scene, const rt_params *p, uint32_t n, int phase, uint64_t first_stream,
+                    const uint32_t *first_draw, const int32_t *depth, const int8_t *caustic, const uint8_t *stacks,
+                    int track_only_caustic, double *photons, uint8_t *kind_out);
+
 #ifdef __cplusplus
 }
 #endif

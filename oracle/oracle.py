@@ -139,6 +139,16 @@ def disc_sample(seed, domain, a, b, first_draw, c, radius, n):
     return out
 
 
+def direct_light(scene: Scene, p: OraParams, domain, a, b, first_draw, point, normal, local):
+    """directLight at one point on a keyed stream: (rgb, stream position afterwards)"""
+    point, normal, local = _c(point, np.float64), _c(normal, np.float64), _c(local, np.float64)
+    out = np.empty(3, np.float64)
+    lib().ora_direct_light_keyed.restype = C.c_uint32
+    draws = lib().ora_direct_light_keyed(C.byref(scene.c), C.byref(p), C.c_uint32(domain), C.c_uint32(a), C.c_uint32(b), C.c_uint32(first_draw),
+                                         _p(point), _p(normal), _p(local), _p(out))
+    return out, draws
+
+
 def emit_many(scene: Scene, p: OraParams):
     nd, nc = p.num_photons_diffuse, p.num_photons_caustic
     diffuse = np.zeros((nd, 11), np.float64)

@@ -656,6 +656,15 @@ static void direct_light(rctx *c, v3 point, v3 normal, const double local[3], do
   for (int k = 0; k < 3; k++) out[k] = floor(col[k] / 1);      /* :1876-1878 */
 }
 
+/* directLight at one point on a keyed stream (for tests of the product's rt_direct_light); returns the stream position */
+uint32_t ora_direct_light_keyed(const ora_scene *s, const ora_params *P, uint32_t domain, uint32_t a, uint32_t b, uint32_t first_draw,
+                                const double point[3], const double normal[3], const double local[3], double out[3]) {
+  rng_t g; rng_set(&g, P->seed, domain, a, b); g.draw = first_draw;
+  rctx c = { s, P, NULL, &g, 0 };
+  direct_light(&c, ld(point), ld(normal), local, out);
+  return g.draw;
+}
+
 typedef struct { const double *rec; v3 normal; double sum[3]; } gather_t;
 static void gather_rec(const ora_maps *m, int k, uint32_t posn, const double x[3], double r, gather_t *G) {
   if (posn >= m->n[k] + 1) return;                             /* kdtree.js:64-80, visiting instead of listing */

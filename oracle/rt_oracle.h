@@ -79,6 +79,10 @@ void ora_disc_sample_keyed(uint64_t seed, uint32_t domain, uint32_t a, uint32_t 
                            const double c[3], double radius, const double n[3], double out[3]);
 int ora_create_photon_keyed(const ora_scene *s, uint64_t seed, uint32_t domain, uint32_t a, uint32_t b,
                             double out8[8]);
+/* directLight (rayphoton.js:1841-1880) at one point on stream (P->seed, domain, a, b) from first_draw; returns the
+ * stream position afterwards */
+uint32_t ora_direct_light_keyed(const ora_scene *s, const ora_params *P, uint32_t domain, uint32_t a, uint32_t b, uint32_t first_draw,
+                                const double point[3], const double normal[3], const double local[3], double out[3]);
 
 /* photon emission: keyed restatement of emitManyPhotons.  Returns 0, or 1 when an attempt cap
  * was hit.  Lists are in store order.  tags: isCaustic, phase, attempt (as int64 triplets). */

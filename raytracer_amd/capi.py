@@ -28,7 +28,7 @@ EXPORTS = [
     "rt_lists_create", "rt_lists_free", "rt_lists_record_words", "rt_lists_apply", "rt_lists_counts", "rt_lists_export", "rt_lists_view",
     "rt_photon_map_build", "rt_photon_map_build_packed", "rt_photon_map_build_lists", "rt_band_rows",
     "rt_photon_map_free", "rt_photon_map_size", "rt_photon_map_nodes", "rt_kd_build", "rt_find_median",
-    "rt_kd_radius", "rt_kd_knn", "rt_gather_radiance", "rt_gather_radiance_static", "rt_gather_radiance_adaptive", "rt_trace_tile",
+    "rt_kd_radius", "rt_kd_knn", "rt_gather_radiance", "rt_gather_radiance_static", "rt_gather_radiance_adaptive", "rt_trace_tile", "rt_trace_rays", "rt_direct_light", "rt_create_photons", "rt_walk_photons",
 ]
 
 
@@ -299,6 +299,68 @@ class Scene:
             C.c_void_p(caustic.h.value if caustic else None), C.c_int(x0), C.c_int(y0), C.c_int(w), C.c_int(h),
             _ptr(pre), _ptr(post), _ptr(rgba8), C.byref(st) if stats else None))
         return dict(pre=pre, post=post, rgba8=rgba8, stats={k: getattr(st, k) for k, _ in TraceStats._fields_} if stats else None)
+
+    @staticmethod
+    def _stacks(stacks, n):
+        """list of material lists (bottom first) -> the n x 16 byte form of rt_trace_rays / rt_walk_photons"""
+        if stacks is None:
+            return None
+        out = np.zeros((n, 16), np.uint8)
+        for i, st in enumerate(stacks):
+            out[i, 0] = len(st)
+            out[i, 1:1 + len(st)] = st
+        return out
+
+    def trace_rays(self, params, ray_o, ray_d, diffuse=None, caustic=None, max_dist=None, depth=None, importance=None, stacks=None,
+                   first_stream=0, first_draw=None, stats=False):
+        """Scene.traceRay for n explicit rays (unit directions): (n, 4) colours [, stats]"""
+        o, d = _c(ray_o, np.float64), _c(ray_d, np.float64)
+        n = o.shape[0]
+        md = _c(max_dist, np.float64) if max_dist is not None else None
+        dp = _c(depth, np.int32) if depth is not None else None
+        im = _c(importance, np.float64) if importance is not None else None
+        fd = _c(first_draw, np.uint32) if first_draw is not None else None
+        sk = self._stacks(stacks, n)
+        out = np.empty((n, 4), np.float64)
+        st = TraceStats()
+        self.ctx.check(self.ctx.lib.rt_trace_rays(
+            self.h, C.byref(params), C.c_void_p(diffuse.h.value if diffuse else None), C.c_void_p(caustic.h.value if caustic else None),
+            C.c_uint32(n), _ptr(o), _ptr(d), _ptr(md), _ptr(dp), _ptr(im), _ptr(sk), C.c_uint32(first_stream), _ptr(fd), _ptr(out),
+            C.byref(st) if stats else None))
+        return (out, {k: getattr(st, k) for k, _ in TraceStats._fields_}) if stats else out
+
+    def direct_light(self, params, points, normals, local_rgb, first_stream=0, first_draw=None):
+        """Scene.directLight for n points: (n, 3) colours and the stream positions afterwards"""
+        pt, nr, lc = _c(points, np.float64), _c(normals, np.float64), _c(local_rgb, np.float64)
+        n = pt.shape[0]
+        fd = _c(first_draw, np.uint32) if first_draw is not None else None
+        out = np.empty((n, 3), np.float64)
+        draws = np.empty(n, np.uint32)
+        self.ctx.check(self.ctx.lib.rt_direct_light(self.h, C.byref(params), C.c_uint32(n), _ptr(pt), _ptr(nr), _ptr(lc), C.c_uint32(first_stream),
+                                                    _ptr(fd), _ptr(out), _ptr(draws)))
+        return out, draws
+
+    def create_photons(self, params, n, phase=1, first_stream=0, source=None):
+        """Scene.createPhoton on the streams of attempts first_stream .. first_stream + n of an emission phase"""
+        src = _c(source, np.int32) if source is not None else None
+        out = np.empty((n, 11), np.float64)
+        draws = np.empty(n, np.uint32)
+        self.ctx.check(self.ctx.lib.rt_create_photons(self.h, C.byref(params), C.c_uint32(n), C.c_int(phase), C.c_uint64(first_stream), _ptr(src),
+                                                      _ptr(out), _ptr(draws)))
+        return out, draws
+
+    def walk_photons(self, params, photons, phase=1, first_stream=0, first_draw=None, depth=None, caustic=None, stacks=None, track_only_caustic=False):
+        """Scene.emitPhoton for explicit photons (n x 11): (records, kind) -- kind 0 nothing stored, 1 diffuse, 2 caustic"""
+        ph = np.array(photons, np.float64, order="C", copy=True)
+        n = ph.shape[0]
+        fd = _c(first_draw, np.uint32) if first_draw is not None else None
+        dp = _c(depth, np.int32) if depth is not None else None
+        ca = _c(caustic, np.int8) if caustic is not None else None
+        sk = self._stacks(stacks, n)
+        kind = np.empty(n, np.uint8)
+        self.ctx.check(self.ctx.lib.rt_walk_photons(self.h, C.byref(params), C.c_uint32(n), C.c_int(phase), C.c_uint64(first_stream), _ptr(fd), _ptr(dp),
+                                                    _ptr(ca), _ptr(sk), C.c_int(int(track_only_caustic)), _ptr(ph), _ptr(kind)))
+        return ph, kind
 
     def emit_photons(self, params, phase, a0, a1):
         cap = max(a1 - a0, 1)

@@ -595,6 +595,131 @@ int rt_intersect(rt_scene *sc, const rt_params *p, int mode, uint32_t n, const d
   return rt_stage_out_end(ctx, idx_out, (size_t)n * 4, ti);
 }
 
+// ------------------------------------------------------------------ explicit rays, points, photons
+// stacks as the callers write them (16 bytes a ray: the length, then the materials from the bottom) -> MatStack words
+static int pack_stacks(rt_ctx *ctx, const uint8_t *stacks, uint32_t n, std::vector<uint64_t> &out) {
+  out.resize(n);
+  for (uint32_t i = 0; i < n; i++) {
+    const uint8_t *s = stacks + (size_t)i * 16;
+    if (s[0] < 1 || s[0] > 15) return rt_fail(ctx, RT_ERR_INVALID, "material stack %u: length %u outside 1..15", i, (unsigned)s[0]);
+    uint64_t bits = (uint64_t)s[0] << 56;
+    for (int k = 0; k < s[0]; k++) {
+      if (s[1 + k] > 7) return rt_fail(ctx, RT_ERR_INVALID, "material stack %u: material %u outside 0..7", i, (unsigned)s[1 + k]);
+      bits |= (uint64_t)s[1 + k] << (3 * k);
+    }
+    out[i] = bits;
+  }
+  return RT_OK;
+}
+
+int rt_trace_rays(rt_scene *sc, const rt_params *p, rt_photon_map *diffuse, rt_photon_map *caustic, uint32_t n, const double *ray_o,
+                  const double *ray_d, const double *max_dist, const int32_t *depth, const double *importance, const uint8_t *stacks,
+                  uint32_t first_stream, const uint32_t *first_draw, double *rgba_out, rt_trace_stats *stats) {
+  if (!sc || !p) return RT_ERR_INVALID;
+  rt_ctx *ctx = sc->ctx;
+  if (!ray_o || !ray_d || !rgba_out) return rt_fail(ctx, RT_ERR_INVALID, "rt_trace_rays: ray_o, ray_d and rgba_out are required");
+  if (p->mode != RT_MODE_PHOTON) return rt_fail(ctx, RT_ERR_INVALID, "rt_trace_rays follows rayphoton.js's traceRay only (mode RT_MODE_PHOTON)");
+  if ((diffuse && diffuse->ctx != ctx) || (caustic && caustic->ctx != ctx)) return rt_fail(ctx, RT_ERR_INVALID, "photon map belongs to another context");
+  if ((uint64_t)first_stream + n > 0x7FFFFFFFull) return rt_fail(ctx, RT_ERR_INVALID, "rt_trace_rays: first_stream + n must stay below 2^31");
+  if (n == 0) return RT_OK;
+  RT_HIP(ctx, hipSetDevice(ctx->device));
+  RT_TRY(rt_synchronize(ctx));                                // (shares the first frame slot's counters)
+  DevMem to, td, tm, tp, ti, ts, tf, tr;
+  const void *o, *d, *md_ = nullptr, *dp = nullptr, *im = nullptr, *st = nullptr, *fd = nullptr; void *out;
+  RT_TRY(rt_stage_in(ctx, ray_o, (size_t)n * 24, to, &o)); RT_TRY(rt_stage_in(ctx, ray_d, (size_t)n * 24, td, &d));
+  if (max_dist) RT_TRY(rt_stage_in(ctx, max_dist, (size_t)n * 8, tm, &md_));
+  if (depth) RT_TRY(rt_stage_in(ctx, depth, (size_t)n * 4, tp, &dp));
+  if (importance) RT_TRY(rt_stage_in(ctx, importance, (size_t)n * 8, ti, &im));
+  std::vector<uint64_t> packed;
+  if (stacks) {
+    if (rt_is_device_ptr(stacks)) return rt_fail(ctx, RT_ERR_INVALID, "rt_trace_rays: stacks must be host memory");
+    RT_TRY(pack_stacks(ctx, stacks, n, packed));
+    RT_TRY(rt_stage_in(ctx, packed.data(), (size_t)n * 8, ts, &st));
+  }
+  if (first_draw) RT_TRY(rt_stage_in(ctx, first_draw, (size_t)n * 4, tf, &fd));
+  RT_TRY(rt_stage_out_begin(ctx, rgba_out, (size_t)n * 32, tr, &out));
+  DevMap md = diffuse ? diffuse->view() : DevMap{}, mc = caustic ? caustic->view() : DevMap{};
+  if (p->precision == RT_PRECISION_F64)
+    RT_TRY(pl_trace_rays<double>(sc, p, md, mc, n, (const double *)o, (const double *)d, (const double *)md_, (const int32_t *)dp, (const double *)im,
+                                 (const uint64_t *)st, first_stream, (const uint32_t *)fd, (double *)out, stats));
+  else
+    RT_TRY(pl_trace_rays<float>(sc, p, md, mc, n, (const double *)o, (const double *)d, (const double *)md_, (const int32_t *)dp, (const double *)im,
+                                (const uint64_t *)st, first_stream, (const uint32_t *)fd, (double *)out, stats));
+  return rt_stage_out_end(ctx, rgba_out, (size_t)n * 32, tr);
+}
+
+int rt_direct_light(rt_scene *sc, const rt_params *p, uint32_t n, const double *points, const double *normals, const double *local_rgb,
+                    uint32_t first_stream, const uint32_t *first_draw, double *rgb_out, uint32_t *draws_out) {
+  if (!sc || !p) return RT_ERR_INVALID;
+  rt_ctx *ctx = sc->ctx;
+  if (!points || !normals || !local_rgb || !rgb_out) return rt_fail(ctx, RT_ERR_INVALID, "rt_direct_light: points, normals, local_rgb and rgb_out are required");
+  if (sc->d32.n_lights == 0) return rt_fail(ctx, RT_ERR_INVALID, "rt_direct_light: the scene has no lights");
+  if (n == 0) return RT_OK;
+  RT_HIP(ctx, hipSetDevice(ctx->device));
+  DevMem tp, tn, tl, tf, tr, tw; const void *pt, *nr, *lc, *fd = nullptr; void *out, *dr = nullptr;
+  RT_TRY(rt_stage_in(ctx, points, (size_t)n * 24, tp, &pt)); RT_TRY(rt_stage_in(ctx, normals, (size_t)n * 24, tn, &nr));
+  RT_TRY(rt_stage_in(ctx, local_rgb, (size_t)n * 24, tl, &lc));
+  if (first_draw) RT_TRY(rt_stage_in(ctx, first_draw, (size_t)n * 4, tf, &fd));
+  RT_TRY(rt_stage_out_begin(ctx, rgb_out, (size_t)n * 24, tr, &out));
+  if (draws_out) RT_TRY(rt_stage_out_begin(ctx, draws_out, (size_t)n * 4, tw, &dr));
+  if (p->precision == RT_PRECISION_F64)
+    RT_TRY(pl_direct_light<double>(sc, p, n, (const double *)pt, (const double *)nr, (const double *)lc, first_stream, (const uint32_t *)fd, (double *)out, (uint32_t *)dr));
+  else
+    RT_TRY(pl_direct_light<float>(sc, p, n, (const double *)pt, (const double *)nr, (const double *)lc, first_stream, (const uint32_t *)fd, (double *)out, (uint32_t *)dr));
+  if (draws_out) RT_TRY(rt_stage_out_end(ctx, draws_out, (size_t)n * 4, tw));
+  return rt_stage_out_end(ctx, rgb_out, (size_t)n * 24, tr);
+}
+
+static int photons_explicit(rt_scene *sc, const rt_params *p, uint32_t n, int phase, uint64_t first_stream, const uint32_t *first_draw, int create,
+                            const int32_t *source, const int32_t *depth, const int8_t *caustic, const uint8_t *stacks, int track_only_caustic,
+                            double *io, uint8_t *kind_out, uint32_t *draws_out, const char *who) {
+  if (!sc || !p) return RT_ERR_INVALID;
+  rt_ctx *ctx = sc->ctx;
+  if (!io || (!create && !kind_out)) return rt_fail(ctx, RT_ERR_INVALID, "%s: the photon array%s required", who, create ? " is" : " and kind_out are");
+  if (phase != 1 && phase != 2) return rt_fail(ctx, RT_ERR_INVALID, "%s: phase must be 1 or 2", who);
+  if (sc->d32.n_lights == 0 && create) return rt_fail(ctx, RT_ERR_INVALID, "%s: the scene has no lights", who);
+  if (n == 0) return RT_OK;
+  RT_HIP(ctx, hipSetDevice(ctx->device));
+  DevMem tf, ts, td, tc, tk, tio, tkind, tdr; const void *fd = nullptr, *src = nullptr, *dp = nullptr, *ca = nullptr, *st = nullptr; void *dio, *dk = nullptr, *dr = nullptr;
+  if (first_draw) RT_TRY(rt_stage_in(ctx, first_draw, (size_t)n * 4, tf, &fd));
+  if (source) RT_TRY(rt_stage_in(ctx, source, (size_t)n * 4, ts, &src));
+  if (depth) RT_TRY(rt_stage_in(ctx, depth, (size_t)n * 4, td, &dp));
+  if (caustic) RT_TRY(rt_stage_in(ctx, caustic, (size_t)n, tc, &ca));
+  std::vector<uint64_t> packed;
+  if (stacks) {
+    if (rt_is_device_ptr(stacks)) return rt_fail(ctx, RT_ERR_INVALID, "%s: stacks must be host memory", who);
+    RT_TRY(pack_stacks(ctx, stacks, n, packed));
+    RT_TRY(rt_stage_in(ctx, packed.data(), (size_t)n * 8, tk, &st));
+  }
+  // the photon array goes in and comes out
+  const bool io_dev = rt_is_device_ptr(io);
+  if (io_dev) dio = io;
+  else { RT_HIP(ctx, tio.alloc((size_t)n * 88)); dio = tio.p; if (!create) RT_HIP(ctx, hipMemcpyAsync(dio, io, (size_t)n * 88, hipMemcpyHostToDevice, ctx->stream)); }
+  if (kind_out) RT_TRY(rt_stage_out_begin(ctx, kind_out, n, tkind, &dk));
+  if (draws_out) RT_TRY(rt_stage_out_begin(ctx, draws_out, (size_t)n * 4, tdr, &dr));
+  const int domain = phase == 1 ? RT_DOMAIN_EMIT_PHASE1 : RT_DOMAIN_EMIT_PHASE2;
+  if (p->precision == RT_PRECISION_F64)
+    RT_TRY(pl_photons_explicit<double>(sc, p, n, domain, first_stream, (const uint32_t *)fd, create, (const int32_t *)src, (const int32_t *)dp, (const int8_t *)ca,
+                                       (const uint64_t *)st, track_only_caustic, (double *)dio, (uint8_t *)dk, (uint32_t *)dr));
+  else
+    RT_TRY(pl_photons_explicit<float>(sc, p, n, domain, first_stream, (const uint32_t *)fd, create, (const int32_t *)src, (const int32_t *)dp, (const int8_t *)ca,
+                                      (const uint64_t *)st, track_only_caustic, (double *)dio, (uint8_t *)dk, (uint32_t *)dr));
+  if (!io_dev) { RT_HIP(ctx, hipMemcpyAsync(io, dio, (size_t)n * 88, hipMemcpyDeviceToHost, ctx->stream)); RT_HIP(ctx, hipStreamSynchronize(ctx->stream)); }
+  if (kind_out) RT_TRY(rt_stage_out_end(ctx, kind_out, n, tkind));
+  if (draws_out) RT_TRY(rt_stage_out_end(ctx, draws_out, (size_t)n * 4, tdr));
+  return RT_OK;
+}
+
+int rt_create_photons(rt_scene *sc, const rt_params *p, uint32_t n, int phase, uint64_t first_stream, const int32_t *source, double *photons_out,
+                      uint32_t *draws_out) {
+  return photons_explicit(sc, p, n, phase, first_stream, nullptr, 1, source, nullptr, nullptr, nullptr, 0, photons_out, nullptr, draws_out, "rt_create_photons");
+}
+
+int rt_walk_photons(rt_scene *sc, const rt_params *p, uint32_t n, int phase, uint64_t first_stream, const uint32_t *first_draw, const int32_t *depth,
+                    const int8_t *caustic, const uint8_t *stacks, int track_only_caustic, double *photons, uint8_t *kind_out) {
+  return photons_explicit(sc, p, n, phase, first_stream, first_draw, 0, nullptr, depth, caustic, stacks, track_only_caustic, photons, kind_out, nullptr, "rt_walk_photons");
+}
+
 // ------------------------------------------------------------------ renderer
 int rt_trace_tile(rt_scene *sc, const rt_params *p, rt_photon_map *diffuse, rt_photon_map *caustic, int x0, int y0, int w, int h,
                   double *pre_rgba, double *post_rgba, uint8_t *rgba8, rt_trace_stats *stats) {

@@ -18,6 +18,65 @@ struct EmitCounters { unsigned long long segments, errors, overflows; };
 
 #define RT_REC_STRIDE 11
 
+// emitPhoton (rayphoton.js:1461-1557) as a loop: follows photon `ph` (at recursion depth `depth`, inside the materials of
+// `st`) until it is absorbed, dropped or leaves the scene.  Returns 0 (nothing stored), 1 (a diffuse photon) or 2 (a
+// caustic one) and, when something is stored, writes its record (hit3, -dir3, power / list cap, rgba) to r[0..10].
+template <typename T>
+RT_D int photon_walk(const DevScene<T> &S, const ScanSrc<T> &G, const EmitCfg &C, RngStream &rng, PhotonState<T> &ph, MatStack &st, int depth,
+                     bool track_only_caustic, T *r, unsigned long long &segments, unsigned long long &errors, unsigned long long &overflows) {
+  const T eps = T(C.epsilon);
+  for (;;) {
+    T t; segments++;
+    int idx = scan_scene<T, 1>(S, G, ph.o, ph.d, eps, T(0), t);
+    if (idx < 0) return 0;                                                   // left the scene
+    V3<T> hit = ph.o + t * ph.d;
+    V3<T> local = shape_colour<T>(S, idx, hit);
+    V3<T> n = shape_normal<T>(S, idx, hit);
+    const T cos1 = -dot(ph.d, n);
+    const bool has_mat = S.meta[4 * idx + 1] < 8;
+    const int mat = S.meta[4 * idx + 1] & 7;
+    if (has_mat && S.mat[0][mat] == T(1) && depth < C.max_depth) {           // :1484
+      V3<T> ndir; bool ovf = false;
+      if (!fresnel_bounce<T>(S, mat, ph.d, n, cos1, st, rng, ndir, ovf)) { errors++; return 0; }   // :1487-1490 throws
+      if (ovf) overflows++;
+      ph.o = hit; ph.d = normalize<T>(ndir, eps);
+      if (ph.caustic < 0) ph.caustic = 1;
+      depth++;
+      continue;
+    }
+    // opaque, or transparent at depth >= MAX_DEPTH where reflectance is undefined (never "< U")
+    const bool opaque_mat = has_mat && S.mat[0][mat] != T(1);
+    if (rng.next_k() < (opaque_mat ? S.refl_k[mat] : 0u)) {                  // :1523
+      if (depth < C.max_depth) {
+        if (rng.next_k() < S.spec_k[mat]) {                                  // :1525-1533 specular
+          ph.o = hit; ph.d = normalize<T>(ph.d + (T(2) * cos1) * n, eps);
+          if (ph.caustic < 0) ph.caustic = 1;
+          depth++;
+          continue;
+        } else if (!track_only_caustic) {                                    // :1536-1546 diffuse
+          V3<T> ndir = vec_perturb<T>(n, eps, rng);
+          T adj = ph.power * T(255 + 255 + 255 + 1) / (local.x + local.y + local.z + T(1));
+          ph.r = ph.r / T(255) * local.x; ph.g = ph.g / T(255) * local.y; ph.b = ph.b / T(255) * local.z; ph.a = T(1);
+          ph.power = adj;
+          ph.o = hit; ph.d = normalize<T>(ndir, eps); ph.caustic = 0;
+          depth++;
+          continue;
+        }
+      }
+      return 0;                                                              // dropped
+    }
+    if (depth > 0) {                                                         // absorbed: store (:1549-1553)
+      const bool is_c = ph.caustic == 1;
+      T power = ph.power / (is_c ? T(C.num_caustic) : T(C.num_diffuse));
+      V3<T> back = normalize<T>(T(-1) * ph.d, eps);
+      r[0] = hit.x; r[1] = hit.y; r[2] = hit.z; r[3] = back.x; r[4] = back.y; r[5] = back.z;
+      r[6] = power; r[7] = ph.r; r[8] = ph.g; r[9] = ph.b; r[10] = ph.a;
+      return is_c ? 2 : 1;
+    }
+    return 0;
+  }
+}
+
 template <typename T, bool LDS>
 __global__ void __launch_bounds__(256) k_emit(DevScene<T> S, EmitCfg C, int phase, unsigned long long a0, uint32_t count,
                                               uint8_t *kind, T *rec, uint8_t *nseg, EmitCounters *ctr) {
@@ -28,63 +87,11 @@ __global__ void __launch_bounds__(256) k_emit(DevScene<T> S, EmitCfg C, int phas
   if (i < count) {
     const unsigned long long attempt = a0 + i;
     const T eps = T(C.epsilon);
-    const bool track_only_caustic = (phase == 2);
     RngStream rng;
     rng.init(C.seed, phase == 1 ? RT_DOMAIN_EMIT_PHASE1 : RT_DOMAIN_EMIT_PHASE2, (uint32_t)attempt, (uint32_t)(attempt >> 32));
     PhotonState<T> ph; create_photon<T>(S, eps, rng, ph);
     MatStack st; st.init();
-    int depth = 0, stored = 0;
-    for (;;) {
-      T t; segments++;
-      int idx = scan_scene<T, 1>(S, G, ph.o, ph.d, eps, T(0), t);
-      if (idx < 0) break;                                                      // left the scene
-      V3<T> hit = ph.o + t * ph.d;
-      V3<T> local = shape_colour<T>(S, idx, hit);
-      V3<T> n = shape_normal<T>(S, idx, hit);
-      const T cos1 = -dot(ph.d, n);
-      const bool has_mat = S.meta[4 * idx + 1] < 8;
-      const int mat = S.meta[4 * idx + 1] & 7;
-      if (has_mat && S.mat[0][mat] == T(1) && depth < C.max_depth) {           // :1484
-        V3<T> ndir; bool ovf = false;
-        if (!fresnel_bounce<T>(S, mat, ph.d, n, cos1, st, rng, ndir, ovf)) { errors++; break; }   // :1487-1490 throws
-        if (ovf) overflows++;
-        ph.o = hit; ph.d = normalize<T>(ndir, eps);
-        if (ph.caustic < 0) ph.caustic = 1;
-        depth++;
-        continue;
-      }
-      // opaque, or transparent at depth >= MAX_DEPTH where reflectance is undefined (never "< U")
-      const bool opaque_mat = has_mat && S.mat[0][mat] != T(1);
-      if (rng.next_k() < (opaque_mat ? S.refl_k[mat] : 0u)) {                  // :1523
-        if (depth < C.max_depth) {
-          if (rng.next_k() < S.spec_k[mat]) {                                  // :1525-1533 specular
-            ph.o = hit; ph.d = normalize<T>(ph.d + (T(2) * cos1) * n, eps);
-            if (ph.caustic < 0) ph.caustic = 1;
-            depth++;
-            continue;
-          } else if (!track_only_caustic) {                                    // :1536-1546 diffuse
-            V3<T> ndir = vec_perturb<T>(n, eps, rng);
-            T adj = ph.power * T(255 + 255 + 255 + 1) / (local.x + local.y + local.z + T(1));
-            ph.r = ph.r / T(255) * local.x; ph.g = ph.g / T(255) * local.y; ph.b = ph.b / T(255) * local.z; ph.a = T(1);
-            ph.power = adj;
-            ph.o = hit; ph.d = normalize<T>(ndir, eps); ph.caustic = 0;
-            depth++;
-            continue;
-          }
-        }
-        break;                                                                 // dropped
-      }
-      if (depth > 0) {                                                         // absorbed: store (:1549-1553)
-        const bool is_c = ph.caustic == 1;
-        T power = ph.power / (is_c ? T(C.num_caustic) : T(C.num_diffuse));
-        V3<T> back = normalize<T>(T(-1) * ph.d, eps);
-        T *r = rec + (size_t)i * RT_REC_STRIDE;
-        r[0] = hit.x; r[1] = hit.y; r[2] = hit.z; r[3] = back.x; r[4] = back.y; r[5] = back.z;
-        r[6] = power; r[7] = ph.r; r[8] = ph.g; r[9] = ph.b; r[10] = ph.a;
-        stored = is_c ? 2 : 1;
-      }
-      break;
-    }
+    const int stored = photon_walk<T>(S, G, C, rng, ph, st, 0, phase == 2, rec + (size_t)i * RT_REC_STRIDE, segments, errors, overflows);
     kind[i] = (uint8_t)stored;
     nseg[i] = (uint8_t)(segments < 255 ? segments : 255);
   }
@@ -97,6 +104,47 @@ __global__ void __launch_bounds__(256) k_emit(DevScene<T> S, EmitCfg C, int phas
     if (errors) atomicAdd(&ctr->errors, errors);
     if (overflows) atomicAdd(&ctr->overflows, overflows);
   }
+}
+
+// createPhoton(source) / emitPhoton(photon, depth, trackOnlyCaustic, materialStack) for explicit photons, one lane each
+// (the host's Scene.createPhoton / emitPhoton; the bulk emission above never goes through here).  Photon i draws from
+// stream (seed, domain, first_stream + i) starting at draw first_draw[i] (0 without the array).
+//   create: io[i] receives createPhoton's photon (origin3 dir3 power rgba), source[i] >= 0 names the light
+//   walk:   io[i] is followed to its end; kind[i] = 0 / 1 / 2 and, if stored, io[i] becomes the stored record
+// draws[i] receives the stream position afterwards.
+template <typename T>
+__global__ void __launch_bounds__(64) k_photons_explicit(DevScene<T> S, EmitCfg C, uint32_t n, int domain, unsigned long long first_stream,
+                                                         const uint32_t *first_draw, int create, const int32_t *source, const int32_t *depth,
+                                                         const int8_t *caustic, const unsigned long long *stacks, int track_only_caustic,
+                                                         double *io, uint8_t *kind, uint32_t *draws, EmitCounters *ctr) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const ScanSrc<T> G = global_scan_src<T>(S);
+  const unsigned long long stream = first_stream + i;
+  RngStream rng;
+  rng.init(C.seed, (uint32_t)domain, (uint32_t)stream, (uint32_t)(stream >> 32), first_draw ? first_draw[i] : 0u);
+  double *r = io + (size_t)i * RT_REC_STRIDE;
+  PhotonState<T> ph;
+  unsigned long long segments = 0, errors = 0, overflows = 0;
+  if (create) {
+    create_photon<T>(S, T(C.epsilon), rng, ph, source ? source[i] : -1);
+    r[0] = (double)ph.o.x; r[1] = (double)ph.o.y; r[2] = (double)ph.o.z; r[3] = (double)ph.d.x; r[4] = (double)ph.d.y; r[5] = (double)ph.d.z;
+    r[6] = (double)ph.power; r[7] = (double)ph.r; r[8] = (double)ph.g; r[9] = (double)ph.b; r[10] = (double)ph.a;
+  } else {
+    ph.o = mk<T>(T(r[0]), T(r[1]), T(r[2])); ph.d = mk<T>(T(r[3]), T(r[4]), T(r[5]));
+    ph.power = T(r[6]); ph.r = T(r[7]); ph.g = T(r[8]); ph.b = T(r[9]); ph.a = T(r[10]);
+    ph.caustic = caustic ? (int)caustic[i] : -1;
+    MatStack st; st.init();
+    if (stacks) st.bits = stacks[i];
+    T rec[RT_REC_STRIDE];
+    const int stored = photon_walk<T>(S, G, C, rng, ph, st, depth ? depth[i] : 0, track_only_caustic != 0, rec, segments, errors, overflows);
+    kind[i] = (uint8_t)stored;
+    if (stored) for (int c = 0; c < RT_REC_STRIDE; c++) r[c] = (double)rec[c];
+    if (segments) atomicAdd(&ctr->segments, segments);
+    if (errors) atomicAdd(&ctr->errors, errors);
+    if (overflows) atomicAdd(&ctr->overflows, overflows);
+  }
+  if (draws) draws[i] = rng.draw;
 }
 
 // ---- ordered compaction: count per block -> scan of block counts -> scatter ----

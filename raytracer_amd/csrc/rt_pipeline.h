@@ -14,6 +14,15 @@ template <typename T> int pl_intersect_scene(rt_scene *sc, const rt_params *p, i
                                              const double *d, const double *source_dist, double *t_out, int32_t *idx_out);
 template <typename T> int pl_trace_tile(rt_scene *sc, int slot, const rt_params *p, DevMap md, DevMap mc, int x0, int y0, int w, int h,
                                         double *pre, double *post, uint8_t *rgba8, rt_trace_stats *stats);
+// explicit rays / points / photons, one lane each (the host's Scene.traceRay, directLight, createPhoton, emitPhoton)
+template <typename T> int pl_trace_rays(rt_scene *sc, const rt_params *p, DevMap md, DevMap mc, uint32_t n, const double *o, const double *d,
+                                        const double *max_dist, const int32_t *depth, const double *importance, const uint64_t *stacks,
+                                        uint32_t first_stream, const uint32_t *first_draw, double *rgba, rt_trace_stats *stats);
+template <typename T> int pl_direct_light(rt_scene *sc, const rt_params *p, uint32_t n, const double *point, const double *normal, const double *local,
+                                          uint32_t first_stream, const uint32_t *first_draw, double *rgb, uint32_t *draws);
+template <typename T> int pl_photons_explicit(rt_scene *sc, const rt_params *p, uint32_t n, int domain, uint64_t first_stream, const uint32_t *first_draw,
+                                              int create, const int32_t *source, const int32_t *depth, const int8_t *caustic, const uint64_t *stacks,
+                                              int track_only_caustic, double *io, uint8_t *kind, uint32_t *draws);
 // runs attempts [a0, a0+count) of one phase into the scene's emission workspace
 template <typename T> int pl_emit_batch(rt_scene *sc, const rt_params *p, int phase, uint64_t a0, uint32_t count);
 // ordered compaction of the workspace: records whose kind matches `want` (0 = any stored) go to

@@ -304,6 +304,129 @@ int pl_trace_tile(rt_scene *sc, int slot, const rt_params *p, DevMap md, DevMap 
   return trace_tile_mode<T, false, false>(sc, slot, p, md, mc, x0, y0, w, h, pre, post, rgba8, stats);
 }
 
+// ------------------------------------------------------------------ explicit rays, points and photons
+// Scene.traceRay(ray, maxDist, depth, importance, materialStack) (rayphoton.js:1626-1838) for n explicit rays, one lane
+// each from the ray's first hit to the end of its path.  Ray i draws from stream (seed, RENDER, C.x0 + i, 0) -- the
+// stream of pixel (C.x0 + i) % width of row (C.x0 + i) / width in a frame of the same seed -- starting at draw
+// first_draw[i].  The call sites of the reference hand it unit directions (Ray's constructor normalises).
+template <typename T, bool FULL>
+__global__ void __launch_bounds__(64) k_trace_rays(DevScene<T> S, TraceCfg C, DevMap Md, DevMap Mc, uint32_t n, const double *o, const double *d,
+                                                   const double *max_dist, const int32_t *depth, const double *importance,
+                                                   const unsigned long long *stacks, const uint32_t *first_draw, double *rgba, TraceCounters *ctr) {
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  ShadeTally tally;
+  unsigned long long rays = 0;
+  if (p < n) {
+    const ScanSrc<T> G = global_scan_src<T>(S);
+    PathState<T> st;
+    st.o = mk<T>(T(o[3 * p]), T(o[3 * p + 1]), T(o[3 * p + 2])); st.d = mk<T>(T(d[3 * p]), T(d[3 * p + 1]), T(d[3 * p + 2]));
+    st.max_dist = max_dist ? T(max_dist[p]) : T(C.max_trace_dist);
+    st.importance = importance ? T(importance[p]) : T(1);
+    st.acc = mk<T>(0, 0, 0);
+    st.draw = first_draw ? first_draw[p] : 0u; st.depth = depth ? depth[p] & 0xFFFF : 0; st.blk_idx = 0xFFFFFFFFu;
+    MatStack ms; ms.init();
+    st.stack = stacks ? stacks[p] : ms.bits;
+    T o4[4] = { T(0), T(0), T(0), T(0) };                    // COL_BLACK: what a ray of importance < 0.01 returns (:1627)
+    if (!(st.importance < T(0.01))) {
+      for (int bounce = 0; bounce < C.max_bounces; bounce++) {
+        T t; rays++;
+        const int idx = scan_scene<T, 0>(S, G, st.o, st.d, T(C.epsilon), T(0), t, &tally.tests);
+        if (!shade_body<T, FULL>(S, G, C, Md, Mc, p, st, t, idx, bounce, o4, tally)) break;
+      }
+    }
+    for (int c = 0; c < 4; c++) rgba[4 * (size_t)p + c] = (double)o4[c];
+  }
+  for (int off = 32; off > 0; off >>= 1) rays += __shfl_down(rays, off, 64);
+  if ((threadIdx.x & 63) == 0 && rays) atomicAdd(&ctr->tail_rays[blockIdx.x % RT_CTR_SLOTS], rays);
+  flush_tally(tally, ctr);
+}
+
+template <typename T>
+int pl_trace_rays(rt_scene *sc, const rt_params *p, DevMap md, DevMap mc, uint32_t n, const double *o, const double *d, const double *max_dist,
+                  const int32_t *depth, const double *importance, const uint64_t *stacks, uint32_t first_stream, const uint32_t *first_draw,
+                  double *rgba, rt_trace_stats *stats) {
+  rt_ctx *ctx = sc->ctx;
+  DevScene<T> &S = SceneOf<T>::get(sc);
+  rt_scene::TraceWs &W = sc->tws[0];
+  RT_HIP(ctx, W.ctr.reserve(sizeof(TraceCounters)));
+  TraceCounters *ctr = W.ctr.as<TraceCounters>();
+  RT_HIP(ctx, hipMemsetAsync(ctr, 0, sizeof(TraceCounters), ctx->stream));
+  TraceCfg C = {};
+  C.epsilon = working_eps<T>(p); C.max_trace_dist = p->max_trace_dist; C.diffuse_radius = p->diffuse_radius;
+  C.caustic_radius = p->caustic_radius; C.standard_lamp_area = p->standard_lamp_area;
+  C.shadow_bias = p->shadow_bias > 0 ? p->shadow_bias : C.epsilon;
+  C.max_depth = p->max_depth; C.sub_sample = 1; C.use_direct_light = p->use_direct_light;
+  C.use_photon_maps = p->use_photon_maps; C.max_bounces = p->max_bounces > 0 ? p->max_bounces : 4096;
+  C.seed = p->seed; C.block = 1; C.n_paths = n;
+  // one row of n "pixels" starting at column first_stream: path i then keys its stream with first_stream + i
+  C.x0 = (int32_t)first_stream; C.y0 = 0; C.w = (int32_t)n; C.h = 1;
+  C.magic_w = (uint32_t)(0x100000000ull / (uint64_t)n); C.magic_ss = 0; C.magic_s = 0;
+  if (!p->use_photon_maps) { md.n = 0; mc.n = 0; }
+  const bool full = p->use_direct_light || (p->use_photon_maps && (md.n || mc.n));
+  if (full) RT_LAUNCH(ctx, "trace_rays", (k_trace_rays<T, true>), div_up(n, 64), 64, S, C, md, mc, n, o, d, max_dist, depth, importance,
+                      (const unsigned long long *)stacks, first_draw, rgba, ctr);
+  else RT_LAUNCH(ctx, "trace_rays", (k_trace_rays<T, false>), div_up(n, 64), 64, S, C, md, mc, n, o, d, max_dist, depth, importance,
+                 (const unsigned long long *)stacks, first_draw, rgba, ctr);
+  RT_HIP(ctx, hipGetLastError());
+  if (stats) {
+    TraceCounters hc;
+    RT_HIP(ctx, hipMemcpyAsync(&hc, ctr, sizeof(hc), hipMemcpyDeviceToHost, ctx->stream));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *stats = rt_trace_stats{};
+    for (int k = 0; k < RT_CTR_SLOTS; k++) stats->rays += hc.tail_rays[k];
+    stats->shadow_rays = hc.shadow_rays; stats->gathers = hc.gathers; stats->stack_overflows = hc.stack_overflows;
+  }
+  return RT_OK;
+}
+
+// Scene.directLight(point, normal, localColour) (rayphoton.js:1841-1880) for n points; point i draws from stream
+// (seed, RENDER, first_stream + i, 0) starting at first_draw[i].
+template <typename T>
+__global__ void __launch_bounds__(64) k_direct_light_points(DevScene<T> S, TraceCfg C, uint32_t n, const double *point, const double *normal,
+                                                            const double *local, unsigned long long first_stream, const uint32_t *first_draw,
+                                                            double *rgb, uint32_t *draws) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const ScanSrc<T> G = global_scan_src<T>(S);
+  RngStream rng;
+  rng.init(C.seed, RT_DOMAIN_RENDER, (uint32_t)(first_stream + i), 0u, first_draw ? first_draw[i] : 0u);
+  unsigned long long shadow = 0; uint32_t tests = 0;
+  const V3<T> c = direct_light<T>(S, G, C, mk<T>(T(point[3 * i]), T(point[3 * i + 1]), T(point[3 * i + 2])),
+                                  mk<T>(T(normal[3 * i]), T(normal[3 * i + 1]), T(normal[3 * i + 2])),
+                                  mk<T>(T(local[3 * i]), T(local[3 * i + 1]), T(local[3 * i + 2])), rng, shadow, &tests);
+  rgb[3 * (size_t)i] = (double)c.x; rgb[3 * (size_t)i + 1] = (double)c.y; rgb[3 * (size_t)i + 2] = (double)c.z;
+  if (draws) draws[i] = rng.draw;
+}
+
+template <typename T>
+int pl_direct_light(rt_scene *sc, const rt_params *p, uint32_t n, const double *point, const double *normal, const double *local,
+                    uint32_t first_stream, const uint32_t *first_draw, double *rgb, uint32_t *draws) {
+  rt_ctx *ctx = sc->ctx;
+  DevScene<T> &S = SceneOf<T>::get(sc);
+  TraceCfg C = {};
+  C.epsilon = working_eps<T>(p); C.standard_lamp_area = p->standard_lamp_area; C.seed = p->seed;
+  RT_LAUNCH(ctx, "direct_light_points", k_direct_light_points<T>, div_up(n, 64), 64, S, C, n, point, normal, local, (unsigned long long)first_stream,
+            first_draw, rgb, draws);
+  RT_HIP(ctx, hipGetLastError());
+  return RT_OK;
+}
+
+// createPhoton / emitPhoton for explicit photons (k_photons_explicit, rt_emit.h)
+template <typename T>
+int pl_photons_explicit(rt_scene *sc, const rt_params *p, uint32_t n, int domain, uint64_t first_stream, const uint32_t *first_draw, int create,
+                        const int32_t *source, const int32_t *depth, const int8_t *caustic, const uint64_t *stacks, int track_only_caustic,
+                        double *io, uint8_t *kind, uint32_t *draws) {
+  rt_ctx *ctx = sc->ctx;
+  DevScene<T> &S = SceneOf<T>::get(sc);
+  if (!sc->ws_misc.p) { RT_HIP(ctx, sc->ws_misc.alloc(256)); RT_HIP(ctx, hipMemsetAsync(sc->ws_misc.p, 0, 256, ctx->stream)); }
+  EmitCfg C; C.epsilon = working_eps<T>(p); C.max_depth = p->max_depth; C.num_diffuse = p->num_photons_diffuse;
+  C.num_caustic = p->num_photons_caustic; C.seed = p->seed;
+  RT_LAUNCH(ctx, "photons_explicit", k_photons_explicit<T>, div_up(n, 64), 64, S, C, n, domain, (unsigned long long)first_stream, first_draw, create,
+            source, depth, caustic, (const unsigned long long *)stacks, track_only_caustic, io, kind, draws, sc->ws_misc.as<EmitCounters>());
+  RT_HIP(ctx, hipGetLastError());
+  return RT_OK;
+}
+
 // ------------------------------------------------------------------ emission
 template <typename T>
 int pl_emit_batch(rt_scene *sc, const rt_params *p, int phase, uint64_t a0, uint32_t count) {
@@ -370,6 +493,12 @@ int pl_emit_shard(rt_scene *sc, uint32_t count, int format, uint32_t tag_offset,
                                      const double *, double *, int32_t *);                                             \
   template int pl_trace_tile<T>(rt_scene *, int, const rt_params *, DevMap, DevMap, int, int, int, int, double *, double *, \
                                 uint8_t *, rt_trace_stats *);                                                          \
+  template int pl_trace_rays<T>(rt_scene *, const rt_params *, DevMap, DevMap, uint32_t, const double *, const double *, const double *, \
+                                const int32_t *, const double *, const uint64_t *, uint32_t, const uint32_t *, double *, rt_trace_stats *); \
+  template int pl_direct_light<T>(rt_scene *, const rt_params *, uint32_t, const double *, const double *, const double *, uint32_t, \
+                                  const uint32_t *, double *, uint32_t *);                                             \
+  template int pl_photons_explicit<T>(rt_scene *, const rt_params *, uint32_t, int, uint64_t, const uint32_t *, int, const int32_t *, \
+                                      const int32_t *, const int8_t *, const uint64_t *, int, double *, uint8_t *, uint32_t *); \
   template int pl_emit_batch<T>(rt_scene *, const rt_params *, int, uint64_t, uint32_t);                               \
   template int pl_emit_shard<T>(rt_scene *, uint32_t, int, uint32_t, uint32_t, uint32_t *, uint32_t *);                \
   template int pl_emit_compact<T>(rt_scene *, uint32_t, int, uint64_t, uint32_t, uint32_t, double *, int64_t *,        \

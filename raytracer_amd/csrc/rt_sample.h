@@ -39,13 +39,14 @@ template <typename T> struct PhotonState {
   int caustic;      // -1 undefined, 0 false, 1 true (rayphoton.js:652)
 };
 
-// createPhoton() with no argument: light chosen by walking the cumulative probabilities.
-// Always 5 draws.  Returns the light index (clamped where the reference would run off the
-// end of the list and throw).
-template <typename T> RT_D int create_photon(const DevScene<T> &S, T eps, RngStream &rng, PhotonState<T> &ph) {
+// createPhoton(source) (rayphoton.js:1326-1344): without a source (< 0) the light is chosen by walking the cumulative
+// probabilities; the draw for that choice is made either way.  Always 5 draws.  Returns the light index (clamped
+// where the reference would run off the end of the list and throw).
+template <typename T> RT_D int create_photon(const DevScene<T> &S, T eps, RngStream &rng, PhotonState<T> &ph, int source = -1) {
   T r = rng.next<T>();
   uint32_t l = 0;
-  while (l < S.n_lights && r > S.light_data[l][2]) { r -= S.light_data[l][2]; l++; }
+  if (source >= 0) l = (uint32_t)source;
+  else while (l < S.n_lights && r > S.light_data[l][2]) { r -= S.light_data[l][2]; l++; }
   if (l >= S.n_lights) l = S.n_lights - 1;
   const T *lg = S.geom + (size_t)S.light_shape[l] * RT_GEOM_STRIDE;
   V3<T> centre = ld3(lg), nrm = ld3(lg + 3);

@@ -221,6 +221,72 @@ class Scene {
     return addon().traceTile(this._scene(), Object.assign({}, this.params, overrides || {}), md, mc, x0, y0, w, h);
   }
 
+  // ---- the reference's single-item methods: batches of one on the GPU entry points that take explicit items.
+  // The reference draws from Math.random(); here every call names a keyed stream and a position in it: `stream` is
+  // {id, draw} (id: a pixel's y * width + x for rays and points, an attempt number for photons), by default the next
+  // id of a counter of the scene and draw 0.  The stream's position after the call is left in scene.lastDraw where
+  // the entry point reports it.
+  _nextStream() { this._streamCounter = (this._streamCounter || 0) + 1; return 0x40000000 + this._streamCounter; }
+  static _stackBytes(materialStack) {
+    const st = materialStack || [S.MAT.AIR], out = new Uint8Array(16);
+    out[0] = st.length; out.set(st, 1);
+    return out;
+  }
+  _maps() {
+    return [this.photonKdTDiffuse instanceof KdTree ? this.photonKdTDiffuse.map : null, this.photonKdTCaustic instanceof KdTree ? this.photonKdTCaustic.map : null];
+  }
+
+  // traceRay(ray, maxDist, depth, importance, materialStack) (rayphoton.js:1626-1838) -> {r, g, b, a}
+  traceRay(ray, maxDist, depth, importance, materialStack, stream) {
+    const [md, mc] = this._maps();
+    const st = stream || { id: this._nextStream(), draw: 0 };
+    const c = addon().traceRays(this._scene(), this.params, md, mc, Float64Array.from(ray.origin.slice(0, 3)), Float64Array.from(ray.dir), {
+      maxDist: Float64Array.of(maxDist === undefined ? this.params.maxTraceDist : maxDist), depth: Int32Array.of(depth || 0),
+      importance: Float64Array.of(importance === undefined ? 1 : importance), stacks: Scene._stackBytes(materialStack),
+      firstStream: st.id, firstDraw: Uint32Array.of(st.draw || 0) });
+    return { r: c[0], g: c[1], b: c[2], a: Number.isNaN(c[3]) ? undefined : c[3] };
+  }
+
+  // directLight(point, normal, localColour) (rayphoton.js:1841-1880) -> {r, g, b, a: 1}
+  directLight(point, normal, localColour, stream) {
+    const st = stream || { id: this._nextStream(), draw: 0 };
+    const res = addon().directLight(this._scene(), this.params, Float64Array.from(point), Float64Array.from(normal),
+      Float64Array.of(localColour.r, localColour.g, localColour.b), st.id, Uint32Array.of(st.draw || 0));
+    this.lastDraw = res.draws[0];
+    return { r: res.rgb[0], g: res.rgb[1], b: res.rgb[2], a: 1 };
+  }
+
+  // createPhoton(source) (rayphoton.js:1326-1344): a photon leaving a light -- light number `source`, or one chosen by
+  // intensity.  The photon remembers its stream so that emitPhoton(photon) carries on where createPhoton stopped: the
+  // two calls together are one emission attempt (stream.id = the attempt, stream.phase = 1 or 2).
+  createPhoton(source, stream) {
+    const st = stream || { id: this._nextStream(), phase: 1 };
+    const res = addon().createPhotons(this._scene(), this.params, 1, st.phase || 1, st.id, source === undefined ? null : Int32Array.of(source));
+    const p = recordsToPhotons(res.photons, undefined)[0];
+    p.stream = { id: st.id, phase: st.phase || 1, draw: res.draws[0] };
+    return p;
+  }
+
+  // emitPhoton(photon, depth, trackOnlyCaustic, materialStack) (rayphoton.js:1461-1557): follows the photon to its end;
+  // what the reference would hand to storePhoton goes to this.storePhoton.  Returns the stored photon, if any.
+  emitPhoton(photon, depth, trackOnlyCaustic, materialStack) {
+    const st = photon.stream || { id: this._nextStream(), phase: trackOnlyCaustic ? 2 : 1, draw: 0 };
+    const res = addon().walkPhotons(this._scene(), this.params, photonsToRecords([photon]), st.phase || 1, st.id, {
+      firstDraw: Uint32Array.of(st.draw || 0), depth: Int32Array.of(depth || 0),
+      caustic: Int8Array.of(photon.isCaustic === undefined ? -1 : (photon.isCaustic ? 1 : 0)),
+      stacks: Scene._stackBytes(materialStack), trackOnlyCaustic: trackOnlyCaustic ? 1 : 0 });
+    if (!res.kind[0]) return undefined;
+    const stored = recordsToPhotons(res.photons, res.kind[0] === 2)[0];
+    this.storePhoton(stored);
+    return stored;
+  }
+
+  // storePhoton (rayphoton.js:1346-1352): the two lists, each up to its cap
+  storePhoton(photon) {
+    if (photon.isCaustic) { if (this.photonListCaustic.length < this.params.numPhotonsCaustic) this.photonListCaustic.push(photon); }
+    else if (this.photonListDiffuse.length < this.params.numPhotonsDiffuse) this.photonListDiffuse.push(photon);
+  }
+
   // traceTile / traceOnCanvas (rayphoton.js:1573-1624) at superSampleScale 0: one launch per tile,
   // then the same fillStyle / fillRect calls per pixel that putPixel makes (:1910-1919)
   traceTile(tile, tileSize, superSampleScale) {

@@ -419,6 +419,124 @@ static napi_value TraceTile(napi_env env, napi_callback_info info) {
   return out;
 }
 
+// an optional typed-array property of an options object (absent / null / undefined -> nullptr); sets *bad on a wrong type or length
+static void *opt_typed(napi_env env, napi_value o, const char *name, napi_typedarray_type want, size_t need, bool *bad) {
+  napi_valuetype ot; napi_typeof(env, o, &ot);
+  if (ot != napi_object) return nullptr;
+  bool has = false; napi_has_named_property(env, o, name, &has);
+  if (!has) return nullptr;
+  napi_value v = get_prop(env, o, name); napi_valuetype t; napi_typeof(env, v, &t);
+  if (t == napi_undefined || t == napi_null) return nullptr;
+  size_t n = 0;
+  void *p = prop_typed(env, o, name, want, &n);
+  if (!p || n != need) { *bad = true; return nullptr; }
+  return p;
+}
+static napi_value make_typed(napi_env env, napi_typedarray_type type, size_t n, size_t elem, void **data) {
+  napi_value ab, out;
+  if (napi_create_arraybuffer(env, n * elem, data, &ab) != napi_ok || napi_create_typedarray(env, type, n, ab, 0, &out) != napi_ok) return nullptr;
+  return out;
+}
+
+// traceRays(scene, params, diffuseMap|null, causticMap|null, rayO, rayD, {maxDist, depth, importance, stacks, firstStream, firstDraw}) -> Float64Array(n*4)
+static napi_value TraceRays(napi_env env, napi_callback_info info) {
+  Args a(env, info);
+  SceneBox *sb = a.ext<SceneBox>(0);
+  if (!sb) return nullptr;
+  rt_params p; read_params(env, a.argv[1], &p);
+  MapBox *md = a.ext<MapBox>(2), *mc = a.ext<MapBox>(3);
+  { bool pending = false; napi_is_exception_pending(env, &pending); if (pending) return nullptr; }
+  if ((md && md->cb != sb->cb) || (mc && mc->cb != sb->cb)) { napi_throw_error(env, nullptr, "traceRays: the maps belong to another context"); return nullptr; }
+  size_t no = 0, nd = 0;
+  const double *o = (const double *)a.typed(4, napi_float64_array, &no), *d = (const double *)a.typed(5, napi_float64_array, &nd);
+  if (!o || !d || no != nd || no % 3) { napi_throw_range_error(env, nullptr, "traceRays: rayO and rayD must be Float64Arrays of n*3 values"); return nullptr; }
+  const uint32_t n = (uint32_t)(no / 3);
+  napi_value opt = a.has(6) ? a.argv[6] : nullptr;
+  bool bad = false;
+  const double *maxd = opt ? (const double *)opt_typed(env, opt, "maxDist", napi_float64_array, n, &bad) : nullptr;
+  const int32_t *depth = opt ? (const int32_t *)opt_typed(env, opt, "depth", napi_int32_array, n, &bad) : nullptr;
+  const double *imp = opt ? (const double *)opt_typed(env, opt, "importance", napi_float64_array, n, &bad) : nullptr;
+  const uint8_t *stacks = opt ? (const uint8_t *)opt_typed(env, opt, "stacks", napi_uint8_array, (size_t)n * 16, &bad) : nullptr;
+  const uint32_t *fd = opt ? (const uint32_t *)opt_typed(env, opt, "firstDraw", napi_uint32_array, n, &bad) : nullptr;
+  if (bad) { napi_throw_range_error(env, nullptr, "traceRays: an option array has the wrong type or length"); return nullptr; }
+  const uint32_t first = opt ? (uint32_t)prop_num(env, opt, "firstStream", 0) : 0;
+  void *data; napi_value out = make_typed(env, napi_float64_array, (size_t)n * 4, 8, &data);
+  if (!out) { napi_throw_error(env, nullptr, "N-API call failed: typed array"); return nullptr; }
+  if (n == 0) return out;
+  int rc = rt_trace_rays(sb->scene, &p, md ? md->map : nullptr, mc ? mc->map : nullptr, n, o, d, maxd, depth, imp, stacks, first, fd, (double *)data, nullptr);
+  if (rc != RT_OK) return fail(env, sb->cb->ctx, rc);
+  return out;
+}
+
+// directLight(scene, params, points, normals, localRgb, firstStream, firstDraw|null) -> {rgb: Float64Array(n*3), draws: Uint32Array(n)}
+static napi_value DirectLight(napi_env env, napi_callback_info info) {
+  Args a(env, info);
+  SceneBox *sb = a.ext<SceneBox>(0);
+  if (!sb) return nullptr;
+  rt_params p; read_params(env, a.argv[1], &p);
+  size_t np_ = 0, nn = 0, nl = 0, nf = 0;
+  const double *pt = (const double *)a.typed(2, napi_float64_array, &np_), *nr = (const double *)a.typed(3, napi_float64_array, &nn);
+  const double *lc = (const double *)a.typed(4, napi_float64_array, &nl);
+  const uint32_t *fd = (const uint32_t *)a.typed(6, napi_uint32_array, &nf);
+  if (!pt || !nr || !lc || np_ != nn || np_ != nl || np_ % 3 || (fd && nf != np_ / 3)) { napi_throw_range_error(env, nullptr, "directLight: array sizes disagree"); return nullptr; }
+  const uint32_t n = (uint32_t)(np_ / 3);
+  void *rd, *dd; napi_value rgb = make_typed(env, napi_float64_array, (size_t)n * 3, 8, &rd), draws = make_typed(env, napi_uint32_array, n, 4, &dd), out;
+  if (!rgb || !draws) { napi_throw_error(env, nullptr, "N-API call failed: typed array"); return nullptr; }
+  if (n) { int rc = rt_direct_light(sb->scene, &p, n, pt, nr, lc, (uint32_t)a.num(5, 0), fd, (double *)rd, (uint32_t *)dd); if (rc != RT_OK) return fail(env, sb->cb->ctx, rc); }
+  NAPI_OK(napi_create_object(env, &out));
+  napi_set_named_property(env, out, "rgb", rgb); napi_set_named_property(env, out, "draws", draws);
+  return out;
+}
+
+// createPhotons(scene, params, n, phase, firstStream, source Int32Array|null) -> {photons: Float64Array(n*11), draws: Uint32Array(n)}
+static napi_value CreatePhotons(napi_env env, napi_callback_info info) {
+  Args a(env, info);
+  SceneBox *sb = a.ext<SceneBox>(0);
+  if (!sb) return nullptr;
+  rt_params p; read_params(env, a.argv[1], &p);
+  const uint32_t n = (uint32_t)a.num(2, 0);
+  size_t ns = 0;
+  const int32_t *src = (const int32_t *)a.typed(5, napi_int32_array, &ns);
+  if (src && ns != n) { napi_throw_range_error(env, nullptr, "createPhotons: source must hold n entries"); return nullptr; }
+  void *pd, *dd; napi_value ph = make_typed(env, napi_float64_array, (size_t)n * 11, 8, &pd), draws = make_typed(env, napi_uint32_array, n, 4, &dd), out;
+  if (!ph || !draws) { napi_throw_error(env, nullptr, "N-API call failed: typed array"); return nullptr; }
+  if (n) { int rc = rt_create_photons(sb->scene, &p, n, (int)a.num(3, 1), (uint64_t)a.num(4, 0), src, (double *)pd, (uint32_t *)dd); if (rc != RT_OK) return fail(env, sb->cb->ctx, rc); }
+  NAPI_OK(napi_create_object(env, &out));
+  napi_set_named_property(env, out, "photons", ph); napi_set_named_property(env, out, "draws", draws);
+  return out;
+}
+
+// walkPhotons(scene, params, photons Float64Array(n*11), phase, firstStream, {firstDraw, depth, caustic, stacks, trackOnlyCaustic})
+//   -> {photons: Float64Array(n*11) (stored records where kind != 0), kind: Uint8Array(n)}
+static napi_value WalkPhotons(napi_env env, napi_callback_info info) {
+  Args a(env, info);
+  SceneBox *sb = a.ext<SceneBox>(0);
+  if (!sb) return nullptr;
+  rt_params p; read_params(env, a.argv[1], &p);
+  size_t n11 = 0;
+  const double *in = (const double *)a.typed(2, napi_float64_array, &n11);
+  if (!in || n11 % 11) { napi_throw_range_error(env, nullptr, "walkPhotons: photons must hold 11 values each"); return nullptr; }
+  const uint32_t n = (uint32_t)(n11 / 11);
+  napi_value opt = a.has(5) ? a.argv[5] : nullptr;
+  bool bad = false;
+  const uint32_t *fd = opt ? (const uint32_t *)opt_typed(env, opt, "firstDraw", napi_uint32_array, n, &bad) : nullptr;
+  const int32_t *depth = opt ? (const int32_t *)opt_typed(env, opt, "depth", napi_int32_array, n, &bad) : nullptr;
+  const int8_t *ca = opt ? (const int8_t *)opt_typed(env, opt, "caustic", napi_int8_array, n, &bad) : nullptr;
+  const uint8_t *stacks = opt ? (const uint8_t *)opt_typed(env, opt, "stacks", napi_uint8_array, (size_t)n * 16, &bad) : nullptr;
+  if (bad) { napi_throw_range_error(env, nullptr, "walkPhotons: an option array has the wrong type or length"); return nullptr; }
+  const int only = opt ? (int)prop_num(env, opt, "trackOnlyCaustic", 0) : 0;
+  void *pd, *kd; napi_value ph = make_typed(env, napi_float64_array, n11, 8, &pd), kind = make_typed(env, napi_uint8_array, n, 1, &kd), out;
+  if (!ph || !kind) { napi_throw_error(env, nullptr, "N-API call failed: typed array"); return nullptr; }
+  if (n) {
+    memcpy(pd, in, n11 * 8);
+    int rc = rt_walk_photons(sb->scene, &p, n, (int)a.num(3, 1), (uint64_t)a.num(4, 0), fd, depth, ca, stacks, only, (double *)pd, (uint8_t *)kd);
+    if (rc != RT_OK) return fail(env, sb->cb->ctx, rc);
+  }
+  NAPI_OK(napi_create_object(env, &out));
+  napi_set_named_property(env, out, "photons", ph); napi_set_named_property(env, out, "kind", kind);
+  return out;
+}
+
 static napi_value FindMedian(napi_env env, napi_callback_info info) {
   Args a(env, info);
   napi_value out; napi_create_uint32(env, rt_find_median((uint32_t)a.num(0, 1)), &out);
@@ -430,6 +548,7 @@ static napi_value ModuleInit(napi_env env, napi_value exports) {
     { "init", Init }, { "shutdown", Shutdown }, { "sceneUpload", SceneUpload }, { "intersectPairs", IntersectPairs }, { "intersect", Intersect },
     { "emitMany", EmitMany }, { "photonMapBuild", PhotonMapBuild }, { "photonMapNodes", PhotonMapNodes },
     { "kdRadius", KdRadius }, { "kdKnn", KdKnn }, { "gatherRadiance", GatherRadiance }, { "gatherRadianceAdaptive", GatherRadianceAdaptive }, { "traceTile", TraceTile },
+    { "traceRays", TraceRays }, { "directLight", DirectLight }, { "createPhotons", CreatePhotons }, { "walkPhotons", WalkPhotons },
     { "findMedian", FindMedian },
   };
   for (const auto &f : fns) {

@@ -168,6 +168,42 @@ check('Scene.traceTile / traceOnCanvas -> fillRect', tileBad <= 2, `${tileBad} p
   fs.unlinkSync(ppm);
 }
 
+// the single-item methods: traceRay on a pixel's camera ray continues that pixel's stream and returns the frame's colour;
+// createPhoton + emitPhoton on an attempt's stream store what the bulk emission stored for that attempt
+{
+  const RNG = require('../rng'), V = require('../vec');
+  const whole = scene.render(0, 0, W, H);
+  const cam = scene.camera;
+  let badRay = 0;
+  for (const [X, Y] of [[0, 0], [160, 120], [77, 201], [319, 239], [200, 60]]) {
+    const s = new RNG.Stream(12345, RNG.DOMAIN.RENDER, Y * W + X, 0);
+    let u = ((X + (0 + s.next()) / 1) * 2 / W) - 1, v = -(((Y + (0 + s.next()) / 1) * 2 / H) - 1);
+    u *= cam.fovScaleWidth; v *= cam.fovScaleHeight;
+    const xyz = cam.toXYZ([u, v, -1]);
+    const c = scene.traceRay(new rt.Ray(cam.origin, V.sub(xyz, cam.origin)), scene.params.maxTraceDist, 0, 1, [rt.MAT.AIR], { id: Y * W + X, draw: 2 });
+    const o = (Y * W + X) * 4;
+    if (!same(c.r, whole.pre[o]) || !same(c.g, whole.pre[o + 1]) || !same(c.b, whole.pre[o + 2]) || !same(c.a === undefined ? NaN : c.a, whole.pre[o + 3])) badRay++;
+  }
+  check('Scene.traceRay continues a pixel of the frame', badRay === 0, `${badRay} of 5 differ`);
+  const black = scene.traceRay(new rt.Ray(cam.origin, [0, 1, 0]), 20, 0, 0.001, [rt.MAT.AIR]);
+  check('Scene.traceRay importance cut', black.r === 0 && black.a === 0);
+  const dl = scene.directLight([0, 0, 0.01], [0, 0, 1], { r: 255, g: 255, b: 255 }, { id: 777, draw: 0 });
+  check('Scene.directLight', Number.isInteger(dl.r) && dl.a === 1 && scene.lastDraw === 5 * scene.lights.length, `rgb ${dl.r},${dl.g},${dl.b}`);
+  // attempts 0 .. 39 of phase 1, one createPhoton + emitPhoton each (the lists are full: make room for what they store)
+  scene.params.numPhotonsDiffuse += 8; scene.params.numPhotonsCaustic += 8;
+  let okWalk = true, storedN = 0;
+  for (let a = 0; a < 40; a++) {
+    const ph = scene.createPhoton(undefined, { id: a, phase: 1 });
+    okWalk = okWalk && ph.stream.draw === 5 && ph.isCaustic === undefined;
+    if (scene.emitPhoton(ph, 0, false, [rt.MAT.AIR])) storedN++;
+  }
+  scene.params.numPhotonsDiffuse -= 8; scene.params.numPhotonsCaustic -= 8;
+  check('Scene.createPhoton / emitPhoton / storePhoton', okWalk && storedN > 0 && storedN <= 40, `${storedN} of 40 attempts stored a photon`);
+  const lamp1 = scene.shapes[scene.lights[1]];
+  const fromLamp = scene.createPhoton(1);
+  check('Scene.createPhoton(source)', V.len(V.sub(fromLamp.origin, lamp1.centre)) <= lamp1.radius + 1e-12 && fromLamp.power === lamp1.wattage);
+}
+
 // handles: wrong kinds and inconsistent flat scenes are rejected before the C ABI sees them; after shutdown(ctx) the
 // scenes and maps made from the context are dead (a call throws, a late finaliser frees nothing twice)
 {

@@ -352,6 +352,115 @@ def test_image_c1_f64_matches_reference(rt):
     assert st["rays"] == 110353 and st["stack_overflows"] == 0       # traceRay calls that scan, counted by the oracle
 
 
+# ------------------------------------------------------------------ the scene's single-item methods, batched
+def _camera_rays(flat, seed, W, H, Y):
+    """the camera rays of row Y as traceOnCanvas builds them (rayphoton.js:1589-1609), fp64, draws 0 and 1 of each pixel's stream"""
+    cam = np.asarray(flat.camera, np.float64)
+    co, cu, cv, cw = cam[0:3], cam[3:6], cam[6:9], cam[9:12]
+    o = np.tile(co, (W, 1))
+    d = np.empty((W, 3))
+    for X in range(W):
+        a = Y * W + X
+        u0, u1 = ora.uniform(seed, 0, a, 0, 0), ora.uniform(seed, 0, a, 0, 1)
+        u = ((X + (0 + u0) / 1) * 2 / W) - 1
+        v = -(((Y + (0 + u1) / 1) * 2 / H) - 1)
+        u *= cam[12]
+        v *= cam[13]
+        xyz = ((co + u * cu) + v * cv) + (-1.0) * cw
+        dv = xyz - co
+        s2 = dv[0] * dv[0] + dv[1] * dv[1] + dv[2] * dv[2]
+        d[X] = (1.0 / np.sqrt(s2)) * dv
+    return o, d
+
+
+def test_trace_rays_continue_the_pixels_of_a_frame(rt):
+    """rt_trace_rays on the camera rays of a frame's rows, keyed with the pixels' streams from draw 2, returns the
+    frame's own colours bit for bit (fp64; direct light and both photon maps on)"""
+    capi, ctx = rt
+    g = load_bundle("image_c1_modeB")
+    W, H = g.meta["W"], g.meta["H"]
+    ph = load_bundle("photons_c1")
+    flat = load_scene(10, W, H)
+    sc = ctx.upload(flat)
+    md, mc = ctx.photon_map(ph["diffuse"]), ctx.photon_map(ph["caustic"])
+    p = capi.default_params(precision=capi.PRECISION_F64, num_photons_diffuse=10000, num_photons_caustic=10000, seed=SEED)
+    frame = sc.trace_tile(p, md, mc)
+    rays = 0
+    for Y in (0, 97, 151, H - 1):
+        o, d = _camera_rays(flat, SEED, W, H, Y)
+        got, st = sc.trace_rays(p, o, d, md, mc, first_stream=Y * W, first_draw=np.full(W, 2, np.uint32), stats=True)
+        assert same(got, frame["pre"][Y]), Y
+        rays += st["rays"]
+    assert rays > 4 * W
+    # the arguments traceRay takes: a ray of importance below 0.01 is black with alpha 0 (:1627); a short maxDist at the
+    # depth limit ends the path at its first hit (:1677); an explicit [MAT_AIR] stack is the default
+    o, d = _camera_rays(flat, SEED, W, H, 97)
+    got = sc.trace_rays(p, o[:8], d[:8], md, mc, importance=np.full(8, 0.005), first_stream=97 * W, first_draw=np.full(8, 2, np.uint32))
+    assert np.array_equal(got, np.zeros((8, 4)))
+    base = sc.trace_rays(p, o, d, md, mc, first_stream=97 * W, first_draw=np.full(W, 2, np.uint32))
+    again = sc.trace_rays(p, o, d, md, mc, stacks=[[0]] * W, max_dist=np.full(W, p.max_trace_dist), depth=np.zeros(W, np.int32),
+                          importance=np.ones(W), first_stream=97 * W, first_draw=np.full(W, 2, np.uint32))
+    assert same(again, base)
+    cut, st_cut = sc.trace_rays(p, o, d, md, mc, max_dist=np.zeros(W), depth=np.full(W, p.max_depth, np.int32), first_stream=97 * W,
+                                first_draw=np.full(W, 2, np.uint32), stats=True)
+    assert st_cut["rays"] == W and not same(cut, base)
+    with pytest.raises(capi.RtError):
+        sc.trace_rays(p, o[:2], d[:2], stacks=[[0], [9]])
+
+
+def test_direct_light_points_match_the_oracle(rt):
+    capi, ctx = rt
+    flat = load_scene(10, 320, 240)
+    sc, osc = ctx.upload(flat), ora.Scene(flat)
+    p = capi.default_params(precision=capi.PRECISION_F64, seed=SEED)
+    op = ora.params(seed=SEED)
+    rng = np.random.default_rng(8)
+    n = 200
+    pts = np.column_stack([rng.uniform(-6, 9, n), rng.uniform(-8, 9, n), rng.uniform(0.01, 9, n)])
+    nrm = rng.normal(size=(n, 3))
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    nrm[: n // 2] = [0, 0, 1]
+    local = rng.uniform(0, 255, (n, 3))
+    first_draw = rng.integers(0, 9, n).astype(np.uint32)
+    got, draws = sc.direct_light(p, pts, nrm, local, first_stream=5000, first_draw=first_draw)
+    lit = 0
+    for i in range(n):
+        exp, dr = ora.direct_light(osc, op, 0, 5000 + i, 0, int(first_draw[i]), pts[i], nrm[i], local[i])
+        assert same(got[i], exp), i
+        assert draws[i] == dr == first_draw[i] + 5 * flat.n_lights
+        lit += bool(np.any(exp != 0))
+    assert lit > n // 10
+
+
+def test_create_and_walk_photons_are_the_attempts_of_the_bulk_emission(rt):
+    """createPhoton then emitPhoton, photon by photon, store what rt_emit_photons stores for the same attempts"""
+    capi, ctx = rt
+    flat = load_scene(10, 320, 240)
+    sc, osc = ctx.upload(flat), ora.Scene(flat)
+    p = capi.default_params(precision=capi.PRECISION_F64, num_photons_diffuse=10000, num_photons_caustic=10000, seed=SEED)
+    n = 4000
+    for phase in (1, 2):
+        made, draws = sc.create_photons(p, n, phase=phase, first_stream=100)
+        assert np.all(draws == 5)
+        for i in (0, 1, 999):
+            l, exp = ora.create_photon(osc, SEED, phase, 100 + i, 0)
+            assert same(made[i, :7], exp[:7])
+        rec, kind = sc.walk_photons(p, made, phase=phase, first_stream=100, first_draw=draws, track_only_caustic=(phase == 2))
+        bulk_rec, bulk_att, bulk_kind, _ = sc.emit_photons(p, phase, 100, 100 + n)
+        stored = np.nonzero(kind)[0]
+        assert np.array_equal(stored + 100, bulk_att) and np.array_equal(kind[stored], bulk_kind)
+        assert same(rec[stored], bulk_rec)
+        assert len(stored) > n // 10
+    # a named source: every photon starts on that light's disc; the draw that would have chosen the light is still made
+    lamp = flat.shape_geom[flat.light_shape[1]]
+    made, draws = sc.create_photons(p, 500, first_stream=0, source=np.ones(500, np.int32))
+    assert np.all(draws == 5)
+    assert np.all(np.linalg.norm(made[:, :3] - lamp[:3], axis=1) <= lamp[6] + 1e-12) and np.all(made[:, 6] == flat.light_data[1][0])
+    # a photon handed over in mid-flight: depth 1 inside glass, already caustic
+    rec2, kind2 = sc.walk_photons(p, made[:64], first_stream=9000, depth=np.ones(64, np.int32), caustic=np.ones(64, np.int8), stacks=[[0, 1]] * 64)
+    assert set(np.unique(kind2)) <= {0, 1, 2}
+
+
 def test_image_c1_f32_within_tolerance(rt):
     capi, ctx = rt
     g = load_bundle("image_c1_modeB")
