@@ -6,7 +6,7 @@ gathers/s on a 1M-photon map, photon emission, the kd-tree build and the other B
   python bench.py --gpus N --steps K --warmup W      (N > 1: launched by torch.distributed.run, one rank per GPU)
 
 A step is one full-frame pass of the hot path.
-  N = 1   every step renders the frame on the one GPU (frames queued back to back, three in flight).
+  N = 1   every step renders the frame on the one GPU (frames queued back to back, two in flight).
   N > 1   ONE job over N ranks, the split of the north star: photon emission sharded by attempt range, the photon
           shards all-gathered from and into device memory (RCCL), the list caps applied and the kd-trees built
           identically on every rank, then every step's frame traced as interleaved row bands, one share per rank,
@@ -211,8 +211,8 @@ def main():
     phases = None
 
     if not split:
-        # ---- frames of config[1] on this rank's GPU, queued back to back, three in flight
-        in_flight = 1 if os.environ.get("RT355_BENCH_SERIAL_FRAMES") else int(os.environ.get("RT355_BENCH_IN_FLIGHT", "3"))
+        # ---- frames of config[1] on this rank's GPU, queued back to back, two in flight
+        in_flight = 1 if os.environ.get("RT355_BENCH_SERIAL_FRAMES") else int(os.environ.get("RT355_BENCH_IN_FLIGHT", "2"))
         frames_out = [torch.empty((H, W, 4), dtype=torch.uint8, device=dev) for _ in range(in_flight)]   # outputs stay in HBM
         frame = frames_out[0]
 
@@ -225,8 +225,9 @@ def main():
             st = step()                         # every step renders the same frame (same seed): its ray count is this one's
         ctx.profile_reset()                     # (the warm-up's timing events go back to the library's pool)
         # the timed frames are only queued (no statistics read back in between) and the clock stops after the library's
-        # streams have drained.  Three frames in flight: consecutive frames rotate through three streams, workspaces and output
-        # buffers, so the thinly occupied end of one frame's path tracing overlaps the start of the next.
+        # streams have drained.  Two frames in flight: consecutive frames alternate between two streams, workspaces and output
+        # buffers, so the thinly occupied end of one frame's path tracing overlaps the start of the next (a third frame in
+        # flight adds 0-6 % and makes every kernel's own duration, which the roofline block reports, half again as long).
         ctx.set_frames_in_flight(in_flight)
         barrier()
         t0 = time.perf_counter()
@@ -507,7 +508,7 @@ def main():
                 "bound": "valu", "achieved": ach, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_VALU_TFLOPS,
                 "traffic": measured_traffic("k_tail"), "algorithmic_flop_per_ray_pass": fl, "avg_launch_ms": t_avg * 1e3,
                 "segments_per_launch": int(tail_rays), "launches_per_step": tail_launches / args.steps,
-                "note": "the timed frames overlap (three frames in flight), so a launch shares the chip with the neighbouring frames' kernels; "
+                "note": "the timed frames overlap (two frames in flight), so a launch shares the chip with the neighbouring frame's kernels; "
                         "`exclusive` has both kernels on frames run one at a time; `frame` is the whole frame against the driver's clock. "
                         "bound 'valu': this path is neither HBM- nor MFMA-bound; peak = fp32 vector FMA rate (the measured sustained v_fma_f32 "
                         "rate on this chip is 106 TFLOP/s, profiles/r02_valu_issue_rate.txt)",

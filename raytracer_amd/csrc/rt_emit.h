@@ -18,82 +18,111 @@ struct EmitCounters { unsigned long long segments, errors, overflows; };
 
 #define RT_REC_STRIDE 11
 
-// emitPhoton (rayphoton.js:1461-1557) as a loop: follows photon `ph` (at recursion depth `depth`, inside the materials of
-// `st`) until it is absorbed, dropped or leaves the scene.  Returns 0 (nothing stored), 1 (a diffuse photon) or 2 (a
-// caustic one) and, when something is stored, writes its record (hit3, -dir3, power / list cap, rgba) to r[0..10].
+// One segment of emitPhoton (rayphoton.js:1461-1557): photon `ph` (at recursion depth `depth`, inside the materials of
+// `st`) is followed to its next hit.  Returns -1 when the photon goes on (ph, st, depth updated), else how it ended:
+// 0 nothing stored (left the scene, dropped, or the reference would have thrown), 1 a diffuse photon stored, 2 a caustic
+// one -- then its record (hit3, -dir3, power / list cap, rgba) is in r[0..10].
+template <typename T>
+RT_D int photon_step(const DevScene<T> &S, const ScanSrc<T> &G, const EmitCfg &C, RngStream &rng, PhotonState<T> &ph, MatStack &st, int &depth,
+                     bool track_only_caustic, T *r, unsigned long long &errors, unsigned long long &overflows) {
+  const T eps = T(C.epsilon);
+  T t;
+  int idx = scan_scene<T, 1>(S, G, ph.o, ph.d, eps, T(0), t);
+  if (idx < 0) return 0;                                                     // left the scene
+  V3<T> hit = ph.o + t * ph.d;
+  V3<T> local = shape_colour<T>(S, idx, hit);
+  V3<T> n = shape_normal<T>(S, idx, hit);
+  const T cos1 = -dot(ph.d, n);
+  const bool has_mat = S.meta[4 * idx + 1] < 8;
+  const int mat = S.meta[4 * idx + 1] & 7;
+  if (has_mat && S.mat[0][mat] == T(1) && depth < C.max_depth) {             // :1484
+    V3<T> ndir; bool ovf = false;
+    if (!fresnel_bounce<T>(S, mat, ph.d, n, cos1, st, rng, ndir, ovf)) { errors++; return 0; }   // :1487-1490 throws
+    if (ovf) overflows++;
+    ph.o = hit; ph.d = normalize<T>(ndir, eps);
+    if (ph.caustic < 0) ph.caustic = 1;
+    depth++;
+    return -1;
+  }
+  // opaque, or transparent at depth >= MAX_DEPTH where reflectance is undefined (never "< U")
+  const bool opaque_mat = has_mat && S.mat[0][mat] != T(1);
+  if (rng.next_k() < (opaque_mat ? S.refl_k[mat] : 0u)) {                    // :1523
+    if (depth < C.max_depth) {
+      if (rng.next_k() < S.spec_k[mat]) {                                    // :1525-1533 specular
+        ph.o = hit; ph.d = normalize<T>(ph.d + (T(2) * cos1) * n, eps);
+        if (ph.caustic < 0) ph.caustic = 1;
+        depth++;
+        return -1;
+      } else if (!track_only_caustic) {                                      // :1536-1546 diffuse
+        V3<T> ndir = vec_perturb<T>(n, eps, rng);
+        T adj = ph.power * T(255 + 255 + 255 + 1) / (local.x + local.y + local.z + T(1));
+        ph.r = ph.r / T(255) * local.x; ph.g = ph.g / T(255) * local.y; ph.b = ph.b / T(255) * local.z; ph.a = T(1);
+        ph.power = adj;
+        ph.o = hit; ph.d = normalize<T>(ndir, eps); ph.caustic = 0;
+        depth++;
+        return -1;
+      }
+    }
+    return 0;                                                                // dropped
+  }
+  if (depth > 0) {                                                           // absorbed: store (:1549-1553)
+    const bool is_c = ph.caustic == 1;
+    T power = ph.power / (is_c ? T(C.num_caustic) : T(C.num_diffuse));
+    V3<T> back = normalize<T>(T(-1) * ph.d, eps);
+    r[0] = hit.x; r[1] = hit.y; r[2] = hit.z; r[3] = back.x; r[4] = back.y; r[5] = back.z;
+    r[6] = power; r[7] = ph.r; r[8] = ph.g; r[9] = ph.b; r[10] = ph.a;
+    return is_c ? 2 : 1;
+  }
+  return 0;
+}
+// the whole walk of one photon
 template <typename T>
 RT_D int photon_walk(const DevScene<T> &S, const ScanSrc<T> &G, const EmitCfg &C, RngStream &rng, PhotonState<T> &ph, MatStack &st, int depth,
                      bool track_only_caustic, T *r, unsigned long long &segments, unsigned long long &errors, unsigned long long &overflows) {
-  const T eps = T(C.epsilon);
   for (;;) {
-    T t; segments++;
-    int idx = scan_scene<T, 1>(S, G, ph.o, ph.d, eps, T(0), t);
-    if (idx < 0) return 0;                                                   // left the scene
-    V3<T> hit = ph.o + t * ph.d;
-    V3<T> local = shape_colour<T>(S, idx, hit);
-    V3<T> n = shape_normal<T>(S, idx, hit);
-    const T cos1 = -dot(ph.d, n);
-    const bool has_mat = S.meta[4 * idx + 1] < 8;
-    const int mat = S.meta[4 * idx + 1] & 7;
-    if (has_mat && S.mat[0][mat] == T(1) && depth < C.max_depth) {           // :1484
-      V3<T> ndir; bool ovf = false;
-      if (!fresnel_bounce<T>(S, mat, ph.d, n, cos1, st, rng, ndir, ovf)) { errors++; return 0; }   // :1487-1490 throws
-      if (ovf) overflows++;
-      ph.o = hit; ph.d = normalize<T>(ndir, eps);
-      if (ph.caustic < 0) ph.caustic = 1;
-      depth++;
-      continue;
-    }
-    // opaque, or transparent at depth >= MAX_DEPTH where reflectance is undefined (never "< U")
-    const bool opaque_mat = has_mat && S.mat[0][mat] != T(1);
-    if (rng.next_k() < (opaque_mat ? S.refl_k[mat] : 0u)) {                  // :1523
-      if (depth < C.max_depth) {
-        if (rng.next_k() < S.spec_k[mat]) {                                  // :1525-1533 specular
-          ph.o = hit; ph.d = normalize<T>(ph.d + (T(2) * cos1) * n, eps);
-          if (ph.caustic < 0) ph.caustic = 1;
-          depth++;
-          continue;
-        } else if (!track_only_caustic) {                                    // :1536-1546 diffuse
-          V3<T> ndir = vec_perturb<T>(n, eps, rng);
-          T adj = ph.power * T(255 + 255 + 255 + 1) / (local.x + local.y + local.z + T(1));
-          ph.r = ph.r / T(255) * local.x; ph.g = ph.g / T(255) * local.y; ph.b = ph.b / T(255) * local.z; ph.a = T(1);
-          ph.power = adj;
-          ph.o = hit; ph.d = normalize<T>(ndir, eps); ph.caustic = 0;
-          depth++;
-          continue;
-        }
-      }
-      return 0;                                                              // dropped
-    }
-    if (depth > 0) {                                                         // absorbed: store (:1549-1553)
-      const bool is_c = ph.caustic == 1;
-      T power = ph.power / (is_c ? T(C.num_caustic) : T(C.num_diffuse));
-      V3<T> back = normalize<T>(T(-1) * ph.d, eps);
-      r[0] = hit.x; r[1] = hit.y; r[2] = hit.z; r[3] = back.x; r[4] = back.y; r[5] = back.z;
-      r[6] = power; r[7] = ph.r; r[8] = ph.g; r[9] = ph.b; r[10] = ph.a;
-      return is_c ? 2 : 1;
-    }
-    return 0;
+    segments++;
+    const int k = photon_step<T>(S, G, C, rng, ph, st, depth, track_only_caustic, r, errors, overflows);
+    if (k >= 0) return k;
   }
 }
 
+// A workgroup takes `per_wg` consecutive attempts.  Walks differ a lot in length (3.6 segments on average, 20 and more
+// for photons caught in glass), so a lane does not idle until the longest walk of its wave is over: a lane whose walk
+// has ended takes the next attempt of its workgroup that nobody has started (a counter in LDS) and joins the others at
+// their next segment.  Which lane runs an attempt does not matter: its stream is keyed by the attempt number and its
+// outputs go to the attempt's own slots.
 template <typename T, bool LDS>
-__global__ void __launch_bounds__(256) k_emit(DevScene<T> S, EmitCfg C, int phase, unsigned long long a0, uint32_t count,
+__global__ void __launch_bounds__(256) k_emit(DevScene<T> S, EmitCfg C, int phase, unsigned long long a0, uint32_t count, uint32_t per_wg,
                                               uint8_t *kind, T *rec, uint8_t *nseg, EmitCounters *ctr) {
   extern __shared__ __align__(16) unsigned char rt_lds[];
+  __shared__ uint32_t next_attempt;
   const ScanSrc<T> G = LDS ? stage_scene_lds<T>(S, rt_lds) : global_scan_src<T>(S);
-  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t wg_first = blockIdx.x * per_wg, wg_end = min(count, wg_first + per_wg);      // (count <= 2^31: no overflow)
+  if (threadIdx.x == 0) next_attempt = wg_first + blockDim.x;
+  __syncthreads();
   unsigned long long segments = 0, errors = 0, overflows = 0;
-  if (i < count) {
-    const unsigned long long attempt = a0 + i;
-    const T eps = T(C.epsilon);
-    RngStream rng;
+  const T eps = T(C.epsilon);
+  uint32_t i = wg_first + threadIdx.x;
+  RngStream rng; PhotonState<T> ph; MatStack st; int depth = 0; uint32_t my_segments = 0;
+  auto start = [&](uint32_t attempt_i) {
+    const unsigned long long attempt = a0 + attempt_i;
     rng.init(C.seed, phase == 1 ? RT_DOMAIN_EMIT_PHASE1 : RT_DOMAIN_EMIT_PHASE2, (uint32_t)attempt, (uint32_t)(attempt >> 32));
-    PhotonState<T> ph; create_photon<T>(S, eps, rng, ph);
-    MatStack st; st.init();
-    const int stored = photon_walk<T>(S, G, C, rng, ph, st, 0, phase == 2, rec + (size_t)i * RT_REC_STRIDE, segments, errors, overflows);
-    kind[i] = (uint8_t)stored;
-    nseg[i] = (uint8_t)(segments < 255 ? segments : 255);
+    create_photon<T>(S, eps, rng, ph);
+    st.init(); depth = 0; my_segments = 0;
+  };
+  bool have = i < wg_end;
+  if (have) start(i);
+  while (have) {
+    my_segments++;
+    const int k = photon_step<T>(S, G, C, rng, ph, st, depth, phase == 2, rec + (size_t)i * RT_REC_STRIDE, errors, overflows);
+    if (k >= 0) {                                            // this attempt is over: record it, take the next one
+      kind[i] = (uint8_t)k;
+      nseg[i] = (uint8_t)(my_segments < 255 ? my_segments : 255);
+      segments += my_segments;
+      i = atomicAdd(&next_attempt, 1u);
+      have = i < wg_end;
+      if (have) start(i);
+    }
   }
   // one atomic per wave for the statistics
   for (int off = 32; off > 0; off >>= 1) {

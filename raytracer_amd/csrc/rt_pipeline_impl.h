@@ -438,12 +438,16 @@ int pl_emit_batch(rt_scene *sc, const rt_params *p, int phase, uint64_t a0, uint
   if (!sc->ws_misc.p) { RT_HIP(ctx, sc->ws_misc.alloc(256)); RT_HIP(ctx, hipMemsetAsync(sc->ws_misc.p, 0, 256, ctx->stream)); }
   EmitCfg C; C.epsilon = working_eps<T>(p); C.max_depth = p->max_depth; C.num_diffuse = p->num_photons_diffuse;
   C.num_caustic = p->num_photons_caustic; C.seed = p->seed;
+  // attempts per workgroup: 16 a lane when the batch is large enough to fill the chip several times over, fewer otherwise
+  uint32_t per_lane = 16;
+  while (per_lane > 1 && (uint64_t)count < (uint64_t)per_lane * 256 * 2048) per_lane /= 2;
+  const uint32_t per_wg = per_lane * 256;
   if (!S.bvh && scene_fits_lds<T>(S.n_shapes))
-    RT_LAUNCH_SMEM(ctx, "photon_emit_bounce", (k_emit<T, true>), div_up(count, 256), 256, scan_lds_bytes<T>(S.n_shapes), S, C, phase,
-                   (unsigned long long)a0, count, sc->ws_emit_kind.as<uint8_t>(), sc->ws_emit_rec.as<T>(), sc->ws_emit_seg.as<uint8_t>(), sc->ws_misc.as<EmitCounters>());
+    RT_LAUNCH_SMEM(ctx, "photon_emit_bounce", (k_emit<T, true>), div_up(count, per_wg), 256, scan_lds_bytes<T>(S.n_shapes), S, C, phase,
+                   (unsigned long long)a0, count, per_wg, sc->ws_emit_kind.as<uint8_t>(), sc->ws_emit_rec.as<T>(), sc->ws_emit_seg.as<uint8_t>(), sc->ws_misc.as<EmitCounters>());
   else
-    RT_LAUNCH_SMEM(ctx, "photon_emit_bounce", (k_emit<T, false>), div_up(count, 256), 256, 0, S, C, phase,
-                   (unsigned long long)a0, count, sc->ws_emit_kind.as<uint8_t>(), sc->ws_emit_rec.as<T>(), sc->ws_emit_seg.as<uint8_t>(), sc->ws_misc.as<EmitCounters>());
+    RT_LAUNCH_SMEM(ctx, "photon_emit_bounce", (k_emit<T, false>), div_up(count, per_wg), 256, 0, S, C, phase,
+                   (unsigned long long)a0, count, per_wg, sc->ws_emit_kind.as<uint8_t>(), sc->ws_emit_rec.as<T>(), sc->ws_emit_seg.as<uint8_t>(), sc->ws_misc.as<EmitCounters>());
   RT_HIP(ctx, hipGetLastError());
   return RT_OK;
 }
