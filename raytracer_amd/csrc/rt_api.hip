@@ -91,7 +91,7 @@ int rt_init(const int *device_ids, int n, rt_ctx **out) {
       return RT_ERR_HIP;
     }
   // the experiment switches: the environment is read here, once per context
-  static const char *names[] = { "tail_threshold", "whole_frame", "bounce_passes", "tail_handoff", "tail_rounds", "no_lds", "no_cull", "raster_order", "bvh", "knn_heap",
+  static const char *names[] = { "tail_threshold", "whole_frame", "bounce_passes", "tail_handoff", "tail_rounds", "tail_persistent", "no_lds", "no_cull", "raster_order", "bvh", "knn_heap",
                                  "knn_verbose", "probe", "knn_radius_scale" };
   for (const char *nm : names) {
     std::string env = "RT355_";
@@ -124,6 +124,7 @@ int rt_set_option(rt_ctx *ctx, const char *name, double value) {
   else if (n == "bounce_passes") K.bounce_passes = (int)value;
   else if (n == "tail_handoff") K.tail_handoff = (int)value;
   else if (n == "tail_rounds") K.tail_rounds = (int)value;
+  else if (n == "tail_persistent") K.tail_persistent = (int)value;
   else if (n == "no_lds") K.no_lds = value != 0;
   else if (n == "no_cull") K.no_cull = value != 0;
   else if (n == "raster_order") K.raster_order = value != 0;

@@ -26,7 +26,7 @@ struct DevMem {
   template <typename T> T *as() const { return (T *)p; }
 };
 
-#define RT_MAX_IN_FLIGHT 4
+#define RT_MAX_IN_FLIGHT 8
 // Experiment / test switches of a context.  Their defaults are the measured best; rt_init reads the RT355_* environment
 // variables ONCE into this struct and rt_set_option changes single entries afterwards, so no frame pays a getenv.
 struct RtKnobs {
@@ -35,6 +35,8 @@ struct RtKnobs {
   int bounce_passes = 0;         // single-bounce passes between the first pass and the tail kernel
   int tail_handoff = 0;          // > 0: tail workgroups down to this many paths (<= 64) hand them on to a further launch
   int tail_rounds = 1;           // how many such further launches (1 .. 3)
+  int tail_persistent = -1;      // tail kernel with persistent lanes, this many queued paths per lane and workgroup; 0: the compacting
+                                 // tail kernel; < 0: by the number of frames in flight (persistent lanes pay from three on)
   int no_lds = 0;                // 1: scans read the primitives through scalar loads instead of the LDS copy
   int no_cull = 0;               // 1: the first pass scans every primitive (no per-workgroup culling)
   int raster_order = 0;          // 1: paths numbered row by row even where 32x8 tiles would fit

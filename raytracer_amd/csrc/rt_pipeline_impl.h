@@ -207,6 +207,17 @@ static int trace_tile_mode(rt_scene *sc, int slot, const rt_params *p, DevMap md
       // k_tail): `rounds` such launches follow the first, the last of which keeps its paths to their end.
       const uint32_t handoff = (direct && K.tail_handoff > 0) ? std::min<uint32_t>((uint32_t)K.tail_handoff, 64u) : 0u;
       const uint32_t rounds = handoff ? std::min<uint32_t>((uint32_t)std::max(K.tail_rounds, 1), RT_MAX_TAIL_ROUNDS) : 0u;
+      // Which tail kernel?  The compacting one finishes a frame sooner when the frame has the chip to itself (0.18 against
+      // 0.23 ms on the 1080p bench frame); with persistent lanes a frame costs fewer instructions but its longest paths
+      // start later, which pays once three or more frames are in flight to fill the gaps (0.118 -> 0.101 ms per frame).
+      const int persistent = K.tail_persistent >= 0 ? K.tail_persistent : (ctx->frames_in_flight >= 3 ? 4 : 0);
+      if (direct && persistent > 0) {
+        const uint32_t per_wg = 256u * (uint32_t)std::min(persistent, 64);
+        const uint32_t pblocks = div_up(ub, per_wg) + RT_SUBQ;
+        if (lds) RT_LAUNCH_SMEM(ctx, "tail", (k_tail_persistent<T, true, WHITTED, FULL>), pblocks, 256, smem, S, P, C, md, mc, levels, (const uint32_t *)q_cur, lens, n_subq, cap, ctr, (int)wave_bounces, per_wg);
+        else RT_LAUNCH_SMEM(ctx, "tail", (k_tail_persistent<T, false, WHITTED, FULL>), pblocks, 256, 0, S, P, C, md, mc, levels, (const uint32_t *)q_cur, lens, n_subq, cap, ctr, (int)wave_bounces, per_wg);
+        break;
+      }
       for (uint32_t r = 0; r <= rounds; r++) {
         const uint32_t ho = r < rounds ? handoff : 0u;
         uint32_t *c_out = ho ? ctr->subq_count[RT_MAX_BOUNCE_PASSES + 1 + r] : nullptr;

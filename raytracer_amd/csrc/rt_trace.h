@@ -839,6 +839,58 @@ __global__ void __launch_bounds__(RT_TAIL_THREADS, RT_TAIL_MIN_WAVES) k_tail(Dev
   flush_tally(tally, ctr);
 }
 
+// The tail with persistent lanes (option tail_persistent = paths per lane): a workgroup takes a chunk of per_wg queued
+// paths; every lane follows one path with the state in registers and, when that path ends, takes the chunk's next path
+// nobody has started (a counter in LDS) -- no compaction, no barrier and no LDS traffic for path states inside the loop,
+// and lanes stay busy until the chunk runs dry.  Paths are at different bounces: each lane takes its bounce number from
+// its path's depth (depth and bounce number advance together).
+template <typename T, bool LDS, bool WHITTED, bool FULL>
+__global__ void __launch_bounds__(256) k_tail_persistent(DevScene<T> S, PathSoA<T> P, TraceCfg C, DevMap Md, DevMap Mc, T *levels, const uint32_t *queue,
+                                                         const uint32_t *counts, uint32_t n_subq, uint32_t cap, TraceCounters *ctr, int bounce0, uint32_t per_wg) {
+  extern __shared__ __align__(16) unsigned char rt_lds[];
+  __shared__ uint32_t next_path;
+  const uint32_t len_raw = subq_load_len(counts, n_subq);   // (in flight while the scene is staged)
+  const ScanSrc<T> G = LDS ? stage_scene_lds<T>(S, rt_lds) : global_scan_src<T>(S);
+  uint32_t sq, first, n;
+  if (!subq_find_chunk(len_raw, cap, per_wg, sq, first, n)) return;          // (workgroup-uniform: the grid is an upper bound)
+  if (threadIdx.x == 0) next_path = blockDim.x;
+  __syncthreads();
+  ShadeTally tally;
+  unsigned long long rays = 0;
+  int last_b = -1;
+  uint32_t j = threadIdx.x;
+  bool have = j < n;
+  uint32_t p = 0;
+  PathState<T> st;
+  // (taking a path costs the wave two dependent global round trips; loading a lane's next path ahead of time was
+  // measured slower: 17 more registers and the loads of paths that the chunk's last lanes never reach)
+  auto take = [&]() {
+    p = queue[first + j];
+    if (p >= C.n_paths) { tally.overflows++; p = 0; }       // (never taken; guards the indexed accesses)
+    st = load_path<T>(P, p);
+  };
+  if (have) take();
+  while (have) {
+    T t;
+    const int b = (int)(st.depth & 0xFFFF);
+    const int idx = scan_scene<T, WHITTED ? 3 : 0>(S, G, st.o, st.d, T(C.epsilon), T(0), t, &tally.tests);
+    rays++; last_b = max(last_b, b);
+    const bool alive = shade_step<T, WHITTED, FULL>(S, G, P, C, Md, Mc, levels, p, st, t, idx, b, tally);
+    if (!alive) {
+      j = atomicAdd(&next_path, 1u);
+      have = j < n;
+      if (have) take();
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) { rays += __shfl_xor(rays, off, 64); last_b = max(last_b, __shfl_xor(last_b, off, 64)); }
+  if ((threadIdx.x & 63) == 0) {
+    const uint32_t slot = (blockIdx.x * 4 + (threadIdx.x >> 6)) % RT_CTR_SLOTS;
+    if (rays) atomicAdd(&ctr->tail_rays[slot], rays);
+    if (last_b >= 0) atomicMax(&ctr->max_iter[slot], (uint32_t)(last_b - bounce0 + 1) + C.iter_base);
+  }
+  flush_tally(tally, ctr);
+}
+
 // Pixel resolve (rayphoton.js:1610-1623): clamp each sub-sample (`colour()`), sum, floor of the
 // mean.  pre = the last sub-sample's unclamped colour; rgba8 = post as bytes.
 template <typename T>

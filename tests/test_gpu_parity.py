@@ -576,6 +576,13 @@ def test_wavefront_and_whole_frame_pipelines_agree(rt, precision):
             assert same(got["pre"], whole["pre"]) and same(got["post"], whole["post"]), (ho, rounds)
             for k in ("rays", "shadow_rays", "gathers", "bounces"):
                 assert got["stats"][k] == whole["stats"][k], (k, ho, rounds)
+        # the tail kernel with persistent lanes
+        for per_lane in (1, 4, 16):
+            with ctx.option("tail_persistent", per_lane, 0):
+                got = sc.trace_tile(p, md, mc)
+            assert same(got["pre"], whole["pre"]) and same(got["post"], whole["post"]), per_lane
+            for k in ("rays", "shadow_rays", "gathers", "bounces"):
+                assert got["stats"][k] == whole["stats"][k], (k, per_lane)
         # single-bounce passes between the first pass and the tail kernel
         for n in (0, 1, 2):
             with ctx.option("bounce_passes", n, 0):

@@ -55,7 +55,7 @@ def main():
     fetch, write = largest(db("fetch"), "FETCH_SIZE"), largest(db("write"), "WRITE_SIZE")
     traffic = {}
     # (the frame kernels by the instantiation the headline workload runs: fp32, culled primitive lists, no photon maps)
-    pick = {"k_primary": "k_primary<float, true, false, false>", "k_tail": "k_tail<float, true, false, false, 0>",
+    pick = {"k_primary": "k_primary<float, true, false, false>", "k_tail": "k_tail<float, true, false, false, 0>", "k_tail_persistent": "k_tail_persistent<float, true, false, false>",
             "k_gather_knn_wave": "k_gather_knn_wave(", "k_gather_knn_single": "k_gather_knn_single(", "k_emit": "k_emit<float", "k_kd_lds": "k_kd_lds("}
     for key, pat in pick.items():
         f = [v for n, v in fetch.items() if pat in n]
