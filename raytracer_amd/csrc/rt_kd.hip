@@ -1160,21 +1160,22 @@ __global__ void __launch_bounds__(64) k_gather_knn_single(DevMap M, const float 
   while (sp > 0) {
     if (m + 64 > KNN2_CAP) {                          // no room for another step: lower tau to the k-th smallest so far
       load_d(m);
-      float4 keep[KNN1_PER_LANE];
-#pragma unroll
-      for (int i = 0; i < KNN1_PER_LANE; i++) { const uint32_t j = (uint32_t)i * 64u + (uint32_t)lane; keep[i] = cand[j < m ? j : 0]; }
       tau = wave_kth_smallest(d, k);
       set_tau();
-      __syncthreads();
+      // in place, 64 entries at a time: what a chunk keeps lands at or below the chunk's own positions, so the chunks
+      // still to come are not overwritten
       uint32_t m2 = 0;
 #pragma unroll
       for (int i = 0; i < KNN1_PER_LANE; i++) {
+        const uint32_t j = (uint32_t)i * 64u + (uint32_t)lane;
+        const float4 entry = cand[j < m ? j : 0];
         const bool kp = d[i] <= tau;                  // (absent entries are +infinity)
         const unsigned long long mk = __ballot(kp);
-        if (kp) cand[m2 + lanes_below(mk, lane)] = keep[i];
+        __syncthreads();                              // (every lane holds its entry)
+        if (kp) cand[m2 + lanes_below(mk, lane)] = entry;
         m2 += (uint32_t)__popcll(mk);
+        __syncthreads();
       }
-      __syncthreads();
       m = m2;
       if (m + 64 > KNN2_CAP) { failed = true; break; }                       // (hundreds of photons at one and the same distance)
     }
