@@ -706,11 +706,17 @@ __global__ void __launch_bounds__(KNN_LANES) k_gather_knn(DevMap M, const float 
 //   4. sums the radiance of the selected candidates.
 // Distances are the same fp64 expression as everywhere else (sq_dist), ties at the k-th distance go to the lowest
 // input index, so the selected set is exactly the one rt_kd_knn returns.  A wave whose candidates or node queue would
-// overflow its LDS buffers hands its queries on as four smaller units (16, then 4 queries, then single queries, which
+// overflow its LDS buffers hands its queries on as eight units of 8 queries, and those in turn as single queries, which
 // k_gather_knn_single streams through the same buffers whatever their number of candidates).
 #ifndef KNN2_CAP
 #define KNN2_CAP 512
 #endif
+// first-try radius: this many times the radius that holds k photons at the density of the query's subtree
+#ifndef KNN_FIRST_TRY
+#define KNN_FIRST_TRY 1.3f
+#endif
+// a unit that does not fit is cut into this many (64 -> 8 -> single queries)
+#define KNN_SPLIT 8u
 #ifndef KNN2_FRONT
 #define KNN2_FRONT 512
 #endif
@@ -725,21 +731,25 @@ __device__ __forceinline__ double wave_min_d(double v) { for (int o = 32; o > 0;
 __device__ __forceinline__ double wave_max_d(double v) { for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64)); return v; }
 __device__ __forceinline__ uint32_t lanes_below(unsigned long long mask, int lane) { return (uint32_t)__popcll(mask & (((unsigned long long)1 << lane) - 1)); }
 
-// Work units: a unit is `count` consecutive queries starting at `first` (count = 64, 16, 4 or 1), served by one wave
+// Work units: a unit is `count` consecutive queries starting at `first` (count = 64 or 8), served by one wave
 // with the lanes beyond count shadowing its queries.  Without a unit list workgroup u serves [64 u, 64 u + 64).  A unit
-// whose candidates do not fit the wave's LDS buffers is cut into four (appended to `next` for the next launch: other
+// whose candidates do not fit the wave's LDS buffers is cut into eight (appended to `next` for the next launch: other
 // waves serve them, in parallel) or, a single query, goes to the list of the per-lane heap kernel.  why[] counts the
 // units given up by cause: candidates, frontier, second try short, search.
-struct KnnQueues { uint2 *next; uint32_t *next_count; uint32_t *heap_list; uint32_t *heap_count; uint32_t *why; };
-__device__ __forceinline__ void knn_give_up(const KnnQueues &Q, uint32_t first, uint32_t count, uint32_t nq, int lane, int cause) {
+struct KnnQueues { uint2 *next; uint32_t *next_count; uint2 *single; uint32_t *single_count; uint32_t *heap_list; uint32_t *heap_count; uint32_t *why; };
+// to_single: the unit is so far beyond the buffers that its eighths would not fit either -- its queries go straight to
+// the single-query kernel's queue
+__device__ __forceinline__ void knn_give_up(const KnnQueues &Q, uint32_t first, uint32_t count, uint32_t nq, int lane, int cause, bool to_single = false) {
   if (lane != 0) return;
   atomicAdd(&Q.why[cause], 1u);
   if (count <= 1) { Q.heap_list[atomicAdd(Q.heap_count, 1u)] = first; return; }
-  const uint32_t part = count / 4;
+  const uint32_t part = to_single ? 1u : count / KNN_SPLIT, parts = count / part;
+  uint2 *dst = part == 1 ? Q.single : Q.next;
+  uint32_t *dst_count = part == 1 ? Q.single_count : Q.next_count;
   uint32_t live = 0;
-  for (uint32_t j = 0; j < 4; j++) live += (first + j * part < nq) ? 1u : 0u;
-  const uint32_t base = atomicAdd(Q.next_count, live);
-  for (uint32_t j = 0, o = 0; j < 4; j++) if (first + j * part < nq) Q.next[base + o++] = make_uint2(first + j * part, part);
+  for (uint32_t j = 0; j < parts; j++) live += (first + j * part < nq) ? 1u : 0u;
+  const uint32_t base = atomicAdd(dst_count, live);
+  for (uint32_t j = 0, o = 0; j < parts; j++) if (first + j * part < nq) dst[base + o++] = make_uint2(first + j * part, part);
 }
 
 // number of nodes in the subtree rooted at heap position pos of a left-balanced tree of n nodes
@@ -844,6 +854,7 @@ __global__ void __launch_bounds__(64) k_gather_knn_wave(DevMap M, const float *h
   const uint32_t mt = load_subtree();
   __syncthreads();
   float rq;                                          // radius of this query's search ball
+  float rho;                                         // photons per unit area around the queries (from T)
   {
     float l0 = 3.4e38f, l1 = 3.4e38f, l2 = 3.4e38f, h0 = -3.4e38f, h1 = -3.4e38f, h2 = -3.4e38f;
     for (uint32_t j = lane; j < mt; j += 64) { const float4 c = cand[j]; l0 = fminf(l0, c.x); h0 = fmaxf(h0, c.x); l1 = fminf(l1, c.y); h1 = fmaxf(h1, c.y); l2 = fminf(l2, c.z); h2 = fmaxf(h2, c.z); }
@@ -851,7 +862,8 @@ __global__ void __launch_bounds__(64) k_gather_knn_wave(DevMap M, const float *h
     const float e0 = h0 - l0, e1 = h1 - l1, e2 = h2 - l2;
     const float emax = fmaxf(e0, fmaxf(e1, e2)), emin = fminf(e0, fminf(e1, e2)), emid = e0 + e1 + e2 - emax - emin;
     const float area = fmaxf(emax * fmaxf(emid, 1e-3f * emax), 1e-30f);
-    const float r_est = 1.4f * sqrtf((float)k * area / (3.14159265f * (float)mt));
+    rho = (float)mt / area;
+    const float r_est = KNN_FIRST_TRY * sqrtf((float)k * area / (3.14159265f * (float)mt));
     const float dx = fmaxf(0.f, fmaxf(l0 - qx, qx - h0)), dy = fmaxf(0.f, fmaxf(l1 - qy, qy - h1)), dz = fmaxf(0.f, fmaxf(l2 - qz, qz - h2));
     rq = (r_est + sqrtf(dx * dx + dy * dy + dz * dz)) * radius_scale;
   }
@@ -882,7 +894,7 @@ __global__ void __launch_bounds__(64) k_gather_knn_wave(DevMap M, const float *h
     }
     b64 = (double)rq * (double)rq;
     // pivots of the first counting pass: a first-try radius is 1.4 x the expected k-th distance; a guaranteed one is looser
-    pt2 = attempt == 0 ? b64 / 1.96 : 0.55 * b64;
+    pt2 = attempt == 0 ? b64 / (double)(KNN_FIRST_TRY * KNN_FIRST_TRY) : 0.55 * b64;
     { const double pdt = pt2 / (double)k * (1.0 + 0.6 * sqrt((double)k)); pt1 = pt2 - pdt > 0.0 ? pt2 - pdt : 0.5 * pt2; pt3 = pt2 + pdt < b64 ? pt2 + pdt : 0.5 * (pt2 + b64); }
     // ---- 1. cooperative walk of the tree over the box of the queries' balls (fp32 bounds rounded outwards: the walk
     // only has to find a superset, the distances below decide)
@@ -895,6 +907,15 @@ __global__ void __launch_bounds__(64) k_gather_knn_wave(DevMap M, const float *h
     const float gx = 0.5f * (wave_min_f(qx) + wave_max_f(qx)), gy = 0.5f * (wave_min_f(qy) + wave_max_f(qy)), gz = 0.5f * (wave_min_f(qz) + wave_max_f(qz));
     const float reach = (sqrtf(wave_max_f((qx - gx) * (qx - gx) + (qy - gy) * (qy - gy) + (qz - gz) * (qz - gz))) + wave_max_f(rw)) * 1.00001f;
     const float reach2 = reach * reach * 1.00001f;
+    // How many photons will that box hold?  Its two largest extents times the density around the queries.  Far beyond
+    // the buffer: no point in walking -- the unit is cut up at once, straight into single queries when its eighths
+    // would not fit either.
+    if (u_count > 1) {
+      const float b0 = hi0 - lo0, b1 = hi1 - lo1, b2 = hi2 - lo2;
+      const float bmax = fmaxf(b0, fmaxf(b1, b2)), bmin = fminf(b0, fminf(b1, b2));
+      const float predicted = rho * bmax * (b0 + b1 + b2 - bmax - bmin);
+      if (predicted > 3.0f * KNN2_CAP) { knn_give_up(Q, u_first, u_count, nq, lane, 0, predicted > 6.0f * KNN2_CAP); return; }
+    }
     __syncthreads();                                 // (T has been consumed)
     m = 0;
     {
@@ -911,13 +932,17 @@ __global__ void __launch_bounds__(64) k_gather_knn_wave(DevMap M, const float *h
       if (lane == 0) front[0] = t_pos >> (t_depth - start_level);
       __syncthreads();
       // the queue is a ring: up to 64 nodes leave at the head, their children join at the tail (the order of the visits
-      // does not matter: the distances decide, and ties go by input index)
+      // does not matter: the distances decide, and ties go by input index).  Once the ring is more than half full the
+      // nodes leave at the TAIL instead -- the deepest ones, which soon end in leaves -- and only as many as leave room
+      // for two children each, so a wide level of the tree does not overflow the ring.
       uint32_t head = 0, tail = 1;
       while (head != tail) {
-        const uint32_t take = min(64u, tail - head);
+        const uint32_t size = tail - head;
+        const bool lifo = size > KNN2_FRONT / 2;
+        const uint32_t take = lifo ? min(64u, max(1u, (KNN2_FRONT - size) / 2u)) : min(64u, size);
         const bool active = (uint32_t)lane < take;
-        const uint32_t pos = active ? front[(head + lane) % KNN2_FRONT] : 1u;      // 1 <= pos <= n by construction
-        head += take;
+        const uint32_t pos = active ? front[((lifo ? tail - take : head) + lane) % KNN2_FRONT] : 1u;      // 1 <= pos <= n by construction
+        if (lifo) tail -= take; else head += take;
         const float4 nd = M.node[pos - 1];
         const float ddx = nd.x - gx, ddy = nd.y - gy, ddz = nd.z - gz;
         const bool inside = active && nd.x >= lo0 && nd.x <= hi0 && nd.y >= lo1 && nd.y <= hi1 && nd.z >= lo2 && nd.z <= hi2 &&
@@ -1258,14 +1283,14 @@ __global__ void __launch_bounds__(64) k_gather_knn_single(DevMap M, const float 
   }
 }
 
-// ---- scratch of the k-nearest gather: counters, the unit queues of the three split levels (16-, 4- and 1-query
+// ---- scratch of the k-nearest gather: counters, the unit queues of the two split levels (8- and 1-query
 // units) and the list of queries left to the heap kernel.  rt_gather_radiance keeps it in a grow-only buffer of the map;
 // rt_gather_radiance_static uses the array below, which exists once per GPU for the life of the process.
 static size_t knn_scratch_bytes(uint32_t nq) {
   const size_t blocks = div_up(nq, KNN_LANES);
-  return 256 + blocks * (4 + 16 + 64) * sizeof(uint2) + (size_t)nq * 4;
+  return 256 + blocks * (8 + 64) * sizeof(uint2) + (size_t)nq * 4;
 }
-#define RT_STATIC_SCRATCH_BYTES ((256 + ((size_t)RT_GATHER_STATIC_MAX_QUERIES / KNN_LANES) * 84 * 8 + (size_t)RT_GATHER_STATIC_MAX_QUERIES * 4 + 255) / 256 * 256)
+#define RT_STATIC_SCRATCH_BYTES ((256 + ((size_t)RT_GATHER_STATIC_MAX_QUERIES / KNN_LANES) * 72 * 8 + (size_t)RT_GATHER_STATIC_MAX_QUERIES * 4 + 255) / 256 * 256)
 static __device__ __align__(256) unsigned char scratch[RT_STATIC_SCRATCH_BYTES];
 // The array's name is only a host-side stand-in; the address of each GPU's copy is looked up once per device
 // (rt_static_scratch_setup, called by rt_init with that device current) and host code uses that pointer from then on.
@@ -1306,30 +1331,33 @@ static int gather_knn_run(rt_photon_map *m, const float *dh, uint32_t nq, uint32
   uint32_t t_depth = 0;
   while (t_depth < 30 && subtree_size((uint64_t)1 << t_depth) > std::min<uint64_t>(4ull * k, KNN2_CAP)) t_depth++;
   while (t_depth > 0 && subtree_size(((uint64_t)2 << t_depth) - 1) < k) t_depth--;
-  // level 0: one wave per 64 consecutive queries.  Levels 1-3: the units whose candidates did not fit, cut into four
-  // each time (16, 4, 1 queries).  What is left then goes to the per-lane heap kernel.
-  uint32_t *counters = (uint32_t *)ws;                                     // [0..2] units queued for level 1..3, [3] queries for the heap kernel, [4..7] units given up by cause
-  uint2 *queue[3] = { (uint2 *)((char *)ws + 256), nullptr, nullptr };
-  queue[1] = queue[0] + (size_t)blocks * 4; queue[2] = queue[1] + (size_t)blocks * 16;
-  uint32_t *heap_list = (uint32_t *)(queue[2] + (size_t)blocks * 64);
+  // level 0: one wave per 64 consecutive queries.  Level 1: the units whose candidates did not fit, cut into eight (one
+  // row of an 8x8 tile each).  Level 2: the queries of the eighths that did not fit either, one wave each, streaming.
+  // What is left then goes to the per-lane heap kernel.
+  uint32_t *counters = (uint32_t *)ws;                                     // [0..1] units queued for level 1..2, [3] queries for the heap kernel, [4..7] units given up by cause
+  uint2 *queue[2] = { (uint2 *)((char *)ws + 256), nullptr };
+  queue[1] = queue[0] + (size_t)blocks * 8;
+  uint32_t *heap_list = (uint32_t *)(queue[1] + (size_t)blocks * 64);
   RT_HIP(ctx, hipMemsetAsync(counters, 0, 32, ctx->stream));
-  uint32_t launched[4] = { blocks, 0, 0, 0 };
-  for (int level = 0; level < 4; level++) {
-    if (launched[level] == 0) break;
-    KnnQueues Q; Q.next = level < 3 ? queue[level] : nullptr; Q.next_count = level < 3 ? counters + level : nullptr;
+  uint32_t launched[3] = { blocks, 0, 0 };
+  for (int level = 0; level < 3; level++) {
+    if (level > 0) {                                         // what the levels before have queued for this one
+      const uint32_t queued = ctx->pinned[level - 1], cap_level = level == 1 ? blocks * KNN_SPLIT : nq;
+      launched[level] = queued <= cap_level ? queued : cap_level;
+      if (launched[level] == 0) continue;
+    }
+    KnnQueues Q; Q.next = level < 2 ? queue[level] : nullptr; Q.next_count = level < 2 ? counters + level : nullptr;
+    Q.single = queue[1]; Q.single_count = counters + 1;
     Q.heap_list = heap_list; Q.heap_count = counters + 3; Q.why = counters + 4;
-    if (level < 3) {
+    if (level < 2) {
       RT_LAUNCH(ctx, level == 0 ? "gather_knn" : "gather_knn_split", k_gather_knn_wave, launched[level], 64, m->view(), dh, nq, k, scale, t_depth, dout,
                 level == 0 ? (const uint2 *)nullptr : (const uint2 *)queue[level - 1], level == 0 ? (const uint32_t *)nullptr : (const uint32_t *)(counters + level - 1), Q);
     } else {                                                               // single queries: one wave each, streaming
       RT_LAUNCH(ctx, "gather_knn_single", k_gather_knn_single, launched[level], 64, m->view(), dh, nq, k, t_depth, dout,
-                (const uint2 *)queue[2], (const uint32_t *)(counters + 2), heap_list, counters + 3);
+                (const uint2 *)queue[1], (const uint32_t *)(counters + 1), heap_list, counters + 3);
     }
     RT_HIP(ctx, hipMemcpyAsync(ctx->pinned, counters, 32, hipMemcpyDeviceToHost, ctx->stream));
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (level == 3) break;
-    const uint32_t cap_next = launched[level] * 4;
-    launched[level + 1] = ctx->pinned[level] <= cap_next ? ctx->pinned[level] : cap_next;
   }
   const uint32_t left = ctx->pinned[3] <= nq ? ctx->pinned[3] : nq;
   if (left > 0) {
@@ -1350,8 +1378,8 @@ static int gather_knn_run(rt_photon_map *m, const float *dh, uint32_t nq, uint32
   }
 #endif
   if (K.knn_verbose)
-    fprintf(stderr, "rt_gather_radiance: %u units of 64 queries, then %u of 16, %u of 4, %u of 1; given up for candidates %u, frontier %u, short %u, search %u; %u queries left to the heap kernel\n",
-            launched[0], launched[1], launched[2], launched[3], ctx->pinned[4], ctx->pinned[5], ctx->pinned[6], ctx->pinned[7], left);
+    fprintf(stderr, "rt_gather_radiance: %u units of 64 queries, then %u of 8, %u of 1; given up for candidates %u, frontier %u, short %u, search %u; %u queries left to the heap kernel\n",
+            launched[0], launched[1], launched[2], ctx->pinned[4], ctx->pinned[5], ctx->pinned[6], ctx->pinned[7], left);
   return RT_OK;
 }
 
