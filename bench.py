@@ -105,6 +105,48 @@ def cpu_baseline(flat, seed, budget_s=10.0):
                       "oracle/rt_oracle.c (fp64, bit-exact with the reference JS on its golden frames)"}
 
 
+_FULL = {}     # the oracle's scene, parameters and photon maps of the full-render leg, set before the pool forks
+
+
+def _cpu_full_band(job):
+    from oracle import oracle as ora
+    y0, h = job
+    osc, op, maps, w = _FULL["job"]
+    return ora.render(osc, op, maps, 0, y0, w, h)[2]
+
+
+def cpu_full_render(seed, w=320, h=240, photons=10000):
+    """The reference's render in full (direct light, both radius gathers) on the CPU oracle: BASELINE config 0's frame
+    -- the default scene at 320x240 with 10k + 10k photons -- emission and tree builds on one core (as the reference
+    does them), the frame over the worker pool and again on one core.  bench.py times the GPU on the same frame."""
+    import multiprocessing as mp
+    from oracle import oracle as ora
+    from raytracer_amd.scene import FlatScene
+    flat = FlatScene.from_json(os.path.join(ROOT, "tests", "golden", "scene_preset10_flat.json")).with_size(w, h)
+    osc = ora.Scene(flat)
+    op = ora.params(seed=seed, num_photons_diffuse=photons, num_photons_caustic=photons, sub_sample=1)
+    t0 = time.perf_counter()
+    em = ora.emit_many(osc, op)
+    t_emit = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    maps = ora.Maps(em["diffuse"], em["caustic"])
+    t_build = time.perf_counter() - t0
+    _FULL["job"] = (osc, op, maps, w)
+    workers = cpu_workers()
+    bands = [(y, min(4, h - y)) for y in range(0, h, 4)]
+    with mp.get_context("fork").Pool(workers) as pool:
+        pool.map(_cpu_full_band, bands[:workers])
+        t0 = time.perf_counter()
+        rays = sum(pool.map(_cpu_full_band, bands))
+        t_pool = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    rays1 = sum(_cpu_full_band(b) for b in bands)
+    t_one = time.perf_counter() - t0
+    return {"frame": f"{w}x{h}, {photons} + {photons} photons, 1 sub-sample", "rays": int(rays), "emission_s_one_core": t_emit, "kd_builds_s_one_core": t_build,
+            "frame_ms_all_cores": t_pool * 1e3, "frame_ms_one_core": t_one * 1e3, "cores": workers, "kind": "port",
+            "Mrays_per_s_all_cores": rays / t_pool / 1e6, "Mrays_per_s_one_core": rays1 / t_one / 1e6}
+
+
 _KD = {}       # the oracle's tree, set before the pool forks (the workers inherit it instead of unpickling 30 MB per chunk)
 
 
@@ -174,10 +216,12 @@ def main():
     seed = 1 + (rank if args.independent_frames else 0)
 
     # the CPU baselines fork worker processes: they run first, before this process initialises the GPU
-    cpu_line, cpu_gather_line = None, None
+    cpu_line, cpu_gather_line, cpu_full_line = None, None, None
     if not args.no_cpu_baseline and world == 1:
         from raytracer_amd import synth as _synth
         cpu_line = cpu_baseline(flat, seed)
+        if not args.no_other_configs:
+            cpu_full_line = cpu_full_render(seed)
         if not args.no_gather:
             cpu_gather_line = cpu_baseline_gather(_synth.box_photons(args.photons, seed=7), _synth.box_queries(W, H), args.knn)
 
@@ -471,6 +515,23 @@ def main():
         extra["full_mode_b_frame"] = {"ms_per_frame": dtf * 1e3, "Mrays_per_s": stf["rays"] / dtf / 1e6, "rays_per_frame": stf["rays"],
                                       "shadow_rays_per_frame": stf["shadow_rays"], "gathers_per_frame": stf["gathers"], "gathers_per_s": stf["gathers"] / dtf,
                                       "photons": stored, "note": "direct light, diffuse (r = 0.40) and caustic (r = 0.15) radius gathers: the reference's traceRay in full"}
+        # ... and BASELINE config 0's frame (320x240, 10k + 10k photons, everything on): the frame the CPU oracle is timed on
+        flat0 = flat.with_size(320, 240)
+        sc0 = ctx.upload(flat0)
+        p0 = capi.default_params(precision=capi.PRECISION_F32, num_photons_diffuse=10000, num_photons_caustic=10000, seed=seed, shadow_bias=1e-4)
+        ctx.synchronize()
+        t_ = time.perf_counter()
+        lists0, _ = sc0.emit_many_lists(p0, capi.SHARD_PACKED, strict=False)
+        md0, mc0 = lists0.photon_map(0), lists0.photon_map(1)
+        ctx.synchronize()
+        dt_prep = time.perf_counter() - t_
+        frame0 = torch.empty((240, 320, 4), dtype=torch.uint8, device=dev)
+        dt0, st0 = timed_frames(sc0, p0, frame0, n=20, maps=(md0, mc0))
+        extra["full_mode_b_config0"] = {"gpu": {"frame_ms": dt0 * 1e3, "emission_and_kd_builds_ms": dt_prep * 1e3, "rays": st0["rays"], "Mrays_per_s": st0["rays"] / dt0 / 1e6},
+                                        "cpu": cpu_full_line,
+                                        "note": "BASELINE config 0 (default scene at 320x240, 10k + 10k photons, direct light and both radius gathers): the same frame on "
+                                                "the GPU (fp32) and on the CPU oracle (fp64)"}
+        del md0, mc0, lists0, sc0
         # the k-nearest gather on that real map at the frame's own first-hit points
         if not args.no_gather:
             hp = capi.default_params(precision=capi.PRECISION_F32, use_direct_light=0, use_photon_maps=0, seed=seed, max_bounces=1)
