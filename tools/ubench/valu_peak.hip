@@ -22,6 +22,12 @@ template <int MODE> __global__ void __launch_bounds__(256) k(float *out, int ite
         if (MODE == 5) asm volatile("v_cmp_lt_f32 vcc, %1, %2\n v_cndmask_b32 %0, %0, %1, vcc" : "+v"(x[i]) : "v"(a), "v"(b) : "vcc");
         if (MODE == 6) asm volatile("v_rcp_f32 %0, %0" : "+v"(x[i]));
         if (MODE == 7) asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(*(double *)&y[i]) : "v"(*(double *)&a2), "v"(*(double *)&b2));
+        if (MODE == 8) asm volatile("v_cvt_f64_f32 %0, %1" : "=v"(*(double *)&y[i]) : "v"(x[i]));
+        if (MODE == 9) asm volatile("v_add_f64 %0, %0, %1" : "+v"(*(double *)&y[i]) : "v"(*(double *)&a2));
+        if (MODE == 10) asm volatile("v_mul_f64 %0, %0, %1" : "+v"(*(double *)&y[i]) : "v"(*(double *)&a2));
+        if (MODE == 11) asm volatile("v_cmp_lt_f64 vcc, %1, %2\n v_addc_co_u32 %0, vcc, 0, %0, vcc" : "+v"(*(int *)&x[i]) : "v"(*(double *)&y[i]), "v"(*(double *)&a2) : "vcc");
+        if (MODE == 12) asm volatile("v_mul_hi_u32 %0, %0, %1" : "+v"(*(unsigned *)&x[i]) : "v"(*(unsigned *)&a));
+        if (MODE == 13) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(*(unsigned long long *)&y[i]) : "v"(*(unsigned *)&x[i]), "v"(*(unsigned *)&a) : "vcc");
       }
     }
   }
@@ -56,5 +62,11 @@ int main() {
   run<5>("v_cmp+v_cndmask", d, 0, 2);
   run<6>("v_rcp_f32", d, 1, 1);
   run<7>("v_fma_f64", d, 2, 1);
+  run<8>("v_cvt_f64_f32", d, 1, 1);
+  run<9>("v_add_f64", d, 1, 1);
+  run<10>("v_mul_f64", d, 1, 1);
+  run<11>("v_cmp_f64+v_addc", d, 0, 2);
+  run<12>("v_mul_hi_u32", d, 0, 1);
+  run<13>("v_mad_u64_u32", d, 0, 1);
   return 0;
 }
