@@ -834,30 +834,32 @@ def test_queued_frames_equal_finished_frames(rt):
 
 
 def test_two_frames_in_flight_equal_serial_frames(rt):
-    """with two frames in flight consecutive queued frames run on alternate streams and workspaces: same pixels"""
+    """with n frames in flight consecutive queued frames rotate through n streams and workspaces (from three on the
+    surviving paths are followed by the tail kernel with persistent lanes): same pixels"""
     import torch
     capi, ctx = rt
     W, H = 320, 200
     sc = ctx.upload(load_scene(10, W, H))
     ps = [capi.default_params(precision=capi.PRECISION_F32, use_photon_maps=0, seed=s) for s in range(11, 17)]
     want = [sc.trace_tile(p, want=("rgba8",))["rgba8"] for p in ps]
-    out = [torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda") for _ in ps]
-    torch.cuda.synchronize()
-    ctx.set_frames_in_flight(2)
-    try:
-        for p, b in zip(ps, out):
-            sc.trace_tile(p, want=(), out_rgba8=b, stats=False)
-        mid = sc.trace_tile(ps[0], want=("rgba8",))          # a finished frame in between waits for the queued ones
-        for p, b in zip(ps[:2], out[:2]):
-            sc.trace_tile(p, want=(), out_rgba8=b, stats=False)
-        ctx.synchronize()
-    finally:
-        ctx.set_frames_in_flight(1)
-    assert np.array_equal(mid["rgba8"], want[0])
-    for w, b in zip(want, out):
-        assert np.array_equal(b.cpu().numpy(), w)
+    for n in (2, 3, 8):
+        out = [torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda") for _ in ps]
+        torch.cuda.synchronize()
+        ctx.set_frames_in_flight(n)
+        try:
+            for p, b in zip(ps, out):
+                sc.trace_tile(p, want=(), out_rgba8=b, stats=False)
+            mid = sc.trace_tile(ps[0], want=("rgba8",))          # a finished frame in between waits for the queued ones
+            for p, b in zip(ps[:2], out[:2]):
+                sc.trace_tile(p, want=(), out_rgba8=b, stats=False)
+            ctx.synchronize()
+        finally:
+            ctx.set_frames_in_flight(1)
+        assert np.array_equal(mid["rgba8"], want[0]), n
+        for w, b in zip(want, out):
+            assert np.array_equal(b.cpu().numpy(), w), n
     with pytest.raises(capi.RtError):
-        ctx.set_frames_in_flight(5)
+        ctx.set_frames_in_flight(9)
 
 
 # ------------------------------------------------------------------ the benchmark's sizes, through size-independent properties
