@@ -91,7 +91,7 @@ int rt_init(const int *device_ids, int n, rt_ctx **out) {
       return RT_ERR_HIP;
     }
   // the experiment switches: the environment is read here, once per context
-  static const char *names[] = { "tail_threshold", "whole_frame", "bounce_passes", "tail_handoff", "tail_rounds", "tail_persistent", "no_lds", "no_cull", "raster_order", "bvh", "knn_heap",
+  static const char *names[] = { "tail_threshold", "whole_frame", "bounce_passes", "tail_handoff", "tail_rounds", "tail_persistent", "no_lds", "no_cull", "raster_order", "bvh", "bvh_one_order", "knn_heap",
                                  "knn_verbose", "probe", "knn_radius_scale" };
   for (const char *nm : names) {
     std::string env = "RT355_";
@@ -129,6 +129,7 @@ int rt_set_option(rt_ctx *ctx, const char *name, double value) {
   else if (n == "no_cull") K.no_cull = value != 0;
   else if (n == "raster_order") K.raster_order = value != 0;
   else if (n == "bvh") K.bvh = (int)value;
+  else if (n == "bvh_one_order") K.bvh_one_order = value != 0;
   else if (n == "knn_heap") K.knn_heap = value != 0;
   else if (n == "knn_verbose") K.knn_verbose = value != 0;
   else if (n == "probe") K.probe = value != 0;
@@ -273,6 +274,7 @@ static bool rt_prim_box(int type, int flags, const double *g, double lo[3], doub
 
 struct BvhBuild {
   std::vector<BvhNode> nodes;
+  std::vector<int8_t> split;                                // per node: axis whose lower centroids went to the first child, -1: none
   std::vector<uint32_t> prims;                              // leaf entries
   std::vector<double> lo, hi;                               // per bounded item
   std::vector<uint32_t> entry, order;                       // per bounded item: encoded entry; working permutation
@@ -291,7 +293,7 @@ struct BvhBuild {
       }
     }
     const uint32_t me = (uint32_t)nodes.size();
-    nodes.push_back(BvhNode());
+    nodes.push_back(BvhNode()); split.push_back(-1);
     for (int k = 0; k < 3; k++) {
       // padding: the boxes only steer the walk, a box that is too large costs tests, one that is too small loses hits
       const double pad = 1e-4 * (nhi[k] - nlo[k]) + 1e-4;
@@ -315,6 +317,7 @@ struct BvhBuild {
     // Split: surface-area heuristic over 16 centroid bins per axis (cost = area x count of either side); the median
     // of the widest axis when the bins cannot separate the items.  The boxes only steer the walk, so any split is exact.
     uint32_t mid = b + (e - b) / 2;
+    int used_axis = -1;
     {
       constexpr int NB = 16;
       double best_cost = INFINITY; int best_axis = -1, best_bin = -1;
@@ -358,6 +361,7 @@ struct BvhBuild {
           return bi <= best_bin;
         };
         mid = (uint32_t)(std::stable_partition(order.begin() + b, order.begin() + e, left) - order.begin());
+        used_axis = ax;
       }
       const uint32_t smaller = (mid - b < e - mid) ? mid - b : e - mid;
       if (best_axis < 0 || mid == b || mid == e || (uint64_t)smaller * 16 < (uint64_t)(e - b)) {       // (bounds the depth of the tree)
@@ -366,12 +370,25 @@ struct BvhBuild {
           const double cx = lo[3 * x + axis] + hi[3 * x + axis], cy = lo[3 * y + axis] + hi[3 * y + axis];
           return cx < cy || (cx == cy && x < y);
         });
+        used_axis = axis;
       }
     }
-    nodes[me].leaf = 0;
+    nodes[me].leaf = 0; split[me] = (int8_t)used_axis;
     build(b, mid); build(mid, e);
     nodes[me].skip = (uint32_t)nodes.size();
     return me;
+  }
+  // The subtree of node `me` appended to `out` in depth-first order with, at every split, the child first that a ray of
+  // direction octant `oct` (bit k: d[k] < 0) meets first along the split axis.
+  void reorder(uint32_t me, unsigned oct, std::vector<BvhNode> &out, size_t base) const {
+    const size_t at = out.size();
+    out.push_back(nodes[me]);
+    if (!nodes[me].leaf) {
+      uint32_t first = me + 1, second = nodes[me + 1].skip;
+      if (split[me] >= 0 && ((oct >> split[me]) & 1u)) std::swap(first, second);
+      reorder(first, oct, out, base); reorder(second, oct, out, base);
+    }
+    out[at].skip = (uint32_t)(out.size() - base);        // indices count from the copy's own first node
   }
 };
 
@@ -402,14 +419,24 @@ static int rt_build_bvh(rt_ctx *ctx, const rt_scene_desc *d, const std::vector<u
   auto up = [&](DevMem &m, const void *src, size_t bytes) -> int {
     RT_HIP(ctx, m.alloc(bytes)); if (bytes) RT_HIP(ctx, hipMemcpy(m.p, src, bytes, hipMemcpyHostToDevice)); return RT_OK;
   };
+  // Eight copies of the node array, one per octant of ray directions, each threaded near child first: a ray finds its
+  // closest hit early and the boxes behind it fail the reach test.  Any order gives the same hit (ties go by index).
+  const uint32_t n_nodes = (uint32_t)B.nodes.size();
+  const bool octants = !ctx->knobs.bvh_one_order && n_nodes > 1;
+  if (octants) {
+    std::vector<BvhNode> all; all.reserve((size_t)n_nodes * 8);
+    for (unsigned oct = 0; oct < 8; oct++) B.reorder(0, oct, all, all.size());
+    if (all.size() != (size_t)n_nodes * 8) return rt_fail(ctx, RT_ERR_INVALID, "hierarchy reordering lost nodes");
+    B.nodes.swap(all);
+  }
   RT_TRY(up(sc->bvh_nodes, B.nodes.data(), B.nodes.size() * sizeof(BvhNode)));
   RT_TRY(up(sc->bvh_prims, B.prims.data(), B.prims.size() * 4));
   RT_TRY(up(sc->bvh_unbounded, unbounded.data(), unbounded.size() * 4));
   for (int pass = 0; pass < 2; pass++) {
     if (pass == 0) { sc->d32.bvh = sc->bvh_nodes.as<BvhNode>(); sc->d32.bvh_prims = sc->bvh_prims.as<uint32_t>(); sc->d32.unbounded = sc->bvh_unbounded.as<uint32_t>();
-                     sc->d32.n_bvh_nodes = (uint32_t)B.nodes.size(); sc->d32.n_unbounded = (uint32_t)unbounded.size(); }
+                     sc->d32.n_bvh_nodes = n_nodes; sc->d32.bvh_octant_stride = octants ? n_nodes : 0u; sc->d32.n_unbounded = (uint32_t)unbounded.size(); }
     else { sc->d64.bvh = sc->bvh_nodes.as<BvhNode>(); sc->d64.bvh_prims = sc->bvh_prims.as<uint32_t>(); sc->d64.unbounded = sc->bvh_unbounded.as<uint32_t>();
-           sc->d64.n_bvh_nodes = (uint32_t)B.nodes.size(); sc->d64.n_unbounded = (uint32_t)unbounded.size(); }
+           sc->d64.n_bvh_nodes = n_nodes; sc->d64.bvh_octant_stride = octants ? n_nodes : 0u; sc->d64.n_unbounded = (uint32_t)unbounded.size(); }
   }
   built = true;
   return RT_OK;

@@ -60,6 +60,7 @@ template <typename T> struct DevScene {
   const uint32_t *bvh_prims;  // leaf entries: sorted slot | type << 28
   const uint32_t *unbounded;  // entries of the same form for planes and infinite cylinders: always tested
   uint32_t n_bvh_nodes, n_unbounded;
+  uint32_t bvh_octant_stride;    // nodes between the per-octant copies of the hierarchy (0: one copy)
   const float4 *sbound;       // per sorted slot: bounding sphere (centre, radius; +inf = unbounded), fp32 build only, or nullptr
 };
 
@@ -452,9 +453,12 @@ template <typename T, int MODE> RT_D int scan_bvh(const DevScene<T> &S, V3<T> o,
   bool occluded = false;
   for (uint32_t u = 0; u < S.n_unbounded && !occluded; u++) occluded = test(S.unbounded[u]);
   const T ix = T(1) / d.x, iy = T(1) / d.y, iz = T(1) / d.z;
+  // the copy of the node array threaded near child first for this ray's direction octant
+  const uint32_t octant = (d.x < T(0) ? 1u : 0u) | (d.y < T(0) ? 2u : 0u) | (d.z < T(0) ? 4u : 0u);
+  const BvhNode *nodes = S.bvh + (size_t)octant * S.bvh_octant_stride;
   uint32_t i = 0, guard = 0;
   while (i < S.n_bvh_nodes && !occluded && guard++ < 2u * S.n_bvh_nodes) {
-    const BvhNode nd = S.bvh[i];
+    const BvhNode nd = nodes[i];
     // slabs; fmin/fmax return the other operand for a NaN (0 * inf), which keeps the interval conservative
     T t1 = (T(nd.lo[0]) - o.x) * ix, t2 = (T(nd.hi[0]) - o.x) * ix;
     T tn = rt_fmin(t1, t2), tf = rt_fmax(t1, t2);

@@ -41,6 +41,7 @@ struct RtKnobs {
   int no_cull = 0;               // 1: the first pass scans every primitive (no per-workgroup culling)
   int raster_order = 0;          // 1: paths numbered row by row even where 32x8 tiles would fit
   int bvh = -1;                  // hierarchy at upload: -1 by scene size, 0 never, 1 always
+  int bvh_one_order = 0;         // 1: the hierarchy is walked in one child order for every ray (no near-child-first copies)
   int knn_heap = 0;              // 1: k-nearest gathers use the per-lane heap kernel only
   int knn_verbose = 0;
   int probe = 0;

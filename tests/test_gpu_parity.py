@@ -725,6 +725,12 @@ def test_hierarchy_frames_equal_all_primitive_frames(rt):
             assert same_px(x["pre"], y["pre"]).mean() > 0.995
         assert x["stats"]["rays"] == y["stats"]["rays"] or prec == capi.PRECISION_F32
         assert x["stats"]["prim_tests"] * 20 < y["stats"]["prim_tests"]       # > 95 % of the tests avoided
+        # one child order for all rays instead of the near-child-first copy per direction octant: same frame, more tests
+        with ctx.option("bvh_one_order", 1, 0):
+            one = ctx.upload(flat)
+        z = one.trace_tile(q)
+        assert same(x["pre"], z["pre"]) and x["stats"]["rays"] == z["stats"]["rays"]
+        assert x["stats"]["prim_tests"] < z["stats"]["prim_tests"]
 
 
 # ------------------------------------------------------------------ every preset of the reference
