@@ -241,6 +241,11 @@ uint32_t rt_find_median(uint32_t n);        /* kdtree.js:109-124 */
  * indices in the reference's pre-order at idx[q*cap ...]. queries: nq x 3 fp32. */
 int rt_kd_radius(rt_photon_map *map, const float *queries, uint32_t nq, double r, uint32_t cap,
                  uint32_t *count, int32_t *idx);
+/* `nearestNeighbourAndDistance(x)` (kdtree.js:10-62) with the reference's own semantics: the closest node of the one
+ * root-to-leaf path the query descends (the far side of a plane is never searched), idx[q] = input index of that photon,
+ * dist[q] = its distance; `[undefined, undefined]` (a path that leaves through a missing upper child, :13) is -1 / NaN.
+ * The exact nearest photon is rt_kd_knn with k = 1. */
+int rt_kd_nearest_path(rt_photon_map *map, const float *queries, uint32_t nq, int32_t *idx, double *dist);
 /* k nearest photons ordered by (squared distance, input index); slots beyond n hold -1 / +inf.
  * The reference has no k-NN query; the order is defined by brute force (oracle/rt_oracle.c). */
 int rt_kd_knn(rt_photon_map *map, const float *queries, uint32_t nq, uint32_t k, int32_t *idx, double *d2);

@@ -2,7 +2,7 @@
 // TEST INFRASTRUCTURE (oracle harness) -- runs only in the build container (needs the
 // reference checkout); writes data-only fixtures into tests/golden/.
 //
-//   node oracle/harness/gen_golden.js [scenes] [intersect] [closest] [samples] [c1] [c1image]
+//   node oracle/harness/gen_golden.js [scenes] [intersect] [closest] [samples] [nearest] [c1] [c1image]
 //
 // Every number written here is produced by evaluating the reference's own functions
 // (rayphoton.js / kdtree.js) under a keyed Philox Math.random; the only logic restated in
@@ -402,6 +402,55 @@ function genC1(withImage, withScaled) {
   console.log(`c1 image done in ${Date.now() - t0} ms`);
 }
 
+// ---------------------------------------------------------------- nearestNeighbourAndDistance (kdtree.js:10-62)
+function genNearest() {
+  const ND = 10000, NC = 10000;
+  const { L, scene } = buildScene(10, { numDiffuse: ND, numCaustic: NC });
+  emitKeyed(L, scene, ND, NC);                         // the lists of photons_c1 again (same seed, same streams)
+  const rounded = (list, n) => list.slice(0, n).map((p, i) => ({ origin: p.origin.map(Math.fround), __idx: i }));
+  const trees = { diffuse: ['diffuse', 10000], caustic9999: ['caustic', 9999], two: ['diffuse', 2], one: ['diffuse', 1] };
+  // queries: every 7th diffuse photon position, the photons around the middle of the list, and points drawn in the
+  // bounding box of the diffuse map (keyed AUX stream 4100)
+  const dl = rounded(scene.photonListDiffuse, ND);
+  const pts = [];
+  for (let i = 0; i < ND; i += 7) pts.push(dl[i].origin);
+  const lo = [Infinity, Infinity, Infinity], hi = [-Infinity, -Infinity, -Infinity];
+  for (const p of dl) for (let j = 0; j < 3; j++) { lo[j] = Math.min(lo[j], p.origin[j]); hi[j] = Math.max(hi[j], p.origin[j]); }
+  for (let i = 0; i < 2048; i++) {
+    L.rng.setStream(PH.DOMAIN_AUX, 4100, i);
+    pts.push([0, 1, 2].map((j) => Math.fround(lo[j] + (hi[j] - lo[j]) * (1.2 * L.rng.next() - 0.1))));
+  }
+  const out = {}, undef = {};
+  for (const [name, [which, n]] of Object.entries(trees)) {
+    const list = rounded(which === 'diffuse' ? scene.photonListDiffuse : scene.photonListCaustic, n);
+    const owner = new Map(list.map((p) => [p.origin, p.__idx]));
+    const tree = new L.ex.KdTree(list);
+    // every photon of the tree is a query too for the tree's own positions (reaches the node with one child)
+    const qs = pts.concat(list.filter((_, i) => i % 3 === 0 || Math.abs(i - n / 2) < 4).map((p) => p.origin));
+    const q = new Float64Array(qs.length * 3), idx = new Int32Array(qs.length), dist = new Float64Array(qs.length);
+    let nu = 0;
+    qs.forEach((x, i) => {
+      q.set(x, i * 3);
+      const [point, d] = tree.nearestNeighbourAndDistance(x);
+      if (point === undefined) { idx[i] = -1; dist[i] = NaN; nu++; } else { idx[i] = owner.get(point); dist[i] = d; }
+    });
+    // ... and each tree position itself, which is how the node with a single child gets visited
+    const own = new Float64Array(n * 3), oidx = new Int32Array(n), odist = new Float64Array(n);
+    for (let pos = 1; pos <= n; pos++) {
+      const x = tree.nodes[pos].photon.origin;
+      own.set(x, (pos - 1) * 3);
+      const [point, d] = tree.nearestNeighbourAndDistance(x);
+      if (point === undefined) { oidx[pos - 1] = -1; odist[pos - 1] = NaN; nu++; } else { oidx[pos - 1] = owner.get(point); odist[pos - 1] = d; }
+    }
+    out[`${name}_queries`] = { data: q, shape: [qs.length, 3] }; out[`${name}_idx`] = idx; out[`${name}_dist`] = dist;
+    out[`${name}_own_queries`] = { data: own, shape: [n, 3] }; out[`${name}_own_idx`] = oidx; out[`${name}_own_dist`] = odist;
+    undef[name] = nu;
+    console.log(`nearest ${name}: ${qs.length} + ${n} queries, ${nu} undefined`);
+  }
+  writeBundle(path.join(OUT, 'nearest_c1'), out, { trees, undefined_results: undef,
+    note: 'nearestNeighbourAndDistance(x) (kdtree.js:10-62) on trees over the first n fp32-rounded photons of the lists of photons_c1: idx = input index of the returned point (-1 = [undefined, undefined]), dist = the returned distance (NaN = undefined); own_* = the tree nodes positions themselves as queries, in node order' });
+}
+
 PH.selfTest();
 fs.mkdirSync(OUT, { recursive: true });
 const want = new Set(process.argv.slice(2));
@@ -411,4 +460,5 @@ if (want.has('presets')) genPresets();
 if (all || want.has('intersect')) genIntersect();
 if (all || want.has('closest')) genClosest();
 if (all || want.has('samples')) genSamples();
+if (all || want.has('nearest')) genNearest();
 if (all || want.has('c1') || want.has('c1image') || want.has('c1scaled')) genC1(all || want.has('c1image'), all || want.has('c1scaled'));

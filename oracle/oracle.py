@@ -197,6 +197,14 @@ def kd_radius(pos, perm, dim, x, r, cap=4096):
     return out[:n].copy()
 
 
+def kd_nearest(pos, perm, dim, x):
+    """nearestNeighbourAndDistance(x) (kdtree.js:10-62): (input index, distance), or (-1, nan) for [undefined, undefined]"""
+    pos, x = _c(pos, np.float64), _c(x, np.float64)
+    idx, dist = C.c_int32(0), C.c_double(0.0)
+    lib().ora_kd_nearest(_p(pos), C.c_uint32(pos.shape[0]), _p(perm), _p(dim), _p(x), C.byref(idx), C.byref(dist))
+    return idx.value, dist.value
+
+
 def knn_brute(pos, x, k):
     pos, x = _c(pos, np.float64), _c(x, np.float64)
     idx = np.empty(k, np.int32)

@@ -592,8 +592,32 @@ uint32_t ora_kd_radius(const double *pos, uint32_t n, const int32_t *perm, const
   return q.count;
 }
 
+/* nearestNeighbourAndDistance(x, pos) (kdtree.js:10-62): the closest of the nodes on ONE root-to-leaf path (the far side
+ * of a splitting plane is never searched: `if (false)`, :34, :50).  A node past the end gives [undefined, undefined]
+ * (:13), and `dist < undefined` is false (:30, :46), so a path that leaves the tree through a missing upper child
+ * returns undefined all the way up.  Returns 0 and (*idx, *dist), or 1 for [undefined, undefined]. */
+static int nearest_rec(const double *pos, uint32_t n, const int32_t *perm, const uint8_t *dim, const double x[3], uint32_t posn,
+                       int32_t *idx, double *dist) {
+  if (posn > n) return 1;                                              /* pos >= nodes.length */
+  const double *pt = pos + 3 * (size_t)perm[posn - 1];
+  int dm = dim[posn - 1];
+  double d = sqrt(sqlen(minus(ld(x), ld(pt))));                        /* vecLength(vecMinus(x, point)) */
+  if (2 * (uint64_t)posn > n) { *idx = perm[posn - 1]; *dist = d; return 0; }     /* pos * 2 >= nodes.length: leaf */
+  int32_t bi; double bd;
+  int undef = nearest_rec(pos, n, perm, dim, x, (x[dm] < pt[dm]) ? 2 * posn : 2 * posn + 1, &bi, &bd);
+  if (undef) return 1;                                                 /* dist < undefined is false */
+  if (d < bd) { bi = perm[posn - 1]; bd = d; }
+  *idx = bi; *dist = bd;
+  return 0;
+}
+int ora_kd_nearest(const double *pos, uint32_t n, const int32_t *perm, const uint8_t *dim, const double x[3], int32_t *idx, double *dist) {
+  int undef = nearest_rec(pos, n, perm, dim, x, 1, idx, dist);
+  if (undef) { *idx = -1; *dist = NAN; }
+  return undef;
+}
+
 /* k nearest by brute force, ordered by (d2, index).  The reference has no k-NN query (its only
- * NN method, kdtree.js:10-62, is approximate and never called): this ordering is the definition
+ * NN method, kdtree.js:10-62 (ora_kd_nearest above), is approximate and never called): this ordering is the definition
  * the device k-NN is held to.  d2 = dx*dx + dy*dy + dz*dz as vecSqLength(vecMinus(x,p)). */
 void ora_knn_brute(const double *pos, uint32_t n, const double x[3], uint32_t k, int32_t *idx, double *d2) {
   uint32_t m = 0;

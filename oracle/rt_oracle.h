@@ -101,6 +101,8 @@ int ora_kd_build(const double *pos, uint32_t n, int32_t *perm, uint8_t *dim);
 /* radius query in reference pre-order; returns number of hits (may exceed cap; only cap written) */
 uint32_t ora_kd_radius(const double *pos, uint32_t n, const int32_t *perm, const uint8_t *dim,
                        const double x[3], double r, int32_t *out, uint32_t cap);
+/* nearestNeighbourAndDistance(x) (kdtree.js:10-62); returns 1 and (-1, NaN) for [undefined, undefined] */
+int ora_kd_nearest(const double *pos, uint32_t n, const int32_t *perm, const uint8_t *dim, const double x[3], int32_t *idx, double *dist);
 void ora_knn_brute(const double *pos, uint32_t n, const double x[3], uint32_t k, int32_t *idx, double *d2);
 
 /* renderer (mode B).  Photon maps are given as record lists; trees are built inside. */

@@ -28,7 +28,7 @@ EXPORTS = [
     "rt_lists_create", "rt_lists_free", "rt_lists_record_words", "rt_lists_apply", "rt_lists_counts", "rt_lists_export", "rt_lists_view",
     "rt_photon_map_build", "rt_photon_map_build_packed", "rt_photon_map_build_lists", "rt_band_rows",
     "rt_photon_map_free", "rt_photon_map_size", "rt_photon_map_nodes", "rt_kd_build", "rt_find_median",
-    "rt_kd_radius", "rt_kd_knn", "rt_gather_radiance", "rt_gather_radiance_static", "rt_gather_radiance_adaptive", "rt_trace_tile", "rt_trace_rays", "rt_direct_light", "rt_create_photons", "rt_walk_photons",
+    "rt_kd_radius", "rt_kd_knn", "rt_kd_nearest_path", "rt_gather_radiance", "rt_gather_radiance_static", "rt_gather_radiance_adaptive", "rt_trace_tile", "rt_trace_rays", "rt_direct_light", "rt_create_photons", "rt_walk_photons",
 ]
 
 
@@ -491,6 +491,14 @@ class PhotonMap:
         idx = np.full((nq, cap), -1, np.int32)
         self.ctx.check(self.ctx.lib.rt_kd_radius(self.h, _ptr(q), C.c_uint32(nq), C.c_double(r), C.c_uint32(cap), _ptr(count), _ptr(idx)))
         return count, idx
+
+    def nearest_path(self, queries):
+        """nearestNeighbourAndDistance(x) (kdtree.js:10-62) per query: (input index | -1, distance | nan)"""
+        q = _c(queries, np.float32) if isinstance(queries, np.ndarray) else queries
+        nq = q.shape[0]
+        idx, dist = np.empty(nq, np.int32), np.empty(nq, np.float64)
+        self.ctx.check(self.ctx.lib.rt_kd_nearest_path(self.h, _ptr(q), C.c_uint32(nq), _ptr(idx), _ptr(dist)))
+        return idx, dist
 
     def knn(self, queries, k, out_idx=None, out_d2=None):
         q = _c(queries, np.float32) if isinstance(queries, np.ndarray) else queries

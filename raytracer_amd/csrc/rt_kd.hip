@@ -637,6 +637,54 @@ extern "C" int rt_kd_knn(rt_photon_map *m, const float *queries, uint32_t nq, ui
   return RT_OK;
 }
 
+// nearestNeighbourAndDistance(x) (kdtree.js:10-62): the reference never searches the far side of a splitting plane
+// (`if (false)`, :34, :50), so the result is the closest node of ONE root-to-leaf path, settled from the leaf upwards
+// with a strict `<` (:30, :46).  A path that leaves the tree through a missing upper child yields [undefined, undefined]
+// (:13; `dist < undefined` is false all the way up): index -1, distance NaN here.  One lane per query.
+__global__ void __launch_bounds__(256) k_kd_nearest_path(DevMap M, const float *q3, uint32_t nq, int32_t *idx, double *dist) {
+  const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= nq) return;
+  const double x0 = q3[(size_t)q * 3], x1 = q3[(size_t)q * 3 + 1], x2 = q3[(size_t)q * 3 + 2];
+  const uint32_t n = M.n;
+  uint32_t pos = 1;
+  while (2 * (uint64_t)pos <= n) {                         // (:20: a node without children ends the descent)
+    const float4 nd = M.node[pos - 1];
+    const int dim = node_dim(nd);
+    const bool below = ((dim == 0) ? x0 : (dim == 1) ? x1 : x2) < (double)((dim == 0) ? nd.x : (dim == 1) ? nd.y : nd.z);
+    pos = below ? 2 * pos : 2 * pos + 1;
+    if (pos > n) { idx[q] = -1; dist[q] = __builtin_nan(""); return; }
+  }
+  float4 nd = M.node[pos - 1];
+  uint32_t best = pos;
+  double bd = sqrt(sq_dist(x0, x1, x2, (double)nd.x, (double)nd.y, (double)nd.z));
+  for (pos >>= 1; pos >= 1; pos >>= 1) {
+    nd = M.node[pos - 1];
+    const double d = sqrt(sq_dist(x0, x1, x2, (double)nd.x, (double)nd.y, (double)nd.z));
+    if (d < bd) { bd = d; best = pos; }
+  }
+  idx[q] = M.perm[best - 1]; dist[q] = bd;
+}
+
+extern "C" int rt_kd_nearest_path(rt_photon_map *m, const float *queries, uint32_t nq, int32_t *idx, double *dist) {
+  if (!m) return RT_ERR_INVALID;
+  rt_ctx *ctx = m->ctx;
+  if (!queries || !idx || !dist) return rt_fail(ctx, RT_ERR_INVALID, "rt_kd_nearest_path: queries, idx and dist are required");
+  if (nq == 0) return RT_OK;
+  RT_HIP(ctx, hipSetDevice(ctx->device));
+  DevMem tq, ti, td; const void *dq; void *di, *dd;
+  RT_TRY(rt_stage_in(ctx, queries, (size_t)nq * 12, tq, &dq));
+  RT_TRY(rt_stage_out_begin(ctx, idx, (size_t)nq * 4, ti, &di));
+  RT_TRY(rt_stage_out_begin(ctx, dist, (size_t)nq * 8, td, &dd));
+  {
+    KernelTimer timer_(ctx, "kd_nearest_path");
+    hipLaunchKernelGGL(k_kd_nearest_path, dim3(div_up(nq, 256)), dim3(256), 0, ctx->stream, m->view(), (const float *)dq, nq, (int32_t *)di, (double *)dd);
+  }
+  RT_HIP(ctx, hipGetLastError());
+  RT_TRY(rt_stage_out_end(ctx, idx, (size_t)nq * 4, ti));
+  RT_TRY(rt_stage_out_end(ctx, dist, (size_t)nq * 8, td));
+  return RT_OK;
+}
+
 // ------------------------------------------------------------------ fused radiance gathers
 // hits: pos3 normal3 albedo3 (fp32); rgb = sum * albedo/255 / (pi r^2)   (rayphoton.js:1779-1784, :1808-1815)
 __global__ void __launch_bounds__(256) k_gather_radius(DevMap M, const float *hits, uint32_t nq, double r, float *rgb) {

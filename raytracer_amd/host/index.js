@@ -137,10 +137,17 @@ class KdTree {
     return addon().gatherRadianceAdaptive(this.map, hits, r0, grow === undefined ? 3 : grow, minCount === undefined ? 10 : minCount,
       minKeep === undefined ? 3 : minKeep, maxAttempts === undefined ? 10 : maxAttempts);
   }
-  // [point, distance] of the nearest photon.  The reference's version (kdtree.js:10-62) never searches
-  // the far side of a split and is therefore approximate (and never called); this one is exact.
+  // [point, distance] as the reference computes them (kdtree.js:10-62): the closest photon of the ONE root-to-leaf path
+  // the query descends -- the far side of a split is never searched (`if (false)`, :34, :50), so the answer is
+  // approximate -- and [undefined, undefined] where that path leaves the tree through a missing upper child (:13).
+  // The device tree holds fp32 positions: the distance is the one to the photon's rounded position.
   nearestNeighbourAndDistance(x, pos) {
     if (pos !== undefined && pos !== 1) throw new Error('nearestNeighbourAndDistance: sub-tree queries are not offered by the device tree');
+    const res = addon().kdNearestPath(this.map, Float32Array.from(x));
+    return res.idx[0] < 0 ? [undefined, undefined] : [this.photonAt(res.idx[0]).origin, res.dist[0]];
+  }
+  // the exact nearest photon: [point, distance]
+  nearestExact(x) {
     const best = this.kNearest(x, 1)[0];
     return best ? [best.photon.origin, Math.sqrt(best.distSq)] : [undefined, undefined];
   }

@@ -354,6 +354,25 @@ static napi_value KdKnn(napi_env env, napi_callback_info info) {
   return out;
 }
 
+// kdNearestPath(map, queries Float32Array(nq*3)) -> {idx: Int32Array(nq), dist: Float64Array(nq)}   (kdtree.js:10-62)
+static napi_value KdNearestPath(napi_env env, napi_callback_info info) {
+  Args a(env, info);
+  MapBox *mb = a.ext<MapBox>(0);
+  size_t nq3 = 0;
+  const float *q = (const float *)a.typed(1, napi_float32_array, &nq3);
+  if (!mb) return nullptr;
+  if (!q) { napi_throw_type_error(env, nullptr, "kdNearestPath(map, queries)"); return nullptr; }
+  uint32_t nq = (uint32_t)(nq3 / 3);
+  napi_value abi, abd, idx, dist, out; void *id, *dd;
+  NAPI_OK(napi_create_arraybuffer(env, (size_t)nq * 4, &id, &abi)); NAPI_OK(napi_create_typedarray(env, napi_int32_array, nq, abi, 0, &idx));
+  NAPI_OK(napi_create_arraybuffer(env, (size_t)nq * 8, &dd, &abd)); NAPI_OK(napi_create_typedarray(env, napi_float64_array, nq, abd, 0, &dist));
+  int rc = rt_kd_nearest_path(mb->map, q, nq, (int32_t *)id, (double *)dd);
+  if (rc != RT_OK) return fail(env, mb->cb->ctx, rc);
+  NAPI_OK(napi_create_object(env, &out));
+  napi_set_named_property(env, out, "idx", idx); napi_set_named_property(env, out, "dist", dist);
+  return out;
+}
+
 // gatherRadiance(map, hits Float32Array(nq*9), r, k) -> Float32Array(nq*3)
 static napi_value GatherRadiance(napi_env env, napi_callback_info info) {
   Args a(env, info);
@@ -547,7 +566,7 @@ static napi_value ModuleInit(napi_env env, napi_value exports) {
   const struct { const char *name; napi_callback fn; } fns[] = {
     { "init", Init }, { "shutdown", Shutdown }, { "sceneUpload", SceneUpload }, { "intersectPairs", IntersectPairs }, { "intersect", Intersect },
     { "emitMany", EmitMany }, { "photonMapBuild", PhotonMapBuild }, { "photonMapNodes", PhotonMapNodes },
-    { "kdRadius", KdRadius }, { "kdKnn", KdKnn }, { "gatherRadiance", GatherRadiance }, { "gatherRadianceAdaptive", GatherRadianceAdaptive }, { "traceTile", TraceTile },
+    { "kdRadius", KdRadius }, { "kdKnn", KdKnn }, { "kdNearestPath", KdNearestPath }, { "gatherRadiance", GatherRadiance }, { "gatherRadianceAdaptive", GatherRadianceAdaptive }, { "traceTile", TraceTile },
     { "traceRays", TraceRays }, { "directLight", DirectLight }, { "createPhotons", CreatePhotons }, { "walkPhotons", WalkPhotons },
     { "findMedian", FindMedian },
   };

@@ -71,6 +71,26 @@ check('KdTree.nearestNeighbours order', radiusOk);
 let fmOk = true;
 for (let n = 1; n <= 4096 && fmOk; n++) fmOk = scene.photonKdTDiffuse.findMedian(n) === kd.find_median[n - 1];
 check('KdTree.findMedian', fmOk);
+// nearestNeighbourAndDistance: the reference's one-path answer (never closer than the exact one; undefined for a
+// query that leaves a two-photon tree through the missing upper child)
+{
+  const tree = scene.photonKdTDiffuse;
+  let ok = true, same = 0, worstD = 0, closer = 0;
+  for (let i = 0; i < 64; i++) {
+    const x = scene.photonListDiffuse[i * 7].origin.map((v) => v + 0.01 * i);
+    const [p, d] = tree.nearestNeighbourAndDistance(x), [pe, de] = tree.nearestExact(x);
+    ok = ok && p !== undefined;
+    if (p === undefined) continue;
+    if (d < de) closer++;
+    worstD = Math.max(worstD, Math.abs(Math.hypot(...[0, 1, 2].map((j) => Math.fround(p[j]) - Math.fround(x[j]))) - d));   // (fp32 positions and queries)
+    if (p === pe) same++;
+  }
+  check('KdTree.nearestNeighbourAndDistance', ok && closer === 0 && worstD < 1e-12 && same > 8, `defined ${ok}, closer than exact ${closer}, |d - hypot| ${worstD}, same as exact ${same}/64`);
+  const two = new rt.KdTree([{ origin: [0, 0, 0], dir: [0, 0, 1], power: 1, colour: { r: 1, g: 1, b: 1 } },
+    { origin: [1, 0, 0], dir: [0, 0, 1], power: 1, colour: { r: 1, g: 1, b: 1 } }]);
+  const below = two.nearestNeighbourAndDistance([0.2, 0, 0]), above = two.nearestNeighbourAndDistance([5, 0, 0]);
+  check('KdTree.nearestNeighbourAndDistance undefined', below[0] !== undefined && above[0] === undefined && above[1] === undefined);
+}
 let threw = false;
 try { new rt.KdTree([]); } catch (e) { threw = /no data/.test(e.message); }
 check('KdTree([]) throws', threw);

@@ -273,6 +273,44 @@ def test_radius_and_knn_queries_match_reference(rt):
         assert np.array_equal(idx, q[f"knn_{name}_idx"]) and np.array_equal(d2, q[f"knn_{name}_d2"])
 
 
+def test_nearest_neighbour_and_distance_is_the_reference_s(rt):
+    """kdtree.js:10-62 through rt_kd_nearest_path: the reference's own (approximate, one-path) answers on trees of
+    10 000 / 9 999 / 2 / 1 photons, bit for bit, [undefined, undefined] as -1 / NaN; lattice maps (distance ties, one-child
+    nodes at every even size) against the oracle"""
+    capi, ctx = rt
+    ph, g = load_bundle("photons_c1"), load_bundle("nearest_c1")
+    for name, (which, n) in g.meta["trees"].items():
+        m = ctx.photon_map(ph[which][:n])
+        n_undef = 0
+        for pre in (name + "_", name + "_own_"):
+            qs = g[pre + "queries"].astype(np.float32)
+            assert np.array_equal(qs.astype(np.float64), g[pre + "queries"])
+            idx, dist = m.nearest_path(qs)
+            assert np.array_equal(idx, g[pre + "idx"]), pre
+            assert np.array_equal(dist, g[pre + "dist"], equal_nan=True), pre
+            n_undef += int((idx < 0).sum())
+        assert n_undef == g.meta["undefined_results"][name]
+    rng = np.random.default_rng(11)
+    for n in (1, 2, 3, 6, 300, 301):
+        rec = np.zeros((n, 11))
+        rec[:, :3] = rng.integers(-3, 4, (n, 3))
+        rec[:, 6:10] = 1
+        m = ctx.photon_map(rec)
+        perm, dim = ora.kd_build(rec[:, :3])
+        queries = np.concatenate([rng.integers(-4, 5, (200, 3)), rec[:, :3]]).astype(np.float32)
+        idx, dist = m.nearest_path(queries)
+        for i in range(queries.shape[0]):
+            oi, od = ora.kd_nearest(rec[:, :3], perm, dim, queries[i].astype(np.float64))
+            assert idx[i] == oi and (dist[i] == od or (oi < 0 and np.isnan(dist[i]))), (n, i)
+    # the one-path answer is never closer than the exact nearest photon, and is it for most queries of a real map
+    m = ctx.photon_map(ph["diffuse"])
+    qs = g["diffuse_queries"].astype(np.float32)
+    idx, dist = m.nearest_path(qs)
+    _, d2 = m.knn(qs, 1)
+    ok = idx >= 0
+    assert (dist[ok] >= np.sqrt(d2[ok, 0])).all() and (dist[ok] == np.sqrt(d2[ok, 0])).mean() > 0.3
+
+
 def test_knn_ties_small_maps_and_k_edge_cases(rt):
     capi, ctx = rt
     rng = np.random.default_rng(5)

@@ -122,6 +122,26 @@ def test_kd_build_and_queries_match_reference():
             assert np.array_equal(idx, q[f"knn_{name}_idx"][i]) and np.array_equal(d2, q[f"knn_{name}_d2"][i])
 
 
+def test_nearest_neighbour_and_distance_matches_reference():
+    """kdtree.js:10-62 run by the reference on trees of 10 000 / 9 999 / 2 / 1 photons: the closest node of one
+    root-to-leaf path, [undefined, undefined] where the path leaves through a missing upper child"""
+    ph = load_bundle("photons_c1")
+    g = load_bundle("nearest_c1")
+    assert g.meta["undefined_results"]["diffuse"] >= 1 and g.meta["undefined_results"]["two"] > 100
+    for name, (which, n) in g.meta["trees"].items():
+        pos = ph[which][:n, :3].astype(np.float32).astype(np.float64)
+        perm, dim = ora.kd_build(pos)
+        for pre in (name + "_", name + "_own_"):
+            qs, want_i, want_d = g[pre + "queries"], g[pre + "idx"], g[pre + "dist"]
+            step = 1 if qs.shape[0] < 4000 else 3
+            for i in range(0, qs.shape[0], step):
+                idx, dist = ora.kd_nearest(pos, perm, dim, qs[i])
+                assert idx == want_i[i] and (dist == want_d[i] or (idx < 0 and np.isnan(dist) and np.isnan(want_d[i]))), (pre, i)
+        undef = np.flatnonzero(g[name + "_own_idx"] < 0)
+        for i in undef:                                # (with step 3 the single undefined result of a big tree could be skipped)
+            assert ora.kd_nearest(pos, perm, dim, g[name + "_own_queries"][i])[0] == -1
+
+
 def test_kd_build_empty_raises():
     with pytest.raises(ValueError):                  # kdtree.js:6
         ora.kd_build(np.zeros((0, 3)))
