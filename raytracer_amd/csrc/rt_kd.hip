@@ -849,20 +849,20 @@ __device__ __forceinline__ void knn_descend(const DevMap &M, float cx, float cy,
 }
 
 // the photons of the subtree at t_pos into cand[] (level by level: contiguous heap positions); their number
-__device__ __forceinline__ uint32_t knn_load_subtree(const DevMap &M, uint32_t t_pos, float4 *cand, int lane) {
+__device__ __forceinline__ uint32_t knn_load_subtree(const DevMap &M, uint32_t t_pos, float4 *cand, int lane, uint32_t cap = KNN2_CAP) {
   const uint32_t n = M.n;
   uint32_t cnt = 0;
   unsigned long long lo = t_pos, hi = t_pos;
-  while (lo <= n && cnt < KNN2_CAP) {
+  while (lo <= n && cnt < cap) {
     const unsigned long long end = hi < n ? hi : (unsigned long long)n;
-    for (unsigned long long p = lo + lane; p <= end && cnt + (uint32_t)(p - lo) < KNN2_CAP; p += 64) {
+    for (unsigned long long p = lo + lane; p <= end && cnt + (uint32_t)(p - lo) < cap; p += 64) {
       float4 nd = M.node[p - 1]; nd.w = __uint_as_float((uint32_t)(p - 1));
       cand[cnt + (uint32_t)(p - lo)] = nd;
     }
     cnt += (uint32_t)(end - lo + 1);
     lo = 2 * lo; hi = 2 * hi + 1;
   }
-  return cnt > KNN2_CAP ? (uint32_t)KNN2_CAP : cnt;                        // (never cut: the host's depth keeps subtrees within the buffer)
+  return cnt > cap ? cap : cnt;                                            // (never cut: the host's depth keeps subtrees within the buffer)
 }
 
 __global__ void __launch_bounds__(64) k_gather_knn_wave(DevMap M, const float *hits, uint32_t nq, uint32_t k, float radius_scale, uint32_t t_depth, float *rgb,
@@ -1167,24 +1167,37 @@ __global__ void __launch_bounds__(64) k_gather_knn_wave(DevMap M, const float *h
 // photons inside the first ball can be streamed through a 512-entry buffer.  Distances that decide are the fp64
 // sq_dist; the fp32 tests of the walk only have to keep a superset.  Ties at the k-th distance go to the lowest
 // input index, as everywhere.  A query whose stack would overflow goes to the heap kernel's list.
-#define KNN1_PER_LANE (KNN2_CAP / 64)
-// k-th smallest (k >= 1) of the wave's 64 x KNN1_PER_LANE non-negative doubles (absent entries: +infinity), bit by bit
+// (the candidate buffer of this kernel: CAP1 entries, 256 where the subtrees of the descent fit that -- 4 k <= 256 -- which
+// lets six waves share a SIMD's LDS instead of four; the walk waits on one global round trip per step)
+#ifdef RT_KNN_PROBE
+__device__ unsigned long long knn1_probe[8];         // cycles: start, walk, refills, final; [4] waves, [5] refills, [6] walk steps, [7] candidates taken
+#define KNN1_PROBE(k) { long long t1_ = clock64(); pacc[k] += (unsigned long long)(t1_ - pt0); pt0 = t1_; }
+#define KNN1_COUNT(k, v) { pacc[k] += (unsigned long long)(v); }
+#define KNN1_FLUSH() { if (lane == 0) for (int i_ = 0; i_ < 8; i_++) atomicAdd(&knn1_probe[i_], pacc[i_]); }
+#else
+#define KNN1_PROBE(k)
+#define KNN1_COUNT(k, v)
+#define KNN1_FLUSH()
+#endif
+// k-th smallest (k >= 1) of the wave's 64 x PER_LANE non-negative doubles (absent entries: +infinity), bit by bit
 // from the top: the largest v with fewer than k entries below it
-__device__ __forceinline__ double wave_kth_smallest(const double (&d)[KNN1_PER_LANE], uint32_t k) {
+template <int PER_LANE> __device__ __forceinline__ double wave_kth_smallest(const double (&d)[PER_LANE], uint32_t k) {
   unsigned long long ans = 0;
   for (int bit = 62; bit >= 0; bit--) {
     const unsigned long long trial = ans | (1ull << bit);
     uint32_t c = 0;
 #pragma unroll
-    for (int i = 0; i < KNN1_PER_LANE; i++) c += (uint32_t)__popcll(__ballot((unsigned long long)__double_as_longlong(d[i]) < trial));
+    for (int i = 0; i < PER_LANE; i++) c += (uint32_t)__popcll(__ballot((unsigned long long)__double_as_longlong(d[i]) < trial));
     if (c < k) ans = trial;
   }
   return __longlong_as_double((long long)ans);
 }
 
+template <int CAP1>
 __global__ void __launch_bounds__(64) k_gather_knn_single(DevMap M, const float *hits, uint32_t nq, uint32_t k, uint32_t t_depth, float *rgb,
                                                           const uint2 *units, const uint32_t *n_units, uint32_t *heap_list, uint32_t *heap_count) {
-  __shared__ float4 cand[KNN2_CAP];                  // x y z, slot (as bits)
+  constexpr int KNN1_PER_LANE = CAP1 / 64;
+  __shared__ float4 cand[CAP1];                      // x y z, slot (as bits)
   __shared__ uint32_t stack[KNN2_FRONT];
   const int lane = threadIdx.x;
   if (blockIdx.x >= *n_units) return;                // (the grid is an upper bound)
@@ -1194,10 +1207,13 @@ __global__ void __launch_bounds__(64) k_gather_knn_single(DevMap M, const float 
   const float qx = h[0], qy = h[1], qz = h[2];
   const double x0 = qx, x1 = qy, x2 = qz;
   const uint32_t n = M.n;
+#ifdef RT_KNN_PROBE
+  long long pt0 = clock64(); unsigned long long pacc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+#endif
   uint32_t t_pos = 1; float plane_val = 0.f; unsigned long long path = 0;
   static_assert(KNN2_FRONT * sizeof(uint32_t) >= 64 * sizeof(float4), "descent staging needs 1 KB");
   knn_descend(M, qx, qy, qz, t_depth, (float4 *)&stack[0], lane, t_pos, path, plane_val);
-  uint32_t m = knn_load_subtree(M, t_pos, cand, lane);
+  uint32_t m = knn_load_subtree(M, t_pos, cand, lane, CAP1);
   __syncthreads();
   double d[KNN1_PER_LANE];
   auto load_d = [&](uint32_t cnt) {
@@ -1230,8 +1246,10 @@ __global__ void __launch_bounds__(64) k_gather_knn_single(DevMap M, const float 
   if (lane == 0) stack[0] = t_pos >> (t_depth - start_level);
   __syncthreads();
   uint32_t sp = 1; bool failed = false;
+  KNN1_PROBE(0)
   while (sp > 0) {
-    if (m + 64 > KNN2_CAP) {                          // no room for another step: lower tau to the k-th smallest so far
+    if (m + 64 > CAP1) {                              // no room for another step: lower tau to the k-th smallest so far
+      KNN1_PROBE(1)
       load_d(m);
       tau = wave_kth_smallest(d, k);
       set_tau();
@@ -1250,7 +1268,8 @@ __global__ void __launch_bounds__(64) k_gather_knn_single(DevMap M, const float 
         __syncthreads();
       }
       m = m2;
-      if (m + 64 > KNN2_CAP) { failed = true; break; }                       // (hundreds of photons at one and the same distance)
+      KNN1_PROBE(2) KNN1_COUNT(5, 1)
+      if (m + 64 > CAP1) { failed = true; break; }                           // (hundreds of photons at one and the same distance)
     }
     // (the fuller the stack, the fewer nodes a step takes off its top: those are the deepest, which soon end in leaves,
     // and a step can add at most one entry per node it takes)
@@ -1264,6 +1283,7 @@ __global__ void __launch_bounds__(64) k_gather_knn_single(DevMap M, const float 
     const unsigned long long mi = __ballot(inside);
     if (inside) cand[m + lanes_below(mi, lane)] = make_float4(nd.x, nd.y, nd.z, __uint_as_float(pos - 1));
     m += (uint32_t)__popcll(mi);
+    KNN1_COUNT(6, 1) KNN1_COUNT(7, __popcll(mi))
     const int dim = node_dim(nd);
     const float delta = ((dim == 0) ? ddx : (dim == 1) ? ddy : ddz);        // query minus plane
     const bool reachable = delta * delta <= tauf;
@@ -1287,6 +1307,7 @@ __global__ void __launch_bounds__(64) k_gather_knn_single(DevMap M, const float 
     return;
   }
   // ---- the k nearest among the candidates
+  KNN1_PROBE(1)
   __syncthreads();
   load_d(m);
   const double vk = wave_kth_smallest(d, k);        // the k-th neighbour's squared distance
@@ -1329,6 +1350,7 @@ __global__ void __launch_bounds__(64) k_gather_knn_single(DevMap M, const float 
     rgb[(size_t)q * 3 + 1] = sg * (h[7] / 255.0f) * inv_area;
     rgb[(size_t)q * 3 + 2] = sb * (h[8] / 255.0f) * inv_area;
   }
+  KNN1_PROBE(3) KNN1_COUNT(4, 1) KNN1_FLUSH()
 }
 
 // ---- scratch of the k-nearest gather: counters, the unit queues of the two split levels (8- and 1-query
@@ -1401,8 +1423,13 @@ static int gather_knn_run(rt_photon_map *m, const float *dh, uint32_t nq, uint32
       RT_LAUNCH(ctx, level == 0 ? "gather_knn" : "gather_knn_split", k_gather_knn_wave, launched[level], 64, m->view(), dh, nq, k, scale, t_depth, dout,
                 level == 0 ? (const uint2 *)nullptr : (const uint2 *)queue[level - 1], level == 0 ? (const uint32_t *)nullptr : (const uint32_t *)(counters + level - 1), Q);
     } else {                                                               // single queries: one wave each, streaming
-      RT_LAUNCH(ctx, "gather_knn_single", k_gather_knn_single, launched[level], 64, m->view(), dh, nq, k, t_depth, dout,
-                (const uint2 *)queue[1], (const uint32_t *)(counters + 1), heap_list, counters + 3);
+      if (4 * k <= 256) {
+        RT_LAUNCH(ctx, "gather_knn_single", k_gather_knn_single<256>, launched[level], 64, m->view(), dh, nq, k, t_depth, dout,
+                  (const uint2 *)queue[1], (const uint32_t *)(counters + 1), heap_list, counters + 3);
+      } else {
+        RT_LAUNCH(ctx, "gather_knn_single", k_gather_knn_single<KNN2_CAP>, launched[level], 64, m->view(), dh, nq, k, t_depth, dout,
+                  (const uint2 *)queue[1], (const uint32_t *)(counters + 1), heap_list, counters + 3);
+      }
     }
     RT_HIP(ctx, hipMemcpyAsync(ctx->pinned, counters, 32, hipMemcpyDeviceToHost, ctx->stream));
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1423,6 +1450,12 @@ static int gather_knn_run(rt_photon_map *m, const float *dh, uint32_t nq, uint32
     const double w = hp[6] ? (double)hp[6] : 1.0;
     fprintf(stderr, "knn probe per wave: bound %.0f walk %.0f check %.0f search %.0f ties %.0f sum %.0f cycles; passes %.2f candidates %.1f (%llu waves)\n",
             hp[5] / w, hp[0] / w, hp[1] / w, hp[2] / w, hp[3] / w, hp[4] / w, hp[7] / w, hp[8] / w, hp[6]);
+    unsigned long long h1[8], zero1[8] = { 0 };
+    RT_HIP(ctx, hipMemcpyFromSymbol(h1, HIP_SYMBOL(knn1_probe), sizeof h1));
+    RT_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(knn1_probe), zero1, sizeof zero1));
+    const double w1 = h1[4] ? (double)h1[4] : 1.0;
+    fprintf(stderr, "single-query probe per wave: start %.0f walk %.0f refills %.0f final %.0f cycles; refills %.2f, walk steps %.1f, candidates taken %.1f (%llu waves)\n",
+            h1[0] / w1, h1[1] / w1, h1[2] / w1, h1[3] / w1, h1[5] / w1, h1[6] / w1, h1[7] / w1, h1[4]);
   }
 #endif
   if (K.knn_verbose)
