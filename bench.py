@@ -431,7 +431,7 @@ def main():
                        "frac": g_achieved / PEAK_HBM_GBS, "traffic": measured_traffic("k_gather_knn_wave"),
                        "algorithmic_bytes_per_gather": BYTES_PER_GATHER, "avg_launch_ms": g_ms / g_launches,
                        "whole_call": {"ms": gdt / gsteps * 1e3, "frac": hits.shape[0] * BYTES_PER_GATHER / (gdt / gsteps) / 1e9 / PEAK_HBM_GBS,
-                                      "note": "every launch of rt_gather_radiance (first pass, the units cut into quarters, single queries) and the host's counter read-backs between them"}}
+                                      "note": "every launch of rt_gather_radiance (first pass, the units cut into eighths, single queries) and the host's counter read-backs between them"}}
         # the same gather on less friendly inputs: the queries in raster order instead of 8x8 tiles, and a real emitted map
         # (the default scene's caustic + diffuse photons) queried at the frame's own first-hit points
         order = np.arange(W * H).reshape(H // 8, 8, W // 8, 8).transpose(0, 2, 1, 3).reshape(-1) if (H % 8 == 0 and W % 8 == 0) else None
