@@ -91,7 +91,7 @@ int rt_init(const int *device_ids, int n, rt_ctx **out) {
       return RT_ERR_HIP;
     }
   // the experiment switches: the environment is read here, once per context
-  static const char *names[] = { "tail_threshold", "whole_frame", "bounce_passes", "tail_handoff", "tail_rounds", "tail_persistent", "no_lds", "no_cull", "raster_order", "bvh", "bvh_one_order", "knn_heap",
+  static const char *names[] = { "tail_threshold", "whole_frame", "bounce_passes", "tail_handoff", "tail_rounds", "tail_persistent", "no_lds", "no_cull", "raster_order", "bvh", "bvh_one_order", "wave_gather", "defer_gathers", "gather_sort", "gather_split", "knn_heap",
                                  "knn_verbose", "probe", "knn_radius_scale" };
   for (const char *nm : names) {
     std::string env = "RT355_";
@@ -130,6 +130,10 @@ int rt_set_option(rt_ctx *ctx, const char *name, double value) {
   else if (n == "raster_order") K.raster_order = value != 0;
   else if (n == "bvh") K.bvh = (int)value;
   else if (n == "bvh_one_order") K.bvh_one_order = value != 0;
+  else if (n == "wave_gather") K.wave_gather = value;
+  else if (n == "defer_gathers") K.defer_gathers = value != 0;
+  else if (n == "gather_sort") K.gather_sort = value != 0;
+  else if (n == "gather_split") K.gather_split = (int)value;
   else if (n == "knn_heap") K.knn_heap = value != 0;
   else if (n == "knn_verbose") K.knn_verbose = value != 0;
   else if (n == "probe") K.probe = value != 0;

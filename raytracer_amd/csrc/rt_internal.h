@@ -42,6 +42,11 @@ struct RtKnobs {
   int raster_order = 0;          // 1: paths numbered row by row even where 32x8 tiles would fit
   int bvh = -1;                  // hierarchy at upload: -1 by scene size, 0 never, 1 always
   int bvh_one_order = 0;         // 1: the hierarchy is walked in one child order for every ray (no near-child-first copies)
+  double wave_gather = 8;        // unsorted request queue (gather_sort = 0): a wave serves its 64 requests together while the box of their search
+                                 // balls is within this many ball areas (0: every lane gathers on its own)
+  int defer_gathers = 1;         // fp32 frames with photon maps: the gathers go through a request queue and kernels of their own
+  int gather_sort = 1;           // the requests are served in the order of their positions
+  int gather_split = 4096;       // ... and subtrees of the maps of at most this many photons are work items of their own (0: one wave per 64 requests does it all)
   int knn_heap = 0;              // 1: k-nearest gathers use the per-lane heap kernel only
   int knn_verbose = 0;
   int probe = 0;
@@ -125,10 +130,12 @@ struct rt_scene {
   DevScene<float> d32; DevScene<double> d64;
   // per-scene workspaces (grow-only) so that steady-state calls do not allocate
   // rt_trace_tile's workspaces, one set per frame in flight
-  struct TraceWs { DevMem paths, queue, ctr, masks, blocks, levels; } tws[RT_MAX_IN_FLIGHT];
+  struct TraceWs { DevMem paths, queue, ctr, masks, blocks, levels, gq, gacc, gsort, gtemp, gitems; } tws[RT_MAX_IN_FLIGHT];
   int next_slot = 0;
   DevMem ws_emit_kind, ws_emit_rec, ws_emit_seg, ws_emit_blocks, ws_emit_shard, ws_misc;
 };
+
+int rt_sort_pairs_u64(rt_ctx *ctx, DevMem &temp, const unsigned long long *keys_in, unsigned long long *keys_out, const uint32_t *vals_in, uint32_t *vals_out, uint32_t n);
 
 // ---- photon map ----
 struct rt_photon_map {

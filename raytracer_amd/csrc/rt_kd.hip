@@ -38,6 +38,16 @@ __host__ __device__ static inline uint32_t find_median(uint32_t n) {     // kdtr
 }
 extern "C" uint32_t rt_find_median(uint32_t n) { return find_median(n); }
 
+// stable radix sort of (64-bit key, 32-bit value) pairs on the context's stream; temp grows as needed
+int rt_sort_pairs_u64(rt_ctx *ctx, DevMem &temp, const unsigned long long *keys_in, unsigned long long *keys_out, const uint32_t *vals_in, uint32_t *vals_out, uint32_t n) {
+  if (n == 0) return RT_OK;
+  size_t bytes = 0;
+  RT_HIP(ctx, rocprim::radix_sort_pairs(nullptr, bytes, keys_in, keys_out, vals_in, vals_out, n, 0, 64, ctx->stream));
+  RT_HIP(ctx, temp.reserve(bytes ? bytes : 16));
+  RT_HIP(ctx, rocprim::radix_sort_pairs(temp.p, bytes, keys_in, keys_out, vals_in, vals_out, n, 0, 64, ctx->stream));
+  return RT_OK;
+}
+
 // ------------------------------------------------------------------ build kernels
 __device__ __forceinline__ uint32_t sortable(float x) {
   if (x == 0.0f) x = 0.0f;                         // -0 and +0 compare equal in the reference's comparator

@@ -126,6 +126,7 @@ static int trace_tile_mode(rt_scene *sc, int slot, const rt_params *p, DevMap md
   C.shadow_bias = p->shadow_bias > 0 ? p->shadow_bias : C.epsilon;
   C.max_depth = p->max_depth; C.sub_sample = p->sub_sample; C.use_direct_light = p->use_direct_light;
   C.use_photon_maps = p->use_photon_maps; C.max_bounces = p->max_bounces > 0 ? p->max_bounces : 4096;
+  C.wave_gather_ratio = (float)ctx->knobs.wave_gather;
   C.seed = p->seed; C.x0 = x0; C.y0 = y0; C.w = wb; C.h = hb; C.block = blk; C.n_paths = (uint32_t)n_paths;
   C.magic_w = (uint32_t)(0x100000000ull / (uint64_t)wb); C.magic_ss = (uint32_t)(0x100000000ull / (uint64_t)(p->sub_sample * p->sub_sample));
   C.magic_s = (uint32_t)(0x100000000ull / (uint64_t)p->sub_sample);
@@ -135,6 +136,20 @@ static int trace_tile_mode(rt_scene *sc, int slot, const rt_params *p, DevMap md
   C.band_first = band_shift ? (uint32_t)(p->band_rows * p->band_index) : 0u;
   C.fuse_resolve = (!WHITTED && p->sub_sample == 1) ? 1 : 0; C.pre = pre; C.post = post; C.rgba8 = rgba8;
   if (!p->use_photon_maps) { md.n = 0; mc.n = 0; }
+  C.gq = nullptr; C.gq_count = nullptr; C.gq_cap = 0; C.gacc = nullptr; C.gq_order = nullptr;
+  bool defer = false;
+  if constexpr (sizeof(T) == 4 && FULL && !WHITTED) {
+    defer = K.defer_gathers && p->use_photon_maps && (md.n || mc.n);
+    if (defer) {                                              // request queue (a counter in its first 256 bytes) and per-path accumulators
+      const uint32_t gq_cap = (uint32_t)std::max<size_t>(2 * n_paths, 4096);      // (requests beyond it are gathered where they are shaded)
+      RT_HIP(ctx, W.gq.reserve(256 + (size_t)gq_cap * 48));
+      RT_HIP(ctx, W.gacc.reserve(n_paths * 3 * 8));
+      C.gq_count = W.gq.as<uint32_t>(); C.gq = (float4 *)((char *)W.gq.p + 256); C.gq_cap = gq_cap; C.gacc = W.gacc.as<long long>();
+      RT_HIP(ctx, hipMemsetAsync(C.gq_count, 0, 16, ctx->stream));      // requests, work items, item cursor
+      RT_HIP(ctx, hipMemsetAsync(C.gacc, 0, n_paths * 3 * 8, ctx->stream));
+      C.fuse_resolve = 0;                                     // the resolve pass adds the accumulators
+    }
+  }
   T *levels = nullptr;
   if (WHITTED) {      // one record of 4 values per path and recursion level (levels 0 .. max_depth)
     if (p->max_depth < 0 || p->max_depth > 255) return rt_fail(ctx, RT_ERR_INVALID, "max_depth %d outside [0, 255]", p->max_depth);
@@ -256,6 +271,31 @@ static int trace_tile_mode(rt_scene *sc, int slot, const rt_params *p, DevMap md
       if (ub == 0) break;
     }
   }
+  if (defer) {
+    // the requests sorted by position, so that the 64 a wave serves are neighbours (hits after a bounce arrive in any order)
+    if (K.gather_sort) {
+      RT_HIP(ctx, W.gsort.reserve((size_t)C.gq_cap * 24));
+      unsigned long long *kin = W.gsort.as<unsigned long long>(), *kout = kin + C.gq_cap;
+      uint32_t *vin = (uint32_t *)(kout + C.gq_cap), *vout = vin + C.gq_cap;
+      const double rmax = std::max(md.n ? p->diffuse_radius : 0.0, mc.n ? p->caustic_radius : 0.0);
+      const float inv_cell = rmax > 0 ? (float)(4.0 / rmax) : 1.0f;
+      RT_LAUNCH(ctx, "gather_keys", k_gather_keys, div_up(C.gq_cap, 256), 256, C, inv_cell, kin, vin);
+      { KernelTimer timer_(ctx, "gather_sort"); RT_TRY(rt_sort_pairs_u64(ctx, W.gtemp, kin, kout, vin, vout, C.gq_cap)); }
+      C.gq_order = vout;
+    }
+    // subtrees of at most ~4096 photons become work items of their own (option gather_split = that size; 0: no splitting)
+    GatherItems items; items.items = nullptr; items.count = C.gq_count + 1; items.cap = 0; items.tag = 0;
+    int split_d = 0, split_c = 0;
+    if (K.gather_sort && K.gather_split > 0) {
+      auto depth_for = [&](uint32_t n) { int d = 0; while (((uint64_t)n >> d) > (uint64_t)K.gather_split && d < 24) d++; return d; };
+      split_d = md.n ? depth_for(md.n) : 0; split_c = mc.n ? depth_for(mc.n) : 0;
+      items.cap = (uint32_t)std::min<size_t>(std::max<size_t>(n_paths, 1u << 16), 1u << 22);
+      RT_HIP(ctx, W.gitems.reserve((size_t)items.cap * 8));
+      items.items = W.gitems.as<uint2>();
+    }
+    RT_LAUNCH(ctx, "gather_deferred", k_gather_deferred, div_up(C.gq_cap, 256), 256, C, md, mc, items, split_d, split_c);
+    if (items.cap) RT_LAUNCH(ctx, "gather_items", k_gather_items, 256 * 3, 256, C, md, mc, items, C.gq_count + 2);
+  }
   if (WHITTED)
     RT_LAUNCH(ctx, "resolve", k_resolve_a<T>, div_up(n_pixels, 256), 256, P, C, levels, (uint32_t)n_paths, (int)p->max_depth, (int)n_pixels,
               (int)p->sub_sample, pre, post, rgba8);
@@ -368,6 +408,7 @@ int pl_trace_rays(rt_scene *sc, const rt_params *p, DevMap md, DevMap mc, uint32
   C.shadow_bias = p->shadow_bias > 0 ? p->shadow_bias : C.epsilon;
   C.max_depth = p->max_depth; C.sub_sample = 1; C.use_direct_light = p->use_direct_light;
   C.use_photon_maps = p->use_photon_maps; C.max_bounces = p->max_bounces > 0 ? p->max_bounces : 4096;
+  C.wave_gather_ratio = (float)ctx->knobs.wave_gather;
   C.seed = p->seed; C.block = 1; C.n_paths = n;
   // one row of n "pixels" starting at column first_stream: path i then keys its stream with first_stream + i
   C.x0 = (int32_t)first_stream; C.y0 = 0; C.w = (int32_t)n; C.h = 1;

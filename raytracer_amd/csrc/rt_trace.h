@@ -69,6 +69,7 @@ RT_D void store_path_lds(uint32_t *L, uint32_t n, uint32_t s, const PathState<fl
 struct TraceCfg {
   double epsilon, max_trace_dist, diffuse_radius, caustic_radius, standard_lamp_area, shadow_bias;
   int32_t max_depth, sub_sample, use_direct_light, use_photon_maps, max_bounces;
+  float wave_gather_ratio;       // > 0: first hits gather their photon sums wave by wave while the box of a wave's balls is within this many ball areas
   uint64_t seed;
   int32_t x0, y0, w, h;               // tile origin (canvas pixels); columns and rows of traced samples
   int32_t block;                      // canvas pixels per traced sample along each axis (1 = every pixel)
@@ -88,7 +89,15 @@ struct TraceCfg {
   // belong to one rank, band_first + j * band_period for j = 0, 1, ...; traced row r (and the outputs, which hold the
   // traced rows only) maps to tile row (r >> band_shift) * band_period + band_first + (r & (2^band_shift - 1)).
   uint32_t band_shift, band_period, band_first;
+  // fp32 frames with photon maps: hits after the first (and first hits a wave could not gather together) do not walk
+  // the maps where they are shaded -- one lane walking for thousands of steps while the rest of its wave waits -- but
+  // leave a request (3 x float4: point + path, normal, albedo / 255) in gq; k_gather_deferred serves the requests with
+  // every lane busy and adds the results to the path's entry of gacc (fixed point, 2^-24: the order of the additions
+  // does not matter), which the resolve pass adds to the path's colour.  gq == nullptr: gathers where they are shaded.
+  float4 *gq; uint32_t *gq_count; uint32_t gq_cap; long long *gacc;
+  const uint32_t *gq_order;      // requests in the order k_gather_deferred serves them (sorted by position), or nullptr
 };
+#define RT_GACC_SCALE 16777216.0
 // row of the tile that traced row `row` stands for
 RT_D uint32_t band_row(const TraceCfg &C, uint32_t row) {
   if (!C.band_shift) return row;
@@ -273,6 +282,132 @@ RT_D V3<T> gather_map(const DevMap &M, V3<T> x, V3<T> normal, double r) {
   return mk<T>(sr, sg, sb);
 }
 
+
+// ---- the same radiance estimate for the 64 surface points of a wave at once (fp32 build, first hits of a frame).
+// Primary rays of one wave hit neighbouring points, so their search balls overlap almost completely: instead of 64
+// divergent tree walks, ONE cooperative walk over the bounding box of the balls collects every photon inside it into
+// LDS (position and payload, one node per lane and step), and whenever the buffer fills every lane adds the candidates
+// within its own ball.  Which photons a lane adds is decided as in gather_map -- the fp64 `d2 < r^2` of
+// kdtree.js:75 -- through an fp32 distance with an error band (fp64 only for candidates inside the band), so the set
+// is identical; the order of the additions is not, hence a tolerance against the one-lane gather, not identity.
+#define RT_WG_CAP 256                      // candidates per wave
+#define RT_WG_FRONT 256                    // node queue per wave (a ring)
+// LDS written by some lanes of a wave is read by others: order the accesses (the waves of a workgroup run this code
+// independently, so no workgroup barrier)
+#define RT_WAVE_SYNC() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
+struct WaveGatherLds { float4 cand[RT_WG_CAP]; float pay[RT_WG_CAP * 6]; uint32_t front[RT_WG_FRONT]; };
+
+RT_D float wg_min(float v) { for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64)); return v; }
+RT_D float wg_max(float v) { for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64)); return v; }
+
+// Work items of the split gather: the subtree at heap position `y` of map (x >> 31) for the 64 requests of wave
+// (x & 0x7FFFFFFF) of the sorted request queue.
+struct GatherItems { uint2 *items; uint32_t *count; uint32_t cap; uint32_t tag; };
+
+// Every lane of the wave must call (need = false: the lane has no point).  false: the points are too far apart for one
+// walk to pay (max_area_ratio > 0 only) -- nothing was computed and the caller gathers lane by lane.
+// The walk covers the subtree at heap position `start`.  With `split`, subtrees at depth split_depth are not walked but
+// appended to the item queue (tagged split->tag) for other waves to serve -- a gather next to a lamp has a million
+// photons in its ball, and one wave takes 64 nodes per global round trip.
+RT_D bool gather_map_wave(const DevMap &M, bool need, V3<float> x, V3<float> nrm, double r, float max_area_ratio, WaveGatherLds &L, V3<float> &sum,
+                          uint32_t start = 1u, int split_depth = -1, const GatherItems *split = nullptr) {
+  const int lane = threadIdx.x & 63;
+  sum = mk<float>(0.f, 0.f, 0.f);
+  if (!__any(need)) return true;
+  const uint32_t n = M.n;
+  const float inf = 3.4e38f;
+  // box of the balls, rounded outwards (the walk only has to find a superset)
+  const float lo0 = wg_min(need ? __double2float_rd((double)x.x - r) : inf), lo1 = wg_min(need ? __double2float_rd((double)x.y - r) : inf),
+              lo2 = wg_min(need ? __double2float_rd((double)x.z - r) : inf);
+  const float hi0 = wg_max(need ? __double2float_ru((double)x.x + r) : -inf), hi1 = wg_max(need ? __double2float_ru((double)x.y + r) : -inf),
+              hi2 = wg_max(need ? __double2float_ru((double)x.z + r) : -inf);
+  {
+    // photons lie on surfaces: the walk's work goes with the box's two largest extents, a lane's own with pi r^2
+    const float b0 = hi0 - lo0, b1 = hi1 - lo1, b2 = hi2 - lo2;
+    const float bmax = fmaxf(b0, fmaxf(b1, b2)), bmin = fminf(b0, fminf(b1, b2));
+    const float area = bmax * (b0 + b1 + b2 - bmax - bmin);
+    if (max_area_ratio > 0.f && area > max_area_ratio * 3.14159265f * (float)(r * r)) return false;
+  }
+  const double r2 = r * r;
+  const float r2lo = (float)(r2 * (1.0 - 1e-6)), r2hi = (float)(r2 * (1.0 + 1e-6));      // fp32 d2 is within 3e-7 (relative) of the fp64 one
+  float sr = 0.f, sg = 0.f, sb = 0.f;
+  uint32_t m = 0;
+  auto consume = [&]() {
+    RT_WAVE_SYNC()
+    for (uint32_t j = 0; j < m; j++) {
+      const float4 cd = L.cand[j];
+      const float dx = x.x - cd.x, dy = x.y - cd.y, dz = x.z - cd.z;
+      const float d2f = dx * dx + dy * dy + dz * dz;
+      bool in = d2f < r2lo;
+      if (__any(need && !in && d2f < r2hi))             // (wave-uniform; rare)
+        in = sq_dist((double)x.x, (double)x.y, (double)x.z, (double)cd.x, (double)cd.y, (double)cd.z) < r2;
+      const float *pl = L.pay + j * 6;
+      float w = pl[0] * nrm.x + pl[1] * nrm.y + pl[2] * nrm.z;
+      w = (in && need && w > 0.f) ? w : 0.f;
+      sr += pl[3] * w; sg += pl[4] * w; sb += pl[5] * w;
+    }
+    m = 0;
+    RT_WAVE_SYNC()
+  };
+  RT_WAVE_SYNC()                                       // (the buffers may still be read by a gather before this one)
+  if (lane == 0) L.front[0] = start;
+  RT_WAVE_SYNC()
+  uint32_t head = 0, tail = 1;
+  bool overflow = false;
+  while (head != tail) {
+    if (m + 64 > RT_WG_CAP) consume();
+    const uint32_t size = tail - head;
+    const bool lifo = size > RT_WG_FRONT / 2;          // a wide level: take the deepest nodes, and only as many as leave room for their children
+    const uint32_t take = lifo ? min(64u, max(1u, (RT_WG_FRONT - size) / 2u)) : min(64u, size);
+    const bool active = (uint32_t)lane < take;
+    const uint32_t pos = active ? L.front[((lifo ? tail - take : head) + lane) % RT_WG_FRONT] : 1u;      // 1 <= pos <= n by construction
+    if (lifo) tail -= take; else head += take;
+    const float4 nd = M.node[pos - 1];
+    const bool inside = active && nd.x >= lo0 && nd.x <= hi0 && nd.y >= lo1 && nd.y <= hi1 && nd.z >= lo2 && nd.z <= hi2;
+    const unsigned long long mi = __ballot(inside);
+    if (inside) {
+      const uint32_t at = m + (uint32_t)__popcll(mi & (((unsigned long long)1 << lane) - 1));
+      L.cand[at] = nd;
+      const float2 *pp = (const float2 *)(M.pay + (size_t)(pos - 1) * 6);      // 24-byte records: 8-byte aligned
+      const float2 p0 = pp[0], p1 = pp[1], p2 = pp[2];
+      float *dst = L.pay + at * 6;
+      dst[0] = p0.x; dst[1] = p0.y; dst[2] = p1.x; dst[3] = p1.y; dst[4] = p2.x; dst[5] = p2.y;
+    }
+    m += (uint32_t)__popcll(mi);
+    const int dim = node_dim(nd);
+    const float pd = (dim == 0) ? nd.x : (dim == 1) ? nd.y : nd.z;
+    const float lod = (dim == 0) ? lo0 : (dim == 1) ? lo1 : lo2, hid = (dim == 0) ? hi0 : (dim == 1) ? hi1 : hi2;
+    // kdtree.js:70-73 for a box: left only if the box ends before the plane, right only if it starts after it
+    bool gl = active && 2ull * pos <= n && !(lod > pd);
+    bool gr = active && 2ull * pos + 1 <= n && !(hid < pd);
+    const bool at_split = split && active && (31 - __clz((int)pos)) + 1 == split_depth;     // (the nodes of a step may lie on different levels)
+    if (__any(at_split && (gl || gr))) {                                               // (wave-uniform)
+      // these children are other waves' work: one item each, while the queue has room
+      const uint32_t mine = at_split ? (gl ? 1u : 0u) + (gr ? 1u : 0u) : 0u;
+      uint32_t before = mine;                                                          // inclusive prefix sum over the lanes
+      for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(before, o, 64); if (lane >= o) before += v; }
+      const uint32_t all = __shfl(before, 63, 64);
+      uint32_t base = 0;
+      if (lane == 0) base = atomicAdd(split->count, all);
+      base = __shfl(base, 0, 64) + before - mine;
+      if (at_split && gl) { if (base < split->cap) { split->items[base] = make_uint2(split->tag, 2 * pos); gl = false; } base++; }
+      if (at_split && gr) { if (base < split->cap) { split->items[base] = make_uint2(split->tag, 2 * pos + 1); gr = false; } }
+    }
+    const unsigned long long ml = __ballot(gl), mr = __ballot(gr);
+    const uint32_t cl = (uint32_t)__popcll(ml), cr = (uint32_t)__popcll(mr);
+    if (tail - head + cl + cr > RT_WG_FRONT) { overflow = true; break; }
+    RT_WAVE_SYNC()
+    if (gl) L.front[(tail + (uint32_t)__popcll(ml & (((unsigned long long)1 << lane) - 1))) % RT_WG_FRONT] = 2 * pos;
+    if (gr) L.front[(tail + cl + (uint32_t)__popcll(mr & (((unsigned long long)1 << lane) - 1))) % RT_WG_FRONT] = 2 * pos + 1;
+    tail += cl + cr;
+    RT_WAVE_SYNC()
+  }
+  if (overflow) return false;
+  consume();
+  sum = mk<float>(sr, sg, sb);
+  return true;
+}
+
 template <typename T> RT_D void finish_path(T *out, V3<T> acc, V3<T> term, T term_a, bool alpha_fixed) {
   out[0] = acc.x + term.x; out[1] = acc.y + term.y; out[2] = acc.z + term.z;
   out[3] = alpha_fixed ? T(1) : term_a;
@@ -332,8 +467,28 @@ RT_D bool shade_body(const DevScene<T> &S, const ScanSrc<T> &G, const TraceCfg &
         if (FULL) {
           V3<T> diff = ZERO, caus = ZERO;
           if (C.use_photon_maps) {
-            if (Md.n) { diff = gather_map<T>(Md, hit, n, C.diffuse_radius); tally.gathers++; }
-            if (Mc.n) { caus = gather_map<T>(Mc, hit, n, C.caustic_radius); tally.gathers++; }
+            int todo = (Md.n ? 1 : 0) | (Mc.n ? 2 : 0);                // maps still to be gathered for this hit
+            if constexpr (sizeof(T) == 4) {
+              if (todo && C.gq) {
+                // one slot per lane that is here, reserved by the first of them
+                const unsigned long long here = __ballot(true);
+                const int lane = threadIdx.x & 63, leader = __ffsll((long long)here) - 1;
+                uint32_t base = 0;
+                if (lane == leader) base = atomicAdd(C.gq_count, (uint32_t)__popcll(here));
+                base = __shfl(base, leader, 64);
+                const uint32_t slot = base + (uint32_t)__popcll(here & (((unsigned long long)1 << lane) - 1));
+                if (slot < C.gq_cap) {                                                     // (else: gathered here, below)
+                  float4 *q = C.gq + (size_t)slot * 3;
+                  q[0] = make_float4(hit.x, hit.y, hit.z, __uint_as_float(p));
+                  q[1] = make_float4(n.x, n.y, n.z, __uint_as_float((uint32_t)todo | ((uint32_t)bounce << 2)));
+                  q[2] = make_float4(local.x / T(255), local.y / T(255), local.z / T(255), 0.f);
+                  todo = 0;
+                }
+              }
+            }
+            if (todo & 1) diff = gather_map<T>(Md, hit, n, C.diffuse_radius);
+            if (todo & 2) caus = gather_map<T>(Mc, hit, n, C.caustic_radius);
+            tally.gathers += (Md.n ? 1 : 0) + (Mc.n ? 1 : 0);
           }
           const T PI_ = T(3.141592653589793);
           const T dArea = PI_ * T(C.diffuse_radius * C.diffuse_radius), cArea = PI_ * T(C.caustic_radius * C.caustic_radius);
@@ -591,18 +746,18 @@ __global__ void __launch_bounds__(256) k_primary(DevScene<T> S, PathSoA<T> P, Tr
   bool alive = false;
   ShadeTally tally;
   PathState<T> st;
+  T t = T(0); int idx = -1;
   if (p < count) {
     if (!C.subq_cap) queue[p] = p;                                       // identity queue for the ordered compaction
     st = raygen_path<T>(S, C, p);
-    T t; int idx;
     if constexpr (OT) {
       if (culled) idx = scan_fast_visible<WHITTED ? 3 : 0>(G, vis, vseg, st.d, (float)C.epsilon, t);
       else idx = scan_scene<T, WHITTED ? 3 : 0, OT>(S, G, st.o, st.d, T(C.epsilon), T(0), t, &tally.tests);
     } else {
       idx = scan_scene<T, WHITTED ? 3 : 0, OT>(S, G, st.o, st.d, T(C.epsilon), T(0), t, &tally.tests);
     }
-    alive = shade_step<T, WHITTED, FULL>(S, G, P, C, Md, Mc, levels, p, st, t, idx, 0, tally);
   }
+  if (p < count) alive = shade_step<T, WHITTED, FULL>(S, G, P, C, Md, Mc, levels, p, st, t, idx, 0, tally);
   if (alive) store_path<T>(P, p, st);
   if constexpr (OT) {
     // tests executed by this workgroup's primary rays (workgroup-uniform list length): one atomic per workgroup
@@ -891,6 +1046,105 @@ __global__ void __launch_bounds__(256) k_tail_persistent(DevScene<T> S, PathSoA<
   flush_tally(tally, ctr);
 }
 
+// (diffuse sum / diffuse area + caustic sum / caustic area) x albedo (rayphoton.js:1808-1815) into the path's
+// fixed-point accumulators; partial sums of one request may arrive from several waves, in any order
+RT_D void gather_accumulate(const TraceCfg &C, uint32_t p, float4 albedo, V3<float> sd, V3<float> sc) {
+  const float PI_ = 3.141592653589793f;
+  const float dArea = PI_ * (float)(C.diffuse_radius * C.diffuse_radius), cArea = PI_ * (float)(C.caustic_radius * C.caustic_radius);
+  const float lc[3] = { albedo.x, albedo.y, albedo.z }, d3[3] = { sd.x, sd.y, sd.z }, c3[3] = { sc.x, sc.y, sc.z };
+  for (int c = 0; c < 3; c++) {
+    const double f = ((double)(d3[c] * lc[c] / dArea) + (double)(c3[c] * lc[c] / cArea)) * RT_GACC_SCALE;
+    const long long k = (f == f && f > -9.0e18 && f < 9.0e18) ? __double2ll_rn(f) : 0ll;
+    if (k) atomicAdd((unsigned long long *)&C.gacc[(size_t)p * 3 + c], (unsigned long long)k);
+  }
+}
+
+// Serves the gather requests of a frame (TraceCfg::gq): one lane per request, a wave's 64 requests together where
+// they lie close enough (gather_map_wave), lane by lane otherwise; (diffuse sum / diffuse area + caustic sum / caustic
+// area) x albedo goes to the path's fixed-point accumulators.  The grid is an upper bound (gq_cap requests).
+static __global__ void __launch_bounds__(256) k_gather_deferred(TraceCfg C, DevMap Md, DevMap Mc, GatherItems items, int split_d, int split_c) {
+  __shared__ WaveGatherLds wg_lds[4];
+  const uint32_t total = min(*C.gq_count, C.gq_cap);
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if ((i & ~63u) >= total) return;                           // (wave-uniform)
+  bool need = i < total;
+  uint32_t r = need ? (C.gq_order ? C.gq_order[i] : i) : 0u;
+  if (r >= C.gq_cap) { r = 0; need = false; }                // (never true)
+  const float4 *q = C.gq + (size_t)r * 3;
+  const float4 q0 = q[0], q1 = q[1], q2 = q[2];
+  const V3<float> hit = mk<float>(q0.x, q0.y, q0.z), nrm = mk<float>(q1.x, q1.y, q1.z);
+  const uint32_t p = __float_as_uint(q0.w), todo = need ? (__float_as_uint(q1.w) & 3u) : 0u;
+  V3<float> sd = mk<float>(0.f, 0.f, 0.f), sc = mk<float>(0.f, 0.f, 0.f);
+  WaveGatherLds &L = wg_lds[threadIdx.x >> 6];
+  const bool nd = (todo & 1u) && Md.n, nc = (todo & 2u) && Mc.n;
+  // With a sorted queue the wave's requests are neighbours: one walk for all of them, whatever their spread, and the
+  // subtrees below the split depth as items for k_gather_items.  Unsorted: together only where that pays.
+  const bool sorted = C.gq_order != nullptr;
+  const float ratio = sorted ? 0.f : C.wave_gather_ratio;
+  const bool coop = sorted || C.wave_gather_ratio > 0.f;
+  GatherItems it = items;
+  it.tag = i >> 6;
+  if (__any(nd) && !(coop && gather_map_wave(Md, nd, hit, nrm, C.diffuse_radius, ratio, L, sd, 1u, split_d, (sorted && split_d > 0) ? &it : nullptr)) && nd)
+    sd = gather_map<float>(Md, hit, nrm, C.diffuse_radius);
+  it.tag = (i >> 6) | 0x80000000u;
+  if (__any(nc) && !(coop && gather_map_wave(Mc, nc, hit, nrm, C.caustic_radius, ratio, L, sc, 1u, split_c, (sorted && split_c > 0) ? &it : nullptr)) && nc)
+    sc = gather_map<float>(Mc, hit, nrm, C.caustic_radius);
+  if (!need || p >= C.n_paths) return;
+  gather_accumulate(C, p, q2, sd, sc);
+}
+
+// The items k_gather_deferred has split off: persistent waves, each taking the next item while there are any (the
+// cursor and the item count live in device memory; the count is final when this kernel starts).
+static __global__ void __launch_bounds__(256) k_gather_items(TraceCfg C, DevMap Md, DevMap Mc, GatherItems items, uint32_t *cursor) {
+  __shared__ WaveGatherLds wg_lds[4];
+  const int lane = threadIdx.x & 63;
+  WaveGatherLds &L = wg_lds[threadIdx.x >> 6];
+  const uint32_t total = min(*C.gq_count, C.gq_cap), n_items = min(*items.count, items.cap);
+  for (;;) {
+    uint32_t k = 0;
+    if (lane == 0) k = atomicAdd(cursor, 1u);
+    k = __shfl(k, 0, 64);
+    if (k >= n_items) break;
+    const uint2 item = items.items[k];
+    const bool caustic = item.x >> 31;
+    const uint32_t i = (item.x & 0x7FFFFFFFu) * 64u + (uint32_t)lane;
+    bool need = i < total;
+    uint32_t r = need ? (C.gq_order ? C.gq_order[i] : i) : 0u;
+    if (r >= C.gq_cap) { r = 0; need = false; }              // (never true)
+    const float4 *q = C.gq + (size_t)r * 3;
+    const float4 q0 = q[0], q1 = q[1], q2 = q[2];
+    const V3<float> hit = mk<float>(q0.x, q0.y, q0.z), nrm = mk<float>(q1.x, q1.y, q1.z);
+    const uint32_t p = __float_as_uint(q0.w), todo = need ? (__float_as_uint(q1.w) & 3u) : 0u;
+    const DevMap &M = caustic ? Mc : Md;
+    const bool want = (todo & (caustic ? 2u : 1u)) && M.n && item.y >= 1u && item.y <= M.n;
+    V3<float> sum = mk<float>(0.f, 0.f, 0.f), zero = mk<float>(0.f, 0.f, 0.f);
+    (void)gather_map_wave(M, want, hit, nrm, caustic ? C.caustic_radius : C.diffuse_radius, 0.f, L, sum, item.y >= 1u && item.y <= M.n ? item.y : 1u);
+    if (want && p < C.n_paths) gather_accumulate(C, p, q2, caustic ? zero : sum, caustic ? sum : zero);
+  }
+}
+
+// Sort keys of the requests: 27-bit Morton code of the point in cells of `cell` (9 bits an axis around the origin, clamped;
+// the sort only has to bring neighbours together), then the path and the bounce, which make the order -- and with it
+// the groups of 64 and the order of every sum -- the same whatever order the requests were queued in; all ones for the
+// unused slots of the queue.
+RT_D uint32_t spread9(uint32_t v) {
+  v &= 511u; v = (v | (v << 16)) & 0x030000FFu; v = (v | (v << 8)) & 0x0300F00Fu; v = (v | (v << 4)) & 0x030C30C3u; v = (v | (v << 2)) & 0x09249249u;
+  return v;
+}
+static __global__ void __launch_bounds__(256) k_gather_keys(TraceCfg C, float inv_cell, unsigned long long *keys, uint32_t *vals) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= C.gq_cap) return;
+  const uint32_t total = min(*C.gq_count, C.gq_cap);
+  unsigned long long key = ~0ull;
+  if (i < total) {
+    const float4 q0 = C.gq[(size_t)i * 3], q1 = C.gq[(size_t)i * 3 + 1];
+    auto cellof = [&](float v) { const float c = v * inv_cell + 256.0f; return (uint32_t)(c < 0.f ? 0.f : (c > 511.f ? 511.f : c)); };   // (NaN -> 0)
+    const uint32_t morton = spread9(cellof(q0.x)) | (spread9(cellof(q0.y)) << 1) | (spread9(cellof(q0.z)) << 2);
+    key = ((unsigned long long)morton << 37) | ((unsigned long long)(__float_as_uint(q0.w) & 0x7FFFFFFFu) << 6) | ((__float_as_uint(q1.w) >> 2) & 63u);
+  }
+  keys[i] = key; vals[i] = i;
+}
+
 // Pixel resolve (rayphoton.js:1610-1623): clamp each sub-sample (`colour()`), sum, floor of the
 // mean.  pre = the last sub-sample's unclamped colour; rgba8 = post as bytes.
 template <typename T>
@@ -903,7 +1157,11 @@ __global__ void __launch_bounds__(256) k_resolve(PathSoA<T> P, TraceCfg C, int n
   double tot[4] = { 0, 0, 0, 0 }, last[4] = { 0, 0, 0, 0 };
   for (int s = 0; s < SS; s++) {
     const T *o = P.out + ((size_t)pp * SS + s) * 4;
-    for (int c = 0; c < 4; c++) { last[c] = (double)o[c]; tot[c] += clamp01(last[c], 0, c == 3 ? 1 : 255); }
+    for (int c = 0; c < 4; c++) {
+      last[c] = (double)o[c];
+      if (C.gacc && c < 3) last[c] = (double)(T)(last[c] + (double)C.gacc[((size_t)pp * SS + s) * 3 + c] / RT_GACC_SCALE);    // the deferred photon gathers
+      tot[c] += clamp01(last[c], 0, c == 3 ? 1 : 255);
+    }
   }
   for (int c = 0; c < 4; c++) {
     double v = floor(tot[c] / SS);
