@@ -332,20 +332,35 @@ RT_D bool gather_map_wave(const DevMap &M, bool need, V3<float> x, V3<float> nrm
   const float r2lo = (float)(r2 * (1.0 - 1e-6)), r2hi = (float)(r2 * (1.0 + 1e-6));      // fp32 d2 is within 3e-7 (relative) of the fp64 one
   float sr = 0.f, sg = 0.f, sb = 0.f;
   uint32_t m = 0;
+  // (a lane without a point: bounds no distance is below)
+  const float lo_lane = need ? r2lo : -1.f, hi_lane = need ? r2hi : -1.f;
   auto consume = [&]() {
     RT_WAVE_SYNC()
+    // the batch in fp32; should any (lane, candidate) distance fall inside the band, the batch again with the fp64 test
+    float br = 0.f, bg = 0.f, bb = 0.f;
+    bool band = false;
     for (uint32_t j = 0; j < m; j++) {
       const float4 cd = L.cand[j];
       const float dx = x.x - cd.x, dy = x.y - cd.y, dz = x.z - cd.z;
       const float d2f = dx * dx + dy * dy + dz * dz;
-      bool in = d2f < r2lo;
-      if (__any(need && !in && d2f < r2hi))             // (wave-uniform; rare)
-        in = sq_dist((double)x.x, (double)x.y, (double)x.z, (double)cd.x, (double)cd.y, (double)cd.z) < r2;
       const float *pl = L.pay + j * 6;
-      float w = pl[0] * nrm.x + pl[1] * nrm.y + pl[2] * nrm.z;
-      w = (in && need && w > 0.f) ? w : 0.f;
-      sr += pl[3] * w; sg += pl[4] * w; sb += pl[5] * w;
+      const float w = fmaxf(pl[0] * nrm.x + pl[1] * nrm.y + pl[2] * nrm.z, 0.f);
+      const float wi = d2f < lo_lane ? w : 0.f;
+      band = band || (!(d2f < lo_lane) && d2f < hi_lane);
+      br += pl[3] * wi; bg += pl[4] * wi; bb += pl[5] * wi;
     }
+    if (__any(band)) {                                   // (wave-uniform; rare)
+      br = 0.f; bg = 0.f; bb = 0.f;
+      for (uint32_t j = 0; j < m; j++) {
+        const float4 cd = L.cand[j];
+        const bool in = need && sq_dist((double)x.x, (double)x.y, (double)x.z, (double)cd.x, (double)cd.y, (double)cd.z) < r2;
+        const float *pl = L.pay + j * 6;
+        const float w = fmaxf(pl[0] * nrm.x + pl[1] * nrm.y + pl[2] * nrm.z, 0.f);
+        const float wi = in ? w : 0.f;
+        br += pl[3] * wi; bg += pl[4] * wi; bb += pl[5] * wi;
+      }
+    }
+    sr += br; sg += bg; sb += bb;
     m = 0;
     RT_WAVE_SYNC()
   };
