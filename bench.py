@@ -514,7 +514,7 @@ def main():
         dtf, stf = timed_frames(sc, pf, frame, n=3, maps=(md, mc))
         extra["full_mode_b_frame"] = {"ms_per_frame": dtf * 1e3, "Mrays_per_s": stf["rays"] / dtf / 1e6, "rays_per_frame": stf["rays"],
                                       "shadow_rays_per_frame": stf["shadow_rays"], "gathers_per_frame": stf["gathers"], "gathers_per_s": stf["gathers"] / dtf,
-                                      "photons": stored, "note": "direct light, diffuse (r = 0.40) and caustic (r = 0.15) radius gathers: the reference's traceRay in full"}
+                                      "photons": stored, "note": "direct light, diffuse (r = 0.40) and caustic (r = 0.15) radius gathers: the reference's traceRay in full; the gathers are queued, sorted by position and served 64 at a time (k_gather_deferred, k_gather_items)"}
         # ... and BASELINE config 0's frame (320x240, 10k + 10k photons, everything on): the frame the CPU oracle is timed on
         flat0 = flat.with_size(320, 240)
         sc0 = ctx.upload(flat0)
