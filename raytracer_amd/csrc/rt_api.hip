@@ -131,7 +131,7 @@ int rt_set_option(rt_ctx *ctx, const char *name, double value) {
   else if (n == "bvh") K.bvh = (int)value;
   else if (n == "bvh_one_order") K.bvh_one_order = value != 0;
   else if (n == "wave_gather") K.wave_gather = value;
-  else if (n == "defer_gathers") K.defer_gathers = value != 0;
+  else if (n == "defer_gathers") K.defer_gathers = (int)value;
   else if (n == "gather_sort") K.gather_sort = value != 0;
   else if (n == "gather_split") K.gather_split = (int)value;
   else if (n == "knn_heap") K.knn_heap = value != 0;

@@ -44,7 +44,9 @@ struct RtKnobs {
   int bvh_one_order = 0;         // 1: the hierarchy is walked in one child order for every ray (no near-child-first copies)
   double wave_gather = 8;        // unsorted request queue (gather_sort = 0): a wave serves its 64 requests together while the box of their search
                                  // balls is within this many ball areas (0: every lane gathers on its own)
-  int defer_gathers = 1;         // fp32 frames with photon maps: the gathers go through a request queue and kernels of their own
+  int defer_gathers = -1;        // fp32 frames with photon maps: the gathers go through a request queue and kernels of their own (1), are done where
+                                 // the hit is shaded (0), or (-1) queued when the maps hold 200 000 photons or more (below that the extra launches cost
+                                 // more than the walks)
   int gather_sort = 1;           // the requests are served in the order of their positions
   int gather_split = 4096;       // ... and subtrees of the maps of at most this many photons are work items of their own (0: one wave per 64 requests does it all)
   int knn_heap = 0;              // 1: k-nearest gathers use the per-lane heap kernel only

@@ -139,7 +139,7 @@ static int trace_tile_mode(rt_scene *sc, int slot, const rt_params *p, DevMap md
   C.gq = nullptr; C.gq_count = nullptr; C.gq_cap = 0; C.gacc = nullptr; C.gq_order = nullptr;
   bool defer = false;
   if constexpr (sizeof(T) == 4 && FULL && !WHITTED) {
-    defer = K.defer_gathers && p->use_photon_maps && (md.n || mc.n);
+    defer = p->use_photon_maps && (md.n || mc.n) && (K.defer_gathers < 0 ? (uint64_t)md.n + mc.n >= 200000u : K.defer_gathers != 0);
     if (defer) {                                              // request queue (a counter in its first 256 bytes) and per-path accumulators
       const uint32_t gq_cap = (uint32_t)std::max<size_t>(2 * n_paths, 4096);      // (requests beyond it are gathered where they are shaded)
       RT_HIP(ctx, W.gq.reserve(256 + (size_t)gq_cap * 48));

@@ -641,46 +641,66 @@ def test_queued_photon_gathers_equal_the_gathers_in_place(rt):
     `d2 < r^2` decides), in another order -- so the frame equals the one with every gather done where it is shaded to
     fp32 rounding, run after run and schedule after schedule bit for bit, and the counters do not change"""
     capi, ctx = rt
-    ph = load_bundle("photons_c1")
-    sc = ctx.upload(load_scene(10, 320, 240))
-    md, mc = ctx.photon_map(ph["diffuse"]), ctx.photon_map(ph["caustic"])
-    for kw in (dict(), dict(sub_sample=2), dict(use_direct_light=0)):
-        p = capi.default_params(precision=capi.PRECISION_F32, num_photons_diffuse=10000, num_photons_caustic=10000, seed=SEED, shadow_bias=1e-4, **kw)
-        with ctx.option("defer_gathers", 0, 1):
-            ref = sc.trace_tile(p, md, mc)
-        got = sc.trace_tile(p, md, mc)
-        again = sc.trace_tile(p, md, mc)
-        assert same(got["pre"], again["pre"]) and same(got["post"], again["post"])
-        for k in ("rays", "shadow_rays", "gathers", "bounces"):
-            assert got["stats"][k] == ref["stats"][k], k
-        assert ref["stats"]["gathers"] > 100000
-        tol = 2e-5 * np.maximum(1.0, np.abs(ref["pre"][..., :3]))
-        assert (np.abs(got["pre"][..., :3] - ref["pre"][..., :3]) <= tol).all()
-        assert (got["post"] != ref["post"]).any(axis=-1).mean() < 2e-3         # (a floor that falls the other way)
-        assert same(got["pre"][..., 3], ref["pre"][..., 3])
-        variants = {}
-        for name, opts in (("unsorted, waves together", dict(gather_sort=0)), ("unsorted, lane by lane", dict(gather_sort=0, wave_gather=0)),
-                           ("sorted, no work items", dict(gather_split=0)), ("sorted, small work items", dict(gather_split=64)),
-                           ("whole frame in one launch", dict(whole_frame=1)), ("persistent tail", dict(tail_persistent=4))):
-            import contextlib
-            with contextlib.ExitStack() as es:
-                for o, v in opts.items():
-                    es.enter_context(ctx.option(o, v, {"gather_sort": 1, "wave_gather": 8, "gather_split": 4096, "whole_frame": 0, "tail_persistent": -1}[o]))
-                variants[name] = sc.trace_tile(p, md, mc)
-        for name, v in variants.items():
-            assert (np.abs(v["pre"][..., :3] - ref["pre"][..., :3]) <= tol).all(), name
-            assert v["stats"]["gathers"] == ref["stats"]["gathers"], name
-        # the order of the sums does not depend on the schedule that queued the requests
-        for name in ("whole frame in one launch", "persistent tail"):
-            assert same(variants[name]["pre"], got["pre"]), name
-    # one map only, and a tile that is not a multiple of anything
-    p = capi.default_params(precision=capi.PRECISION_F32, num_photons_diffuse=10000, num_photons_caustic=10000, seed=SEED, shadow_bias=1e-4)
-    for maps in ((md, None), (None, mc)):
-        with ctx.option("defer_gathers", 0, 1):
-            ref = sc.trace_tile(p, maps[0], maps[1], x0=17, y0=5, w=123, h=77)
-        got = sc.trace_tile(p, maps[0], maps[1], x0=17, y0=5, w=123, h=77)
-        assert (np.abs(got["pre"][..., :3] - ref["pre"][..., :3]) <= 2e-5 * np.maximum(1.0, np.abs(ref["pre"][..., :3]))).all()
-        assert got["stats"]["gathers"] == ref["stats"]["gathers"]
+    ctx.set_option("defer_gathers", 1)                      # (by itself the library queues only for maps of 200 000 photons and more)
+    try:
+        ph = load_bundle("photons_c1")
+        sc = ctx.upload(load_scene(10, 320, 240))
+        md, mc = ctx.photon_map(ph["diffuse"]), ctx.photon_map(ph["caustic"])
+        for kw in (dict(), dict(sub_sample=2), dict(use_direct_light=0)):
+            p = capi.default_params(precision=capi.PRECISION_F32, num_photons_diffuse=10000, num_photons_caustic=10000, seed=SEED, shadow_bias=1e-4, **kw)
+            with ctx.option("defer_gathers", 0, 1):
+                ref = sc.trace_tile(p, md, mc)
+            got = sc.trace_tile(p, md, mc)
+            again = sc.trace_tile(p, md, mc)
+            assert same(got["pre"], again["pre"]) and same(got["post"], again["post"])
+            for k in ("rays", "shadow_rays", "gathers", "bounces"):
+                assert got["stats"][k] == ref["stats"][k], k
+            assert ref["stats"]["gathers"] > 100000
+            tol = 2e-5 * np.maximum(1.0, np.abs(ref["pre"][..., :3]))
+            assert (np.abs(got["pre"][..., :3] - ref["pre"][..., :3]) <= tol).all()
+            assert (got["post"] != ref["post"]).any(axis=-1).mean() < 2e-3         # (a floor that falls the other way)
+            assert same(got["pre"][..., 3], ref["pre"][..., 3])
+            variants = {}
+            for name, opts in (("unsorted, waves together", dict(gather_sort=0)), ("unsorted, lane by lane", dict(gather_sort=0, wave_gather=0)),
+                               ("sorted, no work items", dict(gather_split=0)), ("sorted, small work items", dict(gather_split=64)),
+                               ("whole frame in one launch", dict(whole_frame=1)), ("persistent tail", dict(tail_persistent=4))):
+                import contextlib
+                with contextlib.ExitStack() as es:
+                    for o, v in opts.items():
+                        es.enter_context(ctx.option(o, v, {"gather_sort": 1, "wave_gather": 8, "gather_split": 4096, "whole_frame": 0, "tail_persistent": -1}[o]))
+                    variants[name] = sc.trace_tile(p, md, mc)
+            for name, v in variants.items():
+                assert (np.abs(v["pre"][..., :3] - ref["pre"][..., :3]) <= tol).all(), name
+                assert v["stats"]["gathers"] == ref["stats"]["gathers"], name
+            # the order of the sums does not depend on the schedule that queued the requests
+            for name in ("whole frame in one launch", "persistent tail"):
+                assert same(variants[name]["pre"], got["pre"]), name
+        # one map only, and a tile that is not a multiple of anything
+        p = capi.default_params(precision=capi.PRECISION_F32, num_photons_diffuse=10000, num_photons_caustic=10000, seed=SEED, shadow_bias=1e-4)
+        for maps in ((md, None), (None, mc)):
+            with ctx.option("defer_gathers", 0, 1):
+                ref = sc.trace_tile(p, maps[0], maps[1], x0=17, y0=5, w=123, h=77)
+            got = sc.trace_tile(p, maps[0], maps[1], x0=17, y0=5, w=123, h=77)
+            assert (np.abs(got["pre"][..., :3] - ref["pre"][..., :3]) <= 2e-5 * np.maximum(1.0, np.abs(ref["pre"][..., :3]))).all()
+            assert got["stats"]["gathers"] == ref["stats"]["gathers"]
+        # maps large enough for the library to queue by itself (and balls next to the lamps dense enough for work items)
+        ctx.set_option("defer_gathers", -1)
+        sc2 = ctx.upload(load_scene(10, 640, 360))
+        pe = capi.default_params(precision=capi.PRECISION_F32, num_photons_diffuse=300000, num_photons_caustic=300000, seed=SEED)
+        lists, _ = sc2.emit_many_lists(pe, capi.SHARD_PACKED, strict=False)
+        md2, mc2 = lists.photon_map(0), lists.photon_map(1)
+        p2 = capi.default_params(precision=capi.PRECISION_F32, num_photons_diffuse=300000, num_photons_caustic=300000, seed=SEED, shadow_bias=1e-4)
+        with ctx.option("defer_gathers", 0, -1):
+            ref2 = sc2.trace_tile(p2, md2, mc2)
+        got2 = sc2.trace_tile(p2, md2, mc2)
+        with ctx.option("gather_split", 0, 4096):
+            one2 = sc2.trace_tile(p2, md2, mc2)
+        tol2 = 2e-5 * np.maximum(1.0, np.abs(ref2["pre"][..., :3]))
+        assert (np.abs(got2["pre"][..., :3] - ref2["pre"][..., :3]) <= tol2).all() and (np.abs(one2["pre"][..., :3] - ref2["pre"][..., :3]) <= tol2).all()
+        assert not same(got2["pre"], ref2["pre"])               # (it did take the other route)
+        assert got2["stats"]["gathers"] == ref2["stats"]["gathers"] > 400000
+    finally:
+        ctx.set_option("defer_gathers", -1)
 
 
 # ------------------------------------------------------------------ wave-cooperative k-nearest gather
