@@ -547,6 +547,35 @@ def main():
                 ctx.synchronize()
                 extra["knn_real_map"] = {"gathers_per_s": 2 * rh.shape[0] / (time.perf_counter() - t_), "photons": em["n_caustic"], "queries": int(rh.shape[0]),
                                          "note": "the default scene's emitted caustic map, queried at the frame's first-hit points in 8x8-tile order"}
+                # the reference's own gather (rayphoton.js:1765-1815): fixed radius, at the same points, both maps
+                rad = {}
+                for name, pm_, r_ in (("diffuse_r0.40", md, 0.40), ("caustic_r0.15", mc, 0.15)):
+                    pm_.gather(rh, r=r_, out=out_r)
+                    ctx.synchronize()
+                    t_ = time.perf_counter()
+                    for _ in range(2):
+                        pm_.gather(rh, r=r_, out=out_r)
+                    ctx.synchronize()
+                    gps = 2 * rh.shape[0] / (time.perf_counter() - t_)
+                    # photons inside the balls, from a sample of the queries (rt_kd_radius counts them)
+                    samp = real_hits[:: max(1, real_hits.shape[0] // 4096), :3]
+                    cnt, _ = pm_.radius(samp, r_, cap=1)
+                    mean_in = float(cnt.mean())
+                    # per (query, photon inside the ball): 3 sub + 5 (d^2) + 5 (direction . normal) + 6 (three FMAs) = 19 flop
+                    tf = gps * mean_in * 19 / 1e12
+                    rad[name] = {"gathers_per_s": gps, "photons_in_ball_mean": mean_in, "photon_tests_per_s": gps * mean_in,
+                                 "algorithmic_TFLOP_per_s": tf, "frac_of_fp32_peak": tf / PEAK_FP32_VALU_TFLOPS}
+                with ctx.option("defer_gathers", 0, -1):
+                    sub = rh[::16].contiguous()
+                    out_s = torch.empty((sub.shape[0], 3), dtype=torch.float32, device=dev)
+                    md.gather(sub, r=0.40, out=out_s)
+                    ctx.synchronize()
+                    t_ = time.perf_counter()
+                    md.gather(sub, r=0.40, out=out_s)
+                    ctx.synchronize()
+                    rad["diffuse_r0.40_lane_by_lane"] = {"gathers_per_s": sub.shape[0] / (time.perf_counter() - t_), "note": "every 16th query, one lane walking the tree per query (k_gather_radius)"}
+                rad["note"] = "rt_gather_radiance with k = 0 on the emitted 2 M-photon maps: queries queued, sorted by position, served 64 at a time, subtrees of <= 4096 photons as work items"
+                extra["radius_gather_real_map"] = rad
         del md, mc, lists
 
     if rank == 0:

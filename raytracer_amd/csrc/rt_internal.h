@@ -145,6 +145,7 @@ struct rt_photon_map {
   uint32_t n = 0;
   DevMem node, pay, rec64, perm, dim;
   DevMem ws_flags;                 // per-workgroup fallback flags of the k-nearest gather (grow-only)
+  DevMem ws_queue, ws_sort;        // request queue, accumulators and sort buffers of the queued radius gather (grow-only)
   float bbox[6] = { 0, 0, 0, 0, 0, 0 };   // min xyz, max xyz of the photon positions
   DevMap view() const {
     DevMap m; m.n = n; m.node = node.as<float4>(); m.pay = pay.as<float>(); m.rec64 = rec64.as<double>(); m.perm = perm.as<int32_t>();

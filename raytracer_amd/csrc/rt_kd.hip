@@ -22,6 +22,7 @@
 #include <string.h>
 #include <cstring>
 #include <rocprim/rocprim.hpp>
+#include "rt_pipeline.h"
 #include "rt_internal.h"
 
 // (compiled with -ffp-contract=off, see Makefile)
@@ -1486,7 +1487,13 @@ extern "C" int rt_gather_radiance(rt_photon_map *m, const float *hits, uint32_t 
   RT_TRY(rt_stage_in(ctx, hits, (size_t)nq * 36, th, &dh));
   RT_TRY(rt_stage_out_begin(ctx, rgb_out, (size_t)nq * 12, to, &dout));
   if (k == 0) {
-    RT_LAUNCH(ctx, "gather_radius", k_gather_radius, div_up(nq, 256), 256, m->view(), (const float *)dh, nq, r, (float *)dout);
+    // many queries on a large map: through the request queue of the frames' photon gathers (sorted by position, 64
+    // served together, subtrees as work items) -- the same photons summed in another order; option defer_gathers
+    // as for the frames (1: always, 0: never)
+    const int dg = ctx->knobs.defer_gathers;
+    const bool queued = nq < 0x7FFFFFFFu && (dg < 0 ? (m->n >= 200000u && nq >= 16384u) : dg != 0);
+    if (queued) RT_TRY(pl_gather_radius_queued(m, m->ws_queue, m->ws_sort, (const float *)dh, nq, r, (float *)dout));
+    else RT_LAUNCH(ctx, "gather_radius", k_gather_radius, div_up(nq, 256), 256, m->view(), (const float *)dh, nq, r, (float *)dout);
     RT_HIP(ctx, hipGetLastError());
   } else {
     RT_HIP(ctx, m->ws_flags.reserve(knn_scratch_bytes(nq)));

@@ -31,3 +31,6 @@ template <typename T> int pl_emit_compact(rt_scene *sc, uint32_t count, int want
                                           double *out_rec, int64_t *out_attempt, uint8_t *out_kind, uint32_t *n_match);
 template <typename T> int pl_emit_shard(rt_scene *sc, uint32_t count, int format, uint32_t tag_offset, uint32_t cap, uint32_t *shard, uint32_t *n_dev);
 int pl_emit_counters(rt_scene *sc, bool reset, uint64_t *segments, uint64_t *errors);
+// rt_gather_radiance with k = 0 for many queries on a large map: the queries as gather requests through the queue, sort
+// and work items of the frame's photon gathers (rt_trace.h).  ws: grow-only workspace of the map.
+int pl_gather_radius_queued(rt_photon_map *m, DevMem &ws, DevMem &sort_tmp, const float *hits_dev, uint32_t nq, double r, float *rgb_dev);

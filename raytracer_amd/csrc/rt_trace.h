@@ -97,7 +97,7 @@ struct TraceCfg {
   float4 *gq; uint32_t *gq_count; uint32_t gq_cap; long long *gacc;
   const uint32_t *gq_order;      // requests in the order k_gather_deferred serves them (sorted by position), or nullptr
 };
-#define RT_GACC_SCALE 16777216.0
+#define RT_GACC_SCALE 4294967296.0      // 2^32: values below 2^31 in steps of 2.3e-10
 // row of the tile that traced row `row` stands for
 RT_D uint32_t band_row(const TraceCfg &C, uint32_t row) {
   if (!C.band_shift) return row;

@@ -699,6 +699,21 @@ def test_queued_photon_gathers_equal_the_gathers_in_place(rt):
         assert (np.abs(got2["pre"][..., :3] - ref2["pre"][..., :3]) <= tol2).all() and (np.abs(one2["pre"][..., :3] - ref2["pre"][..., :3]) <= tol2).all()
         assert not same(got2["pre"], ref2["pre"])               # (it did take the other route)
         assert got2["stats"]["gathers"] == ref2["stats"]["gathers"] > 400000
+        # rt_gather_radiance with k = 0 takes the same queue for many queries on a large map
+        from raytracer_amd import synth
+        hp = capi.default_params(precision=capi.PRECISION_F32, use_direct_light=0, use_photon_maps=0, seed=SEED)
+        hits = synth.first_hit_queries(sc2, hp, 640, 360)
+        assert hits.shape[0] > 100000
+        for pm_, r_ in ((md2, 0.40), (mc2, 0.15)):
+            with ctx.option("defer_gathers", 0, -1):
+                lane = pm_.gather(hits, r=r_)
+            queued = pm_.gather(hits, r=r_)
+            assert not np.array_equal(queued, lane) and np.abs(queued - lane).max() <= 2e-5 * max(1.0, float(np.abs(lane).max()))
+            assert np.allclose(queued, lane, rtol=3e-5, atol=1e-7 * float(np.abs(lane).max()))
+            assert np.array_equal(pm_.gather(hits, r=r_), queued)                   # the same from run to run
+            with ctx.option("defer_gathers", 1, -1):                                # few queries, forced through the queue
+                few = pm_.gather(hits[:777], r=r_)
+            assert np.allclose(few, lane[:777], rtol=3e-5, atol=1e-7 * float(np.abs(lane).max()))
     finally:
         ctx.set_option("defer_gathers", -1)
 
