@@ -252,7 +252,10 @@ int rt_kd_knn(rt_photon_map *map, const float *queries, uint32_t nq, uint32_t k,
 /* fused radiance estimate at nq surface points (rayphoton.js:1779-1784, :1808-1815):
  *   rgb = sum_p colour_p * power_p * max(0, dir_p . normal) * albedo/255 / (pi r^2)
  * over the photons within r (k == 0) or over the k nearest with r^2 = the k-th squared
- * distance (k > 0).  hits: nq x 9 fp32 = pos3 normal3 albedo3; rgb_out: nq x 3 fp32. */
+ * distance (k > 0).  hits: nq x 9 fp32 = pos3 normal3 albedo3; rgb_out: nq x 3 fp32.
+ * k == 0 with 16 384 queries or more on a map of 200 000 photons or more: the queries are sorted by position and served
+ * 64 at a time (the photons of a ball are the same -- the fp64 d2 < r^2 decides -- their sum is taken in another order
+ * than the tree walk's; the same from run to run).  Option defer_gathers = 0: every query walks on its own. */
 int rt_gather_radiance(rt_photon_map *map, const float *hits, uint32_t nq, double r, uint32_t k, float *rgb_out);
 
 /* rt_gather_radiance for callers that cannot allocate device memory (code under HIP graph capture, tight serving
@@ -262,7 +265,9 @@ int rt_gather_radiance(rt_photon_map *map, const float *hits, uint32_t nq, doubl
  * device array of about 3.8 MB that each GPU the library runs on holds until the process ends.  nq may be at most
  * RT_GATHER_STATIC_MAX_QUERIES (RT_ERR_TOO_LARGE beyond: split the queries over several calls).  All calls on one GPU
  * share that array: calls that overlap in time on one GPU (two contexts, two host threads) race.  Returns when the
- * results are complete. */
+ * results are complete.  With k == 0 every query walks the tree on its own lane: the bits of rt_gather_radiance's own
+ * lane-by-lane walk; the queue rt_gather_radiance takes for many queries on a large map (the same photons summed in
+ * another order, equal to fp32 rounding) needs buffers that grow with nq. */
 #define RT_GATHER_STATIC_MAX_QUERIES 262144u
 int rt_gather_radiance_static(rt_photon_map *map, const float *hits_dev, uint32_t nq, double r, uint32_t k, float *rgb_dev);
 
