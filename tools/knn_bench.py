@@ -43,3 +43,18 @@ if len(sys.argv) > 1 and sys.argv[1] == "heap":
     rate(mc, sub, "HEAP kernel: caustic map (1/16 of the queries)", reps=1)
     rate(md, sub, "HEAP kernel: diffuse map (1/16)", reps=1)
     rate(pm, np.ascontiguousarray(hits[::16]), "HEAP kernel: synthetic (1/16)", reps=1)
+# the same query sets sorted by the Morton code of their positions (what a caller, or the library, could do first)
+def morton_order(h, cells=1024):
+    p = h[:, :3].astype(np.float64)
+    lo, hi = p.min(axis=0), p.max(axis=0)
+    c = np.clip(((p - lo) / (hi - lo).max() * cells).astype(np.int64), 0, cells - 1)
+    def spread(v):
+        v = (v | (v << 16)) & 0x030000FF; v = (v | (v << 8)) & 0x0300F00F; v = (v | (v << 4)) & 0x030C30C3; v = (v | (v << 2)) & 0x09249249
+        return v
+    key = spread(c[:, 0]) | (spread(c[:, 1]) << 1) | (spread(c[:, 2]) << 2)
+    return np.argsort(key, kind="stable")
+if len(sys.argv) > 1 and sys.argv[1] == "sorted":
+    for cells in (256, 1024):
+        rate(pm, np.ascontiguousarray(hits[morton_order(hits, cells)]), f"synthetic, Morton order ({cells} cells)")
+        rate(mc, np.ascontiguousarray(rh[morton_order(rh, cells)]), f"caustic map, Morton order ({cells} cells)")
+        rate(md, np.ascontiguousarray(rh[morton_order(rh, cells)]), f"diffuse map, Morton order ({cells} cells)")
