@@ -65,7 +65,7 @@ int pl_gather_radius_queued(rt_photon_map *m, DevMem &ws, DevMem &sort_tmp, cons
   if (K.gather_split > 0) while (((uint64_t)m->n >> split) > (uint64_t)K.gather_split && split < 24) split++;
   DevMap none = {};
   RT_LAUNCH(ctx, "gather_deferred", k_gather_deferred, div_up(nq, 256), 256, C, m->view(), none, items, split, 0);
-  if (items.cap) RT_LAUNCH(ctx, "gather_items", k_gather_items, 256 * 3, 256, C, m->view(), none, items, C.gq_count + 2);
+  if (items.cap) RT_LAUNCH(ctx, "gather_items", k_gather_items, 256 * RT_GATHER_ITEM_WGS, 256, C, m->view(), none, items, C.gq_count + 2);
   RT_LAUNCH(ctx, "gather_to_rgb", k_accumulators_to_rgb, div_up((uint64_t)nq * 3, 256), 256, (const long long *)C.gacc, nq * 3, rgb_dev);
   RT_HIP(ctx, hipGetLastError());
   return RT_OK;

@@ -294,7 +294,7 @@ static int trace_tile_mode(rt_scene *sc, int slot, const rt_params *p, DevMap md
       items.items = W.gitems.as<uint2>();
     }
     RT_LAUNCH(ctx, "gather_deferred", k_gather_deferred, div_up(C.gq_cap, 256), 256, C, md, mc, items, split_d, split_c);
-    if (items.cap) RT_LAUNCH(ctx, "gather_items", k_gather_items, 256 * 3, 256, C, md, mc, items, C.gq_count + 2);
+    if (items.cap) RT_LAUNCH(ctx, "gather_items", k_gather_items, 256 * RT_GATHER_ITEM_WGS, 256, C, md, mc, items, C.gq_count + 2);
   }
   if (WHITTED)
     RT_LAUNCH(ctx, "resolve", k_resolve_a<T>, div_up(n_pixels, 256), 256, P, C, levels, (uint32_t)n_paths, (int)p->max_depth, (int)n_pixels,

@@ -290,12 +290,16 @@ RT_D V3<T> gather_map(const DevMap &M, V3<T> x, V3<T> normal, double r) {
 // within its own ball.  Which photons a lane adds is decided as in gather_map -- the fp64 `d2 < r^2` of
 // kdtree.js:75 -- through an fp32 distance with an error band (fp64 only for candidates inside the band), so the set
 // is identical; the order of the additions is not, hence a tolerance against the one-lane gather, not identity.
-#define RT_WG_CAP 256                      // candidates per wave
+#ifndef RT_WG_CAP
+#define RT_WG_CAP 128                      // candidates per wave (a step adds up to 64; smaller buffers, more waves per SIMD: 256 was 12 % slower)
+#endif
 #define RT_WG_FRONT 256                    // node queue per wave (a ring)
 // LDS written by some lanes of a wave is read by others: order the accesses (the waves of a workgroup run this code
 // independently, so no workgroup barrier)
 #define RT_WAVE_SYNC() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
 struct WaveGatherLds { float4 cand[RT_WG_CAP]; float pay[RT_WG_CAP * 6]; uint32_t front[RT_WG_FRONT]; };
+// workgroups of k_gather_items per CU: as many as the staging buffers of their four waves leave room for in 160 KB of LDS
+#define RT_GATHER_ITEM_WGS ((int)((160 * 1024) / (4 * sizeof(WaveGatherLds))) > 8 ? 8 : (int)((160 * 1024) / (4 * sizeof(WaveGatherLds))))
 
 RT_D float wg_min(float v) { for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64)); return v; }
 RT_D float wg_max(float v) { for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64)); return v; }

@@ -21,7 +21,7 @@ for dl, pm in ((0, 0), (1, 0), (0, 1), (1, 1)):
     for _ in range(3):
         st = sc.trace_tile(pf, md, mc, out_rgba8=frame, want=())["stats"]
     ctx.synchronize(); dt = (time.perf_counter() - t) / 3
-    kern = {k: round(ctx.profile_get(k)[0] / 3, 3) for k in ("primary", "tail")}
+    kern = {k: round(ctx.profile_get(k)[0] / 3, 3) for k in ("primary", "tail", "gather_sort", "gather_deferred", "gather_items")}
     ctx.profile_enable(False)
     print(json.dumps({"direct_light": dl, "photon_maps": pm, "ms_per_frame": round(dt * 1e3, 3), "kernel_ms": kern,
                       "rays": st["rays"], "shadow_rays": st["shadow_rays"], "gathers": st["gathers"], "bounces": st.get("bounces")}), flush=True)
