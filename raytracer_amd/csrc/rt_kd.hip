@@ -1491,7 +1491,7 @@ extern "C" int rt_gather_radiance(rt_photon_map *m, const float *hits, uint32_t 
     // served together, subtrees as work items) -- the same photons summed in another order; option defer_gathers
     // as for the frames (1: always, 0: never)
     const int dg = ctx->knobs.defer_gathers;
-    const bool queued = nq < 0x7FFFFFFFu && (dg < 0 ? (m->n >= 200000u && nq >= 16384u) : dg != 0);
+    const bool queued = nq < (1u << 26) && (dg < 0 ? (m->n >= 200000u && nq >= 16384u) : dg != 0);
     if (queued) RT_TRY(pl_gather_radius_queued(m, m->ws_queue, m->ws_sort, (const float *)dh, nq, r, (float *)dout));
     else RT_LAUNCH(ctx, "gather_radius", k_gather_radius, div_up(nq, 256), 256, m->view(), (const float *)dh, nq, r, (float *)dout);
     RT_HIP(ctx, hipGetLastError());

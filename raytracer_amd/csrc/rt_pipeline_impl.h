@@ -141,7 +141,7 @@ static int trace_tile_mode(rt_scene *sc, int slot, const rt_params *p, DevMap md
   if constexpr (sizeof(T) == 4 && FULL && !WHITTED) {
     defer = p->use_photon_maps && (md.n || mc.n) && (K.defer_gathers < 0 ? (uint64_t)md.n + mc.n >= 200000u : K.defer_gathers != 0);
     if (defer) {                                              // request queue (a counter in its first 256 bytes) and per-path accumulators
-      const uint32_t gq_cap = (uint32_t)std::max<size_t>(2 * n_paths, 4096);      // (requests beyond it are gathered where they are shaded)
+      const uint32_t gq_cap = (uint32_t)std::min<size_t>(std::max<size_t>(2 * n_paths, 4096), (size_t)1 << 26);      // (requests beyond it are gathered where they are shaded)
       RT_HIP(ctx, W.gq.reserve(256 + (size_t)gq_cap * 48));
       RT_HIP(ctx, W.gacc.reserve(n_paths * 3 * 8));
       C.gq_count = W.gq.as<uint32_t>(); C.gq = (float4 *)((char *)W.gq.p + 256); C.gq_cap = gq_cap; C.gacc = W.gacc.as<long long>();

@@ -699,6 +699,19 @@ def test_queued_photon_gathers_equal_the_gathers_in_place(rt):
         assert (np.abs(got2["pre"][..., :3] - ref2["pre"][..., :3]) <= tol2).all() and (np.abs(one2["pre"][..., :3] - ref2["pre"][..., :3]) <= tol2).all()
         assert not same(got2["pre"], ref2["pre"])               # (it did take the other route)
         assert got2["stats"]["gathers"] == ref2["stats"]["gathers"] > 400000
+        # BASELINE's full size: 1920x1080, 2 M + 2 M emitted photons (balls next to the lamps hold hundreds of thousands)
+        sc3 = ctx.upload(load_scene(10, 1920, 1080))
+        pe3 = capi.default_params(precision=capi.PRECISION_F32, num_photons_diffuse=2_000_000, num_photons_caustic=2_000_000, seed=1)
+        lists3, _ = sc3.emit_many_lists(pe3, capi.SHARD_PACKED, strict=False)
+        md3, mc3 = lists3.photon_map(0), lists3.photon_map(1)
+        p3 = capi.default_params(precision=capi.PRECISION_F32, num_photons_diffuse=2_000_000, num_photons_caustic=2_000_000, seed=1, shadow_bias=1e-4)
+        with ctx.option("defer_gathers", 0, -1):
+            ref3 = sc3.trace_tile(p3, md3, mc3, want=("pre",))
+        got3 = sc3.trace_tile(p3, md3, mc3, want=("pre",))
+        assert (np.abs(got3["pre"][..., :3] - ref3["pre"][..., :3]) <= 3e-5 * np.maximum(1.0, np.abs(ref3["pre"][..., :3]))).all()
+        assert got3["stats"]["gathers"] == ref3["stats"]["gathers"] > 4_000_000 and got3["stats"]["rays"] == ref3["stats"]["rays"]
+        assert same(sc3.trace_tile(p3, md3, mc3, want=("pre",))["pre"], got3["pre"])
+        del lists3, md3, mc3, sc3, ref3, got3
         # rt_gather_radiance with k = 0 takes the same queue for many queries on a large map
         from raytracer_amd import synth
         hp = capi.default_params(precision=capi.PRECISION_F32, use_direct_light=0, use_photon_maps=0, seed=SEED)
