@@ -91,7 +91,7 @@ int rt_init(const int *device_ids, int n, rt_ctx **out) {
       return RT_ERR_HIP;
     }
   // the experiment switches: the environment is read here, once per context
-  static const char *names[] = { "tail_threshold", "whole_frame", "bounce_passes", "tail_handoff", "tail_rounds", "tail_persistent", "no_lds", "no_cull", "raster_order", "bvh", "bvh_one_order", "wave_gather", "defer_gathers", "gather_sort", "gather_split", "knn_heap",
+  static const char *names[] = { "tail_threshold", "whole_frame", "bounce_passes", "tail_handoff", "tail_rounds", "tail_persistent", "no_lds", "no_cull", "cull_lists", "raster_order", "bvh", "bvh_one_order", "wave_gather", "defer_gathers", "gather_sort", "gather_split", "knn_heap",
                                  "knn_verbose", "probe", "knn_radius_scale" };
   for (const char *nm : names) {
     std::string env = "RT355_";
@@ -127,6 +127,7 @@ int rt_set_option(rt_ctx *ctx, const char *name, double value) {
   else if (n == "tail_persistent") K.tail_persistent = (int)value;
   else if (n == "no_lds") K.no_lds = value != 0;
   else if (n == "no_cull") K.no_cull = value != 0;
+  else if (n == "cull_lists") K.cull_lists = value != 0;
   else if (n == "raster_order") K.raster_order = value != 0;
   else if (n == "bvh") K.bvh = (int)value;
   else if (n == "bvh_one_order") K.bvh_one_order = value != 0;
@@ -571,6 +572,12 @@ int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *d, rt_scene **out) {
     sc->d32.sbound = sc->sbound.as<float4>();                 // (option no_cull switches the culling off per frame)
   }
   memcpy(sc->d32.seg, seg, sizeof seg); memcpy(sc->d64.seg, seg, sizeof seg);
+  // fp32: what every test needs of the camera's position (all rays of a first pass start there), by the device's own code
+  if (hipError_t e = sc->sot_cam.alloc((size_t)n * RT_OT_STRIDE * 4); e != hipSuccess) {
+    delete sc; return rt_fail(ctx, RT_ERR_HIP, "hipMalloc failed: %s", hipGetErrorString(e));
+  }
+  if ((rc = pl_camera_origin_terms(ctx, sc->d32, sc->sot_cam.as<float>()))) { delete sc; return rc; }
+  sc->d32.sot_cam = sc->sot_cam.as<float>();
   *out = sc;
   return RT_OK;
 }

@@ -62,6 +62,7 @@ template <typename T> struct DevScene {
   uint32_t n_bvh_nodes, n_unbounded;
   uint32_t bvh_octant_stride;    // nodes between the per-octant copies of the hierarchy (0: one copy)
   const float4 *sbound;       // per sorted slot: bounding sphere (centre, radius; +inf = unbounded), fp32 build only, or nullptr
+  const float *sot_cam;       // per sorted slot: the origin terms (RT_OT_STRIDE floats) for rays that start at the camera, fp32 build only, or nullptr
 };
 
 // A miss is reported as -1 (every accepted distance is > epsilon > 0).
@@ -320,8 +321,11 @@ RT_D uint16_t *scan_lds_vis(uint32_t n, void *lds) { return (uint16_t *)(scan_ld
 // With `origin` (fp32 only) the origin terms of every primitive are staged behind it.
 // Every thread issues all its loads of a round (16-byte pieces of the records, four per thread, then the index and
 // flag words) before it stores any of them: a small scene costs the workgroup ONE global round trip, not one per
-// element.  The origin terms are then computed from the LDS copy.
-template <typename T> RT_D ScanSrc<T> stage_scene_lds(const DevScene<T> &S, void *lds, const V3<T> *origin = nullptr) {
+// element.  The origin terms are copied too when `origin` is the camera and the scene holds the camera's terms
+// (S.sot_cam, computed at upload by this same code), else computed from the LDS copy.  `extra`: n_extra more words the
+// caller wants copied to `extra_dst` (LDS) in the same round trip.
+template <typename T> RT_D ScanSrc<T> stage_scene_lds(const DevScene<T> &S, void *lds, const V3<T> *origin = nullptr, const uint32_t *extra = nullptr,
+                                                      uint32_t *extra_dst = nullptr, uint32_t n_extra = 0) {
   T *lg = (T *)lds;
   uint32_t *lo = (uint32_t *)(lg + (size_t)S.n_shapes * RT_GEOM_STRIDE), *lf = lo + S.n_shapes;
   const uint32_t n = S.n_shapes, tid = threadIdx.x, nt = blockDim.x;
@@ -329,6 +333,13 @@ template <typename T> RT_D ScanSrc<T> stage_scene_lds(const DevScene<T> &S, void
   const uint4 *src = (const uint4 *)S.sgeom;
   uint4 *dst = (uint4 *)lg;
   const uint32_t o0 = S.sorig[tid < n ? tid : 0], f0 = S.sflags32[tid < n ? tid : 0];     // (first round of the words: in flight with the pieces)
+  const uint32_t x0 = (extra && tid < n_extra) ? extra[tid] : 0u;
+  bool ot_copied = false;
+  float t0 = 0.f;
+  if constexpr (sizeof(T) == 4) {
+    ot_copied = origin && S.sot_cam;
+    if (ot_copied) t0 = S.sot_cam[tid < n * RT_OT_STRIDE ? tid : 0];
+  }
   for (uint32_t base = 0; base < n16; base += 4 * nt) {
     uint4 v[4];
 #pragma unroll
@@ -338,9 +349,18 @@ template <typename T> RT_D ScanSrc<T> stage_scene_lds(const DevScene<T> &S, void
   }
   if (tid < n) { lo[tid] = o0; lf[tid] = f0; }
   for (uint32_t i = tid + nt; i < n; i += nt) { lo[i] = S.sorig[i]; lf[i] = S.sflags32[i]; }
+  if (extra) {
+    if (tid < n_extra) extra_dst[tid] = x0;
+    for (uint32_t i = tid + nt; i < n_extra; i += nt) extra_dst[i] = extra[i];
+  }
   ScanSrc<T> G; G.geom = lg; G.orig = lo; G.flags = lf; G.ot = nullptr;
   if constexpr (sizeof(T) == 4) {
-    if (origin) {
+    if (ot_copied) {
+      float *lt = (float *)(lf + n);
+      if (tid < n * RT_OT_STRIDE) lt[tid] = t0;
+      for (uint32_t i = tid + nt; i < n * RT_OT_STRIDE; i += nt) lt[i] = S.sot_cam[i];
+      G.ot = lt;
+    } else if (origin) {
       __syncthreads();
       float *lt = (float *)(lf + n);
       for (uint32_t i = tid; i < n; i += nt) {

@@ -10,6 +10,9 @@ template <typename T> int pl_intersect_pairs(rt_ctx *ctx, const rt_params *p, ui
 // origin_terms, isect_fast); fast_rec: n x 12 floats
 int pl_intersect_pairs_fast(rt_ctx *ctx, const rt_params *p, uint32_t n, const double *o, const double *d, int normalize_dir,
                             const uint8_t *meta, const float *fast_rec, double *t_out);
+// fp32: the origin terms of the scene's sorted primitives for rays that start at its camera (n_shapes x RT_OT_STRIDE
+// floats), computed by the code the scan kernels would run themselves; synchronises the context's stream
+int pl_camera_origin_terms(rt_ctx *ctx, const DevScene<float> &S, float *out);
 template <typename T> int pl_intersect_scene(rt_scene *sc, const rt_params *p, int mode, uint32_t n, const double *o,
                                              const double *d, const double *source_dist, double *t_out, int32_t *idx_out);
 template <typename T> int pl_trace_tile(rt_scene *sc, int slot, const rt_params *p, DevMap md, DevMap mc, int x0, int y0, int w, int h,

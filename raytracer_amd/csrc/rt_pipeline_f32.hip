@@ -70,3 +70,21 @@ int pl_gather_radius_queued(rt_photon_map *m, DevMem &ws, DevMem &sort_tmp, cons
   RT_HIP(ctx, hipGetLastError());
   return RT_OK;
 }
+
+// ---- origin terms of the sorted primitives for the camera's position, once per uploaded scene
+__global__ void __launch_bounds__(64) k_camera_origin_terms(DevScene<float> S, float *out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= S.n_shapes) return;
+  int type = 0;
+  while (type < RT_NUM_TYPES - 1 && i >= S.seg[type + 1]) type++;
+  float rec[RT_GEOM_STRIDE], ot[RT_OT_STRIDE] = { 0.f, 0.f, 0.f, 0.f, 0.f };
+  for (int k = 0; k < RT_GEOM_STRIDE; k++) rec[k] = S.sgeom[(size_t)i * RT_GEOM_STRIDE + k];
+  origin_terms_any(type, rec, ld3(S.camera), ot);
+  for (int k = 0; k < RT_OT_STRIDE; k++) out[(size_t)i * RT_OT_STRIDE + k] = ot[k];
+}
+int pl_camera_origin_terms(rt_ctx *ctx, const DevScene<float> &S, float *out) {
+  RT_LAUNCH(ctx, "camera_origin_terms", k_camera_origin_terms, div_up(S.n_shapes, 64), 64, S, out);
+  RT_HIP(ctx, hipGetLastError());
+  RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return RT_OK;
+}

@@ -1,6 +1,7 @@
 // Definitions of the pl_* drivers; included by rt_pipeline_f32.hip / rt_pipeline_f64.hip, which
 // instantiate them for one precision each.
 #pragma once
+#include <string.h>
 #include "rt_emit.h"
 #include "rt_pipeline.h"
 #include "rt_trace.h"
@@ -196,6 +197,23 @@ static int trace_tile_mode(rt_scene *sc, int slot, const rt_params *p, DevMap md
   uint32_t bounce_passes = direct ? std::min<uint32_t>((uint32_t)std::max(K.bounce_passes, 0), RT_MAX_BOUNCE_PASSES) : 0;
   if ((int)bounce_passes > C.max_bounces - 1) bounce_passes = (uint32_t)std::max(C.max_bounces - 1, 0);    // pass j traces segment j
   C.iter_base = bounce_passes;
+  C.cull_lists = nullptr; C.cull_stride = 0;
+  if constexpr (sizeof(T) == 4) {
+    // The first pass's per-workgroup lists of reachable primitives depend on the scene (fixed for this workspace), its
+    // camera and the tile's layout only: made by one small launch when the layout changes, read by every frame after.
+    if (lds && S.sbound && !S.bvh && !whole_frame && K.cull_lists) {
+      rt_scene::CullKey key = { x0, y0, wb, hb, blk, p->sub_sample, (uint32_t)n_paths, C.tiles_x, C.band_shift, C.band_period, C.band_first };
+      const uint32_t stride = cull_list_words(S.n_shapes), n_wg = div_up(n_paths, 256);
+      const size_t need = (size_t)n_wg * stride * 4;
+      if (!W.cull_valid || W.cull.bytes < need || memcmp(&W.cull_key, &key, sizeof key) != 0) {
+        W.cull_valid = false;
+        RT_HIP(ctx, W.cull.reserve(need));
+        RT_LAUNCH(ctx, "cull_lists", k_cull_lists, div_up(n_wg, 4), 256, S, C, n_wg, 256u, W.cull.as<uint32_t>(), stride);
+        W.cull_key = key; W.cull_valid = true;
+      }
+      C.cull_lists = W.cull.as<uint32_t>(); C.cull_stride = stride;
+    }
+  }
   if (whole_frame) {
     const uint32_t tblocks = div_up(n_paths, RT_TAIL_THREADS);
     if (lds_tail) RT_LAUNCH_SMEM(ctx, "trace", (k_tail<T, true, WHITTED, FULL, RT_TAIL_PRIMARY>), tblocks, RT_TAIL_THREADS, smem, S, P, C, md, mc, levels, (const uint32_t *)nullptr, (const uint32_t *)nullptr, 0u, 0u, ctr, 0, 0u, (uint32_t *)nullptr, (uint32_t *)nullptr, 0);

@@ -96,7 +96,13 @@ struct TraceCfg {
   // does not matter), which the resolve pass adds to the path's colour.  gq == nullptr: gathers where they are shaded.
   float4 *gq; uint32_t *gq_count; uint32_t gq_cap; long long *gacc;
   const uint32_t *gq_order;      // requests in the order k_gather_deferred serves them (sorted by position), or nullptr
+  // fp32 first pass: per workgroup the list of primitives its rays can reach (cull_stride words each: 16 segment words,
+  // then the sorted slots as 16-bit entries), made once per scene and tile layout by k_cull_lists, or nullptr: every
+  // workgroup works its list out itself
+  const uint32_t *cull_lists; uint32_t cull_stride;
 };
+// words of one workgroup's list of reachable primitives
+static inline __host__ __device__ uint32_t cull_list_words(uint32_t n_shapes) { return 16u + (2u * n_shapes + 3u) / 4u; }
 #define RT_GACC_SCALE 4294967296.0      // 2^32: values below 2^31 in steps of 2.3e-10
 // row of the tile that traced row `row` stands for
 RT_D uint32_t band_row(const TraceCfg &C, uint32_t row) {
@@ -675,10 +681,11 @@ RT_D bool shade_step(const DevScene<T> &S, const ScanSrc<T> &G, const PathSoA<T>
 // sorted by type, so one pass in slot order keeps the types together).  first64: the bounding sphere of slot `lane`,
 // which the caller loads before it stages the scene so that the round trip is not paid here.
 // Conservative (padded spheres, the rectangle widened by a pixel), so the scan over the list finds the same hits.
-RT_D void cull_primitives(const DevScene<float> &S, const TraceCfg &C, uint16_t *vis, uint32_t *vseg, float4 first64) {
-  if (threadIdx.x < 64) {                                       // wave 0 does it all; the others wait at the barrier below
-    const int lane = threadIdx.x;
-    const uint32_t p0 = blockIdx.x * blockDim.x, p1 = min(p0 + blockDim.x, C.n_paths) - 1;
+// wg: the workgroup of the first pass (wg_size consecutive paths) the list is for; called by one whole wave.
+RT_D void cull_primitives_wave(const DevScene<float> &S, const TraceCfg &C, uint32_t wg, uint32_t wg_size, uint16_t *vis, uint32_t *vseg, float4 first64) {
+  {
+    const int lane = threadIdx.x & 63;
+    const uint32_t p0 = wg * wg_size, p1 = min(p0 + wg_size, C.n_paths) - 1;
     uint32_t r_, c0, c1;
     const uint32_t ss = (uint32_t)(C.sub_sample * C.sub_sample);
     const uint32_t pix0 = div_by(p0, ss, C.magic_ss, r_), pix1 = div_by(p1, ss, C.magic_ss, r_);
@@ -731,7 +738,21 @@ RT_D void cull_primitives(const DevScene<float> &S, const TraceCfg &C, uint16_t 
     }
     if (lane == 0) vseg[RT_NUM_TYPES] = total;
   }
+}
+RT_D void cull_primitives(const DevScene<float> &S, const TraceCfg &C, uint16_t *vis, uint32_t *vseg, float4 first64) {
+  if (threadIdx.x < 64) cull_primitives_wave(S, C, blockIdx.x, blockDim.x, vis, vseg, first64);      // wave 0 does it all; the others wait
   __syncthreads();
+}
+// The lists of a whole frame, one wave per workgroup of the first pass, into lists[wg * stride ...] (the layout of the
+// LDS copy: 16 segment words, then the slots).  They depend on the scene, its camera and the tile's layout only, so the
+// host keeps them from frame to frame.
+static __global__ void __launch_bounds__(256) k_cull_lists(DevScene<float> S, TraceCfg C, uint32_t n_wg, uint32_t wg_size, uint32_t *lists, uint32_t stride) {
+  const uint32_t wg = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (wg >= n_wg) return;
+  const int lane = threadIdx.x & 63;
+  uint32_t *rec = lists + (size_t)wg * stride;
+  const float4 first64 = (uint32_t)lane < S.n_shapes ? S.sbound[lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+  cull_primitives_wave(S, C, wg, wg_size, (uint16_t *)(rec + 16), rec, first64);
 }
 
 // First pass of a frame, fused: camera ray, closest hit and shade of every path with the path state in
@@ -752,14 +773,15 @@ __global__ void __launch_bounds__(256) k_primary(DevScene<T> S, PathSoA<T> P, Tr
   float4 first64 = make_float4(0.f, 0.f, 0.f, 0.f);
   if constexpr (OT) {
     culled = S.sbound && !S.bvh;
-    if (culled && threadIdx.x < 64 && threadIdx.x < S.n_shapes) first64 = S.sbound[threadIdx.x];
+    if (culled) { vseg = scan_lds_vseg(S.n_shapes, rt_lds); vis = scan_lds_vis(S.n_shapes, rt_lds); }
+    if (culled && !C.cull_lists && threadIdx.x < 64 && threadIdx.x < S.n_shapes) first64 = S.sbound[threadIdx.x];
   }
-  const ScanSrc<T> G = LDS ? stage_scene_lds<T>(S, rt_lds, OT ? &cam_o : nullptr) : global_scan_src<T>(S);
+  const bool listed = OT && culled && C.cull_lists;           // this workgroup's list comes ready-made, staged with the scene
+  const ScanSrc<T> G = LDS ? stage_scene_lds<T>(S, rt_lds, OT ? &cam_o : nullptr, listed ? C.cull_lists + (size_t)blockIdx.x * C.cull_stride : nullptr,
+                                                vseg, listed ? C.cull_stride : 0u)
+                           : global_scan_src<T>(S);
   if constexpr (OT) {
-    if (culled) {
-      vseg = scan_lds_vseg(S.n_shapes, rt_lds); vis = scan_lds_vis(S.n_shapes, rt_lds);
-      cull_primitives(S, C, vis, vseg, first64);
-    }
+    if (culled && !listed) cull_primitives(S, C, vis, vseg, first64);
   }
   const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
   bool alive = false;

@@ -1068,7 +1068,10 @@ def test_culling_and_tile_order_are_exact(rt, size):
             b = sc.trace_tile(p, want=("pre", "rgba8"))
         with ctx.option("no_cull", 1, 0), ctx.option("raster_order", 1, 0):
             c = sc.trace_tile(p, want=("pre", "rgba8"))
-        for name, x in (("no_cull", a), ("raster_order", b), ("no_cull+raster_order", c)):
+        with ctx.option("cull_lists", 0, 1):               # every workgroup culls for itself instead of reading the kept lists
+            d = sc.trace_tile(p, want=("pre", "rgba8"))
+        assert d["stats"]["prim_tests"] == ref["stats"]["prim_tests"]
+        for name, x in (("no_cull", a), ("raster_order", b), ("no_cull+raster_order", c), ("cull_lists=0", d)):
             assert same(x["pre"], ref["pre"]) and np.array_equal(x["rgba8"], ref["rgba8"]), (name, kw)
             for k in ("rays", "shadow_rays", "tail_rays", "bounces"):
                 assert x["stats"][k] == ref["stats"][k], (name, k)
@@ -1081,6 +1084,10 @@ def test_culling_and_tile_order_are_exact(rt, size):
     with ctx.option("no_cull", 1, 0):
         part_all = sc.trace_tile(p, x0=37, y0=11, w=w, h=h, want=("pre",))
     assert same(part["pre"], part_all["pre"])
+    # the kept lists follow the tile's layout: the partial tile again, then the whole frame again
+    assert same(sc.trace_tile(p, x0=37, y0=11, w=w, h=h, want=("pre",))["pre"], part["pre"])
+    p = capi.default_params(precision=capi.PRECISION_F32, seed=1, shadow_bias=1e-4, use_photon_maps=0)
+    assert same(sc.trace_tile(p, want=("pre",))["pre"], ref["pre"])
 
 
 # ------------------------------------------------------------------ BASELINE config 4: the 10 000-primitive scene
