@@ -91,7 +91,7 @@ int rt_init(const int *device_ids, int n, rt_ctx **out) {
       return RT_ERR_HIP;
     }
   // the experiment switches: the environment is read here, once per context
-  static const char *names[] = { "tail_threshold", "whole_frame", "bounce_passes", "tail_handoff", "tail_rounds", "tail_persistent", "no_lds", "no_cull", "cull_lists", "raster_order", "bvh", "bvh_one_order", "wave_gather", "defer_gathers", "gather_sort", "gather_split", "knn_heap",
+  static const char *names[] = { "tail_threshold", "whole_frame", "bounce_passes", "tail_handoff", "tail_rounds", "tail_persistent", "no_lds", "no_cull", "cull_lists", "scan_groups", "raster_order", "bvh", "bvh_one_order", "wave_gather", "defer_gathers", "gather_sort", "gather_split", "knn_heap",
                                  "knn_verbose", "probe", "knn_radius_scale" };
   for (const char *nm : names) {
     std::string env = "RT355_";
@@ -128,6 +128,7 @@ int rt_set_option(rt_ctx *ctx, const char *name, double value) {
   else if (n == "no_lds") K.no_lds = value != 0;
   else if (n == "no_cull") K.no_cull = value != 0;
   else if (n == "cull_lists") K.cull_lists = value != 0;
+  else if (n == "scan_groups") K.scan_groups = value != 0;
   else if (n == "raster_order") K.raster_order = value != 0;
   else if (n == "bvh") K.bvh = (int)value;
   else if (n == "bvh_one_order") K.bvh_one_order = value != 0;
@@ -277,6 +278,88 @@ static bool rt_prim_box(int type, int flags, const double *g, double lo[3], doub
   }
 }
 
+// ------------------------------------------------------------------ scan groups (fp32 all-primitives scans)
+// Primitives that lie close together -- the faces of a box, a lamp's shells, rim and disc, a tube's walls and ends --
+// are put into a group with one bounding sphere; a scan skips the groups that no ray of its wave reaches.  gid[i]:
+// group of shape i (0: none -- unbounded, alone and cheap, or too spread out), spheres: 4 floats per group 0 .. n_groups.
+static double rt_prim_extent(int type, const double *g, const double X[3]) {      // farthest point of a bounded primitive from X
+  auto dist = [&](const double *p) { return sqrt((p[0] - X[0]) * (p[0] - X[0]) + (p[1] - X[1]) * (p[1] - X[1]) + (p[2] - X[2]) * (p[2] - X[2])); };
+  switch (type) {
+    case RT_SPHERE: case RT_HEMISPHERE: return dist(g) + fabs(g[6]);
+    case RT_DISC: case RT_ANNULUS: case RT_CYLINDER: {      // rim point(s) on the far side of the axis
+      const double nl = sqrt(g[3] * g[3] + g[4] * g[4] + g[5] * g[5]);
+      if (!(nl > 0)) return dist(g) + fabs(g[6]) + (type == RT_CYLINDER ? fabs(g[7]) : 0);
+      const double v[3] = { g[0] - X[0], g[1] - X[1], g[2] - X[2] };
+      const double h = (v[0] * g[3] + v[1] * g[4] + v[2] * g[5]) / nl;
+      const double rho2 = v[0] * v[0] + v[1] * v[1] + v[2] * v[2] - h * h;
+      const double along = fabs(h) + (type == RT_CYLINDER ? fabs(g[7]) : 0), across = sqrt(rho2 > 0 ? rho2 : 0) + fabs(g[6]);
+      return sqrt(along * along + across * across);
+    }
+    default: {                                               // triangle, square: the corners
+      double m = 0;
+      for (int c = 0; c < 4; c++) {
+        if (c == 3 && type != RT_SQUARE) break;
+        double p[3];
+        for (int k = 0; k < 3; k++) p[k] = g[k] + ((c & 1) ? g[3 + k] : 0) + ((c & 2) ? g[6 + k] : 0);
+        m = fmax(m, dist(p));
+      }
+      return m;
+    }
+  }
+}
+static uint32_t rt_scan_groups(const rt_scene_desc *d, std::vector<uint8_t> &gid, std::vector<float> &spheres) {
+  static const int cost[RT_NUM_TYPES] = { 8, 20, 30, 45, 37, 37, 22, 24 };     // instructions of one test, roughly
+  const uint32_t n = d->n_shapes;
+  gid.assign(n, 0); spheres.assign(4, 0.f);
+  struct Cluster { std::vector<uint32_t> members; double lo[3], hi[3], c[3], r; int cost; };
+  std::vector<Cluster> cl;
+  for (uint32_t i = 0; i < n; i++) {
+    const int type = d->shape_meta[4 * i], flags = d->shape_meta[4 * i + 2];
+    Cluster k; k.members.push_back(i); k.cost = cost[type];
+    if (!rt_prim_box(type, flags, d->shape_geom + (size_t)i * 12, k.lo, k.hi)) continue;
+    bool finite = true;
+    for (int a = 0; a < 3; a++) finite = finite && (k.lo[a] - k.lo[a]) == 0 && (k.hi[a] - k.hi[a]) == 0;
+    if (!finite) continue;
+    cl.push_back(k);
+  }
+  if (cl.empty() || cl.size() > 96) return 0;                // (larger scenes: the pairwise merging below is quartic)
+  auto bound = [&](Cluster &k) {                             // sphere around the centre of the members' boxes
+    for (int a = 0; a < 3; a++) k.c[a] = 0.5 * (k.lo[a] + k.hi[a]);
+    k.r = 0;
+    for (uint32_t i : k.members) k.r = fmax(k.r, rt_prim_extent(d->shape_meta[4 * i], d->shape_geom + (size_t)i * 12, k.c));
+  };
+  for (Cluster &k : cl) bound(k);
+  // merge the pair whose common sphere is the smallest multiple of the larger of its two spheres, while that is <= 1.2
+  for (;;) {
+    double best = 1.2; size_t ba = 0, bb = 0; Cluster bm;
+    for (size_t a = 0; a < cl.size(); a++)
+      for (size_t b = a + 1; b < cl.size(); b++) {
+        Cluster m; m.members = cl[a].members; m.members.insert(m.members.end(), cl[b].members.begin(), cl[b].members.end());
+        for (int k = 0; k < 3; k++) { m.lo[k] = fmin(cl[a].lo[k], cl[b].lo[k]); m.hi[k] = fmax(cl[a].hi[k], cl[b].hi[k]); }
+        m.cost = cl[a].cost + cl[b].cost;
+        bound(m);
+        const double ratio = m.r / fmax(fmax(cl[a].r, cl[b].r), 1e-300);
+        if (ratio <= best) { best = ratio; ba = a; bb = b; bm = m; }
+      }
+    if (ba == bb) break;
+    cl[ba] = bm; cl.erase(cl.begin() + (long)bb);
+  }
+  // a group's sphere test costs about 16 instructions per scan: only clusters worth several tests become groups
+  std::vector<size_t> keep;
+  for (size_t k = 0; k < cl.size(); k++) if (cl[k].cost >= 45) keep.push_back(k);
+  std::sort(keep.begin(), keep.end(), [&](size_t a, size_t b) { return cl[a].cost != cl[b].cost ? cl[a].cost > cl[b].cost : a < b; });
+  if (keep.size() > RT_MAX_GROUPS) keep.resize(RT_MAX_GROUPS);
+  std::sort(keep.begin(), keep.end());
+  uint32_t ng = 0;
+  for (size_t k : keep) {
+    ng++;
+    for (uint32_t i : cl[k].members) gid[i] = (uint8_t)ng;
+    for (int a = 0; a < 3; a++) spheres.push_back((float)cl[k].c[a]);
+    spheres.push_back((float)(cl[k].r * 1.002 + 4e-3));     // padded: the skip must be conservative in fp32
+  }
+  return ng;
+}
+
 struct BvhBuild {
   std::vector<BvhNode> nodes;
   std::vector<int8_t> split;                                // per node: axis whose lower centroids went to the first child, -1: none
@@ -399,12 +482,14 @@ struct BvhBuild {
 
 // Scenes whose type-sorted copy does not fit the scan kernels' LDS budget (or every scene, with option bvh = 1, for
 // tests) get a hierarchy; `order` maps sorted slot -> original index.
+static bool rt_wants_bvh(const rt_ctx *ctx, uint32_t n) {
+  const int knob = ctx->knobs.bvh;
+  return n > 0 && (knob >= 0 ? knob != 0 : (size_t)n * (RT_GEOM_STRIDE * 4 + 8 + RT_OT_STRIDE * 4) > 56 * 1024);
+}
 static int rt_build_bvh(rt_ctx *ctx, const rt_scene_desc *d, const std::vector<uint32_t> &order, rt_scene *sc, bool &built) {
   built = false;
   const uint32_t n = d->n_shapes;
-  const int knob = ctx->knobs.bvh;
-  const bool want = knob >= 0 ? knob != 0 : (size_t)n * (RT_GEOM_STRIDE * 4 + 8 + RT_OT_STRIDE * 4) > 56 * 1024;
-  if (!want || n == 0) return RT_OK;
+  if (!rt_wants_bvh(ctx, n)) return RT_OK;
   if (n >= (1u << 24)) return rt_fail(ctx, RT_ERR_TOO_LARGE, "hierarchy supports up to 2^24 primitives");
   BvhBuild B;
   std::vector<uint32_t> unbounded;
@@ -547,13 +632,23 @@ int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *d, rt_scene **out) {
   auto up = [&](DevMem &m, const void *src, size_t bytes) -> int {
     RT_HIP(ctx, m.alloc(bytes)); RT_HIP(ctx, hipMemcpy(m.p, src, bytes, hipMemcpyHostToDevice)); return RT_OK;
   };
+  // fp32 scan groups (see rt_scan_groups): spheres and, per group, the mask of its sorted slots; none with a hierarchy
+  std::vector<uint8_t> gid(n, 0);
+  std::vector<float> gspheres(4, 0.f);
+  uint32_t n_groups = 0;
+  if (!rt_wants_bvh(ctx, n) && ctx->knobs.scan_groups) n_groups = rt_scan_groups(d, gid, gspheres);
+  std::vector<uint64_t> gmask(n_groups + 1, 0);
+  for (uint32_t s = 0; s < n && s < 64; s++) gmask[gid[order[s]]] |= 1ull << s;
+  if (n < 64) gmask[0] |= ~0ull << n;
   if ((rc = up(sc->meta, d->shape_meta, (size_t)n * 4)) || (rc = up(sc->sorig, order.data(), (size_t)n * 4)) ||
       (rc = up(sc->sflags, sflags.data(), (size_t)n * 4)) ||
+      (rc = up(sc->gsphere, gspheres.data(), gspheres.size() * 4)) || (rc = up(sc->gmask, gmask.data(), gmask.size() * 8)) ||
       (rc = up(sc->spec_gt, spec_gt.data(), (size_t)n * 4)) ||
       (rc = upload_typed<float>(ctx, d, order, sc->geom32, sc->colour32, sc->sgeom32, sc->surface32, sc->hit32, sc->d32, sc, spec_gt)) ||
       (rc = upload_typed<double>(ctx, d, order, sc->geom64, sc->colour64, sc->sgeom64, sc->surface64, sc->hit64, sc->d64, sc, spec_gt))) {
     delete sc; return rc;
   }
+  sc->d32.n_groups = n_groups; sc->d32.gsphere = sc->gsphere.as<float4>(); sc->d32.gmask = sc->gmask.as<uint2>();
   bool has_bvh = false;
   if ((rc = rt_build_bvh(ctx, d, order, sc, has_bvh))) { delete sc; return rc; }
   {   // bounding spheres of the sorted primitives for the primary pass's per-workgroup culling (fp32 build)

@@ -63,7 +63,15 @@ template <typename T> struct DevScene {
   uint32_t bvh_octant_stride;    // nodes between the per-octant copies of the hierarchy (0: one copy)
   const float4 *sbound;       // per sorted slot: bounding sphere (centre, radius; +inf = unbounded), fp32 build only, or nullptr
   const float *sot_cam;       // per sorted slot: the origin terms (RT_OT_STRIDE floats) for rays that start at the camera, fp32 build only, or nullptr
+  // fp32 build: GROUPS of primitives that lie close together.  A scan first finds the groups whose bounding sphere some
+  // ray of its wave reaches and skips the sorted slots of the others (scan_fast).  gsphere[g] = centre, padded radius
+  // of group g = 1 .. n_groups; gmask[g] = its sorted slots as a bit mask (slots 0 .. 63; later slots are always
+  // tested); gmask[0] = the slots outside every group.
+  uint32_t n_groups;          // <= RT_MAX_GROUPS
+  const float4 *gsphere;
+  const uint2 *gmask;
 };
+#define RT_MAX_GROUPS 31
 
 // A miss is reported as -1 (every accepted distance is > epsilon > 0).
 template <typename T> RT_D T miss() { return T(-1); }
@@ -305,13 +313,16 @@ template <int TYPE> RT_D void load_origin_terms(const float *ot, float *out) {
   for (int k = 0; k < N; k++) out[k] = ot[k];
 }
 
-template <typename T> struct ScanSrc { const T *geom; const uint32_t *orig; const uint32_t *flags; const T *ot; };
+template <typename T> struct ScanSrc { const T *geom; const uint32_t *orig; const uint32_t *flags; const T *ot; const float4 *gsphere; const uint2 *gmask; };
 
 // LDS bytes needed to stage n primitives
 // (fp32: + origin terms, + the list of primitives a workgroup's primary rays can reach: 9 segment bounds, n slots,
 // n flag bytes)
+// (fp32: + the scan groups' spheres and slot masks)
+constexpr size_t scan_lds_groups_offset(uint32_t n) { return (((size_t)n * (RT_GEOM_STRIDE * 4 + 8 + RT_OT_STRIDE * 4 + 3) + 64) + 15) & ~(size_t)15; }
 template <typename T> constexpr size_t scan_lds_bytes(uint32_t n) {
-  return (size_t)n * (RT_GEOM_STRIDE * sizeof(T) + 8 + (sizeof(T) == 4 ? RT_OT_STRIDE * 4 + 3 : 0)) + (sizeof(T) == 4 ? 64 : 0);
+  return sizeof(T) == 4 ? scan_lds_groups_offset(n) + (RT_MAX_GROUPS + 1) * 24
+                        : (size_t)n * (RT_GEOM_STRIDE * sizeof(T) + 8);
 }
 // where that list lives in a workgroup's staging area
 RT_D uint32_t *scan_lds_vseg(uint32_t n, void *lds) { return (uint32_t *)((char *)lds + (size_t)n * (RT_GEOM_STRIDE * 4 + 8 + RT_OT_STRIDE * 4)); }
@@ -334,6 +345,11 @@ template <typename T> RT_D ScanSrc<T> stage_scene_lds(const DevScene<T> &S, void
   uint4 *dst = (uint4 *)lg;
   const uint32_t o0 = S.sorig[tid < n ? tid : 0], f0 = S.sflags32[tid < n ? tid : 0];     // (first round of the words: in flight with the pieces)
   const uint32_t x0 = (extra && tid < n_extra) ? extra[tid] : 0u;
+  uint32_t n_mask_words = 0, n_sphere_words = 0, m0 = 0, g0 = 0;
+  if constexpr (sizeof(T) == 4) {
+    n_mask_words = 2u * (S.n_groups + 1u); n_sphere_words = 4u * (S.n_groups + 1u);      // (at most 64 and 128: one word per thread)
+    m0 = ((const uint32_t *)S.gmask)[tid < n_mask_words ? tid : 0]; g0 = ((const uint32_t *)S.gsphere)[tid < n_sphere_words ? tid : 0];
+  }
   bool ot_copied = false;
   float t0 = 0.f;
   if constexpr (sizeof(T) == 4) {
@@ -353,7 +369,15 @@ template <typename T> RT_D ScanSrc<T> stage_scene_lds(const DevScene<T> &S, void
     if (tid < n_extra) extra_dst[tid] = x0;
     for (uint32_t i = tid + nt; i < n_extra; i += nt) extra_dst[i] = extra[i];
   }
-  ScanSrc<T> G; G.geom = lg; G.orig = lo; G.flags = lf; G.ot = nullptr;
+  ScanSrc<T> G; G.geom = lg; G.orig = lo; G.flags = lf; G.ot = nullptr; G.gsphere = nullptr; G.gmask = nullptr;
+  if constexpr (sizeof(T) == 4) {
+    uint32_t *lsph = (uint32_t *)((char *)lds + scan_lds_groups_offset(n)), *lm = lsph + 4u * (RT_MAX_GROUPS + 1);
+    if (tid < n_sphere_words) lsph[tid] = g0;
+    for (uint32_t i = tid + nt; i < n_sphere_words; i += nt) lsph[i] = ((const uint32_t *)S.gsphere)[i];
+    if (tid < n_mask_words) lm[tid] = m0;
+    for (uint32_t i = tid + nt; i < n_mask_words; i += nt) lm[i] = ((const uint32_t *)S.gmask)[i];
+    G.gsphere = (const float4 *)lsph; G.gmask = (const uint2 *)lm;
+  }
   if constexpr (sizeof(T) == 4) {
     if (ot_copied) {
       float *lt = (float *)(lf + n);
@@ -375,7 +399,7 @@ template <typename T> RT_D ScanSrc<T> stage_scene_lds(const DevScene<T> &S, void
   return G;
 }
 template <typename T> RT_D ScanSrc<T> global_scan_src(const DevScene<T> &S) {
-  ScanSrc<T> G; G.geom = S.sgeom; G.orig = S.sorig; G.flags = S.sflags32; G.ot = nullptr;
+  ScanSrc<T> G; G.geom = S.sgeom; G.orig = S.sorig; G.flags = S.sflags32; G.ot = nullptr; G.gsphere = S.gsphere; G.gmask = S.gmask;
   return G;
 }
 
@@ -391,22 +415,65 @@ template <int MODE, bool OT> RT_D int scan_fast(const DevScene<float> &S, const 
   float best = __builtin_huge_valf(); int best_s = -1;
   const float lim = (MODE == 2) ? limit - eps : 0.0f;
   bool occluded = false;
-#define RT_FAST_LOOP(TYPE)                                                                              \
-  RT_SCAN_UNROLL_PRAGMA                                                                                 \
-  for (uint32_t s = S.seg[TYPE]; s < S.seg[TYPE + 1]; s++) {                                            \
+  // Sorted slots (0 .. 63) whose primitives some ray of this wave can reach: those outside every group, and those of
+  // the groups whose sphere a ray reaches.  A ray reaches a sphere if its line passes within the radius and the centre
+  // lies ahead of the origin or the origin inside; the distance from the line is taken of q = oc - (oc.d) d itself,
+  // whose rounding error grows with |oc|, not |oc|^2, and the radii are padded, so a wave never skips a primitive that
+  // one of its rays would hit (d is a unit vector).  The next group's sphere is fetched while this one is tested.
+  unsigned long long act = ~0ull;
+  if (S.n_groups) {
+    const uint2 m0 = G.gmask[0];
+    act = (unsigned long long)m0.x | ((unsigned long long)m0.y << 32);
+    float4 bs = G.gsphere[1]; uint2 gm = G.gmask[1];
+    for (uint32_t g = 1; g <= S.n_groups; g++) {
+      const uint32_t gn = g < S.n_groups ? g + 1 : g;
+      const float4 bs_next = G.gsphere[gn]; const uint2 gm_next = G.gmask[gn];
+      const V3<float> oc = o - mk<float>(bs.x, bs.y, bs.z);
+      const float b = dot(oc, d), r2 = bs.w * bs.w;
+      const V3<float> q = oc - b * d;
+      const bool may = sqlen(q) <= r2 && (b < 0.0f || sqlen(oc) <= r2);
+      if (__ballot(may) != 0ull) act |= (unsigned long long)gm.x | ((unsigned long long)gm.y << 32);
+      bs = bs_next; gm = gm_next;
+    }
+  }
+#define RT_FAST_BODY(TYPE, SLOT)                                                                        \
+  {                                                                                                     \
+    const uint32_t s = (SLOT);                                                                          \
     float f[RT_GEOM_STRIDE], ot[RT_OT_STRIDE];                                                          \
     load_record<TYPE>(G.geom + (size_t)s * RT_GEOM_STRIDE, f);                                          \
     const int flags = (MODE == 1 || MODE == 2 || TYPE == RT_CYLINDER) ? (int)G.flags[s] : 0;            \
     if (OT) load_origin_terms<TYPE>(G.ot + (size_t)s * RT_OT_STRIDE, ot);                               \
-    if ((MODE == 1 || MODE == 2) && (flags & RT_FLAG_LIGHT)) continue;                                  \
+    const bool counts = !((MODE == 1 || MODE == 2) && (flags & RT_FLAG_LIGHT));                         \
     if (!OT) origin_terms<TYPE>(f, o, ot);                                                              \
     const float t = isect_fast<TYPE>(f, ot, d, eps, flags);                                             \
-    if (MODE == 2) occluded = occluded || (t > eps && t < lim);                                         \
-    else { const bool upd = t > eps && t < best; best = upd ? t : best; best_s = upd ? (int)s : best_s; } \
+    if (MODE == 2) occluded = occluded || (counts && t > eps && t < lim);                               \
+    else { const bool upd = counts && t > eps && t < best; best = upd ? t : best; best_s = upd ? (int)s : best_s; } \
   }
-  RT_FAST_LOOP(RT_PLANE) RT_FAST_LOOP(RT_SPHERE) RT_FAST_LOOP(RT_HEMISPHERE) RT_FAST_LOOP(RT_CYLINDER)
-  RT_FAST_LOOP(RT_TRIANGLE) RT_FAST_LOOP(RT_SQUARE) RT_FAST_LOOP(RT_DISC) RT_FAST_LOOP(RT_ANNULUS)
+  if (S.n_shapes <= 64u) {
+    // the slots to test as bits, taken two at a time (two tests in flight hide each other's LDS round trips)
+#define RT_FAST_LOOP(TYPE)                                                                              \
+    {                                                                                                   \
+      const uint32_t s0 = S.seg[TYPE], s1 = S.seg[TYPE + 1];                                            \
+      unsigned long long m = act & ((s1 >= 64u ? ~0ull : ((1ull << s1) - 1ull)) & ~((1ull << s0) - 1ull)); \
+      while (m & (m - 1ull)) {                                                                          \
+        const uint32_t sa = (uint32_t)__builtin_ctzll(m); m &= m - 1ull;                                \
+        const uint32_t sb = (uint32_t)__builtin_ctzll(m); m &= m - 1ull;                                \
+        RT_FAST_BODY(TYPE, sa) RT_FAST_BODY(TYPE, sb)                                                   \
+      }                                                                                                 \
+      if (m) RT_FAST_BODY(TYPE, (uint32_t)__builtin_ctzll(m))                                           \
+    }
+    RT_FAST_LOOP(RT_PLANE) RT_FAST_LOOP(RT_SPHERE) RT_FAST_LOOP(RT_HEMISPHERE) RT_FAST_LOOP(RT_CYLINDER)
+    RT_FAST_LOOP(RT_TRIANGLE) RT_FAST_LOOP(RT_SQUARE) RT_FAST_LOOP(RT_DISC) RT_FAST_LOOP(RT_ANNULUS)
 #undef RT_FAST_LOOP
+  } else {
+#define RT_FAST_LOOP(TYPE)                                                                              \
+    RT_SCAN_UNROLL_PRAGMA                                                                               \
+    for (uint32_t s_ = S.seg[TYPE]; s_ < S.seg[TYPE + 1]; s_++) RT_FAST_BODY(TYPE, s_)
+    RT_FAST_LOOP(RT_PLANE) RT_FAST_LOOP(RT_SPHERE) RT_FAST_LOOP(RT_HEMISPHERE) RT_FAST_LOOP(RT_CYLINDER)
+    RT_FAST_LOOP(RT_TRIANGLE) RT_FAST_LOOP(RT_SQUARE) RT_FAST_LOOP(RT_DISC) RT_FAST_LOOP(RT_ANNULUS)
+#undef RT_FAST_LOOP
+  }
+#undef RT_FAST_BODY
   if (MODE == 2) { t_out = 0.0f; return occluded ? 1 : 0; }
   t_out = best;
   return best_s >= 0 ? (int)G.orig[best_s] : -1;

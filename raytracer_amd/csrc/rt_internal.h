@@ -39,6 +39,7 @@ struct RtKnobs {
                                  // tail kernel; < 0: by the number of frames in flight (persistent lanes pay from three on)
   int no_lds = 0;                // 1: scans read the primitives through scalar loads instead of the LDS copy
   int no_cull = 0;               // 1: the first pass scans every primitive (no per-workgroup culling)
+  int scan_groups = 1;           // 0: scenes are uploaded without scan groups (every fp32 all-primitives scan tests every primitive)
   int cull_lists = 1;            // 0: every workgroup of the first pass works out its own list of reachable primitives, every frame
   int raster_order = 0;          // 1: paths numbered row by row even where 32x8 tiles would fit
   int bvh = -1;                  // hierarchy at upload: -1 by scene size, 0 never, 1 always
@@ -129,7 +130,7 @@ static inline uint32_t div_up(uint64_t a, uint32_t b) { return (uint32_t)((a + b
 struct rt_scene {
   rt_ctx *ctx = nullptr;
   DevMem meta, geom32, geom64, colour32, colour64, sgeom32, sgeom64, sorig, sflags, surface32, surface64, spec_gt, hit32, hit64;
-  DevMem bvh_nodes, bvh_prims, bvh_unbounded, sbound, sot_cam;
+  DevMem bvh_nodes, bvh_prims, bvh_unbounded, sbound, sot_cam, gsphere, gmask;
   DevScene<float> d32; DevScene<double> d64;
   // per-scene workspaces (grow-only) so that steady-state calls do not allocate
   // rt_trace_tile's workspaces, one set per frame in flight

@@ -1090,6 +1090,54 @@ def test_culling_and_tile_order_are_exact(rt, size):
     assert same(sc.trace_tile(p, want=("pre",))["pre"], ref["pre"])
 
 
+@pytest.mark.parametrize("name", ALL_PRESETS)
+def test_scan_groups_are_exact(rt, name):
+    """fp32 scans skip the groups of primitives (box faces, a lamp's shells ...) whose bounding sphere no ray of the wave
+    reaches.  That is only a schedule: scans of incoherent random rays in all three modes, the emitted photon lists and a
+    frame with direct light must equal, bit for bit, those of the same scene uploaded without groups -- also with the
+    scene 200 times larger and far from the origin, where the sphere test's rounding matters most."""
+    capi, ctx = rt
+    W, H = 160, 96
+    rng = np.random.default_rng(99)
+    for scale, shift in ((1.0, 0.0), (200.0, 5000.0)):
+        flat = load_packaged_preset(name, W, H)
+        g = flat.shape_geom.copy()
+        t = flat.shape_meta[:, 0]
+        g[:, 0:3] = g[:, 0:3] * scale + shift                                   # every type keeps a point in slots 0-2
+        g[:, 6] *= scale                                                         # radius / AC.x
+        tri = (t == 4) | (t == 5)
+        g[tri, 3:6] *= scale; g[tri, 7:9] *= scale                               # AB, rest of AC
+        rnd = (t == 2) | (t == 3) | (t == 7)
+        g[rnd, 7] *= scale; g[t == 2, 8] *= scale                                # truncMin / halfHeight / inner radius, truncMax
+        cam = flat.camera.copy(); cam[0:3] = cam[0:3] * scale + shift
+        flat2 = type(flat)(flat.shape_meta, g, flat.shape_colour, flat.light_shape, flat.light_data, cam, W, H, flat.materials, flat.shape_surface)
+        with ctx.option("scan_groups", 0, 1):
+            plain = ctx.upload(flat2)
+        grouped = ctx.upload(flat2)
+        p = capi.default_params(precision=capi.PRECISION_F32, seed=SEED, use_photon_maps=0, max_trace_dist=1000.0 * scale,
+                                num_photons_diffuse=3000, num_photons_caustic=3000, max_bounces=200)
+        n = 20000
+        lo, hi = g[:, 0:3].min(axis=0) - 2 * scale, g[:, 0:3].max(axis=0) + 2 * scale
+        ro = lo + rng.random((n, 3)) * (hi - lo)
+        rd = rng.normal(size=(n, 3)); rd /= np.linalg.norm(rd, axis=1, keepdims=True)
+        # half of the rays in bundles of 64 with nearly one direction and origin (waves that do skip groups)
+        ro[n // 2:] = np.repeat(ro[n // 2::64], 64, axis=0)[:n - n // 2] + 0.01 * scale * rng.normal(size=(n - n // 2, 3))
+        rd[n // 2:] = np.repeat(rd[n // 2::64], 64, axis=0)[:n - n // 2] + 0.02 * rng.normal(size=(n - n // 2, 3))
+        rd /= np.linalg.norm(rd, axis=1, keepdims=True)
+        for mode in (capi.SCAN_CLOSEST, capi.SCAN_CLOSEST_NOLIGHT, capi.SCAN_ANY):
+            sd = np.full(n, 30.0 * scale) if mode == capi.SCAN_ANY else None
+            ta, ia = plain.intersect(p, mode, ro, rd, sd)
+            tb, ib = grouped.intersect(p, mode, ro, rd, sd)
+            assert np.array_equal(ia, ib) and same(ta, tb), (name, scale, mode)
+        a, b = plain.trace_tile(p, want=("pre",)), grouped.trace_tile(p, want=("pre",))
+        assert same(a["pre"], b["pre"]) and a["stats"]["rays"] == b["stats"]["rays"] and a["stats"]["shadow_rays"] == b["stats"]["shadow_rays"], (name, scale)
+        if scale == 1.0:
+            ea, eb = plain.emit_many(p, strict=False), grouped.emit_many(p, strict=False)
+            assert same(ea["diffuse"], eb["diffuse"]) and same(ea["caustic"], eb["caustic"]), name
+            assert ea["stats"]["attempts_phase1"] == eb["stats"]["attempts_phase1"] and ea["stats"]["attempts_phase2"] == eb["stats"]["attempts_phase2"]
+        plain.close(); grouped.close()
+
+
 # ------------------------------------------------------------------ BASELINE config 4: the 10 000-primitive scene
 def test_config4_scene_matches_the_oracle(rt):
     """the synthetic 10 000-primitive scene (hierarchy chosen automatically), fp64, direct light on, paths of up to 8
