@@ -636,7 +636,7 @@ int rt_scene_upload(rt_ctx *ctx, const rt_scene_desc *d, rt_scene **out) {
   std::vector<uint8_t> gid(n, 0);
   std::vector<float> gspheres(4, 0.f);
   uint32_t n_groups = 0;
-  if (!rt_wants_bvh(ctx, n) && ctx->knobs.scan_groups) n_groups = rt_scan_groups(d, gid, gspheres);
+  if (!rt_wants_bvh(ctx, n) && ctx->knobs.scan_groups && n <= 64) n_groups = rt_scan_groups(d, gid, gspheres);    // (a scan keeps the slots to test in 64 bits)
   std::vector<uint64_t> gmask(n_groups + 1, 0);
   for (uint32_t s = 0; s < n && s < 64; s++) gmask[gid[order[s]]] |= 1ull << s;
   if (n < 64) gmask[0] |= ~0ull << n;

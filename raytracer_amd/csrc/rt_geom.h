@@ -411,7 +411,8 @@ template <typename T> RT_D ScanSrc<T> global_scan_src(const DevScene<T> &S) {
 #define RT_SCAN_UNROLL_PRAGMA RT_PRAGMA_(unroll RT_SCAN_UNROLL)
 // fp32 scan over the precomputed records; same MODEs as scan_scene below.  Equal distances keep the first
 // primitive in type-sorted order.
-template <int MODE, bool OT> RT_D int scan_fast(const DevScene<float> &S, const ScanSrc<float> &G, V3<float> o, V3<float> d, float eps, float limit, float &t_out) {
+template <int MODE, bool OT> RT_D int scan_fast(const DevScene<float> &S, const ScanSrc<float> &G, V3<float> o, V3<float> d, float eps, float limit, float &t_out,
+                                                uint32_t *tests = nullptr) {
   float best = __builtin_huge_valf(); int best_s = -1;
   const float lim = (MODE == 2) ? limit - eps : 0.0f;
   bool occluded = false;
@@ -435,6 +436,8 @@ template <int MODE, bool OT> RT_D int scan_fast(const DevScene<float> &S, const 
       if (__ballot(may) != 0ull) act |= (unsigned long long)gm.x | ((unsigned long long)gm.y << 32);
       bs = bs_next; gm = gm_next;
     }
+    // (statistics: the primitives this closest-hit scan goes on to test)
+    if (MODE != 2 && tests) *tests += (uint32_t)__popcll(S.n_shapes >= 64u ? act : act & ((1ull << S.n_shapes) - 1ull));
   }
 #define RT_FAST_BODY(TYPE, SLOT)                                                                        \
   {                                                                                                     \
@@ -579,7 +582,7 @@ template <typename T, int MODE> RT_D int scan_bvh(const DevScene<T> &S, V3<T> o,
 template <typename T, int MODE, bool OT = false> RT_D int scan_scene(const DevScene<T> &S, const ScanSrc<T> &G, V3<T> o, V3<T> d, T eps, T limit, T &t_out,
                                                                      uint32_t *tests = nullptr) {
   if (S.bvh) return scan_bvh<T, MODE>(S, o, d, eps, limit, t_out, tests);
-  if constexpr (sizeof(T) == 4) return scan_fast<MODE, OT>(S, G, o, d, eps, limit, t_out);
+  if constexpr (sizeof(T) == 4) return scan_fast<MODE, OT>(S, G, o, d, eps, limit, t_out, tests);
   T best = Limits<T>::inf(); int best_idx = -1;
   const T lim = (MODE == 2) ? limit - eps : T(0);
 #define RT_SCAN_LOOP(TYPE, EXPR)                                                        \

@@ -354,7 +354,11 @@ static int trace_tile_mode(rt_scene *sc, int slot, const rt_params *p, DevMap md
     // without a hierarchy every segment is tested against every primitive (shadow rays stop at the first occluder)
     // the fp32 primary pass scans only the primitives each workgroup's rays can reach and counts them
     const bool culled = !whole_frame && lds && sizeof(T) == 4 && S.sbound != nullptr;
-    stats->prim_tests = S.bvh ? tests : (culled ? tests + (stats->rays - n_paths) * (uint64_t)S.n_shapes : stats->rays * (uint64_t)S.n_shapes);
+    // fp32 scans of a scene with scan groups (<= 64 primitives) count what they test after skipping the groups out of reach
+    bool grouped = false;
+    if constexpr (sizeof(T) == 4) grouped = S.n_groups > 0 && S.n_shapes <= 64;
+    stats->prim_tests = (S.bvh || grouped) ? tests
+                                           : (culled ? tests + (stats->rays - n_paths) * (uint64_t)S.n_shapes : stats->rays * (uint64_t)S.n_shapes);
     stats->prims_per_ray_brute_force = S.n_shapes;
   }
   return RT_OK;
