@@ -595,13 +595,14 @@ def main():
             tx_avg, px_avg = tx_ms / max(1, tx_n) * 1e-3, px_ms / max(1, px_n) * 1e-3
             frame_ach = (rays // args.steps) * fl / (t_total / args.steps) / 1e12
             line["roofline"] = {
-                "kernel": ("k_tail_persistent<float> (every path that survives its first hit, to its end: all-primitives closest-hit scan + shade per "
-                           "segment; a lane whose path has ended takes the next queued path of its workgroup's chunk)" if in_flight >= 3 else
-                           "k_tail<float> (every path that survives its first hit, to its end: all-primitives closest-hit scan + shade per segment, "
+                "kernel": ("k_tail_persistent<float> (every path that survives its first hit, to its end: closest-hit scan (every primitive, less the groups "
+                           "no ray of the wave reaches) + shade per segment; a lane whose path has ended takes the next queued path of its workgroup's chunk)" if in_flight >= 3 else
+                           "k_tail<float> (every path that survives its first hit, to its end: closest-hit scan (every primitive, less the groups no ray of the wave reaches) + shade per segment, "
                            "256-lane groups with LDS-resident path state)") + " -- the longer of the frame's two kernels",
                 "bound": "valu", "achieved": ach, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_VALU_TFLOPS,
                 "traffic": measured_traffic("k_tail_persistent" if in_flight >= 3 else "k_tail"), "algorithmic_flop_per_ray_pass": fl, "avg_launch_ms": t_avg * 1e3,
                 "segments_per_launch": int(tail_rays), "launches_per_step": tail_launches / args.steps,
+                "primitive_tests_per_segment_executed": st["prim_tests"] / max(1, st["rays"]),
                 "note": "the timed frames overlap (three frames in flight), so a launch shares the chip with the neighbouring frames' kernels and its duration is not its cost; "
                         "`exclusive` has both kernels on frames run one at a time; `frame` is the whole frame against the driver's clock. "
                         "bound 'valu': this path is neither HBM- nor MFMA-bound; peak = fp32 vector FMA rate (the measured sustained v_fma_f32 "

@@ -133,8 +133,10 @@ int rt_synchronize(rt_ctx *ctx);            /* host wait for everything the cont
  * order their own work behind rt_stream() (an event, hipStreamWaitEvent, a framework's external-stream wrapper)
  * instead of calling rt_synchronize().  No counterpart in the reference. */
 int rt_join(rt_ctx *ctx);
-/* Experiment / test switches, by name: tail_threshold, whole_frame, bounce_passes, no_lds, no_cull, raster_order,
- * bvh (-1 by scene size / 0 / 1; read by rt_scene_upload), knn_heap, knn_radius_scale, knn_verbose, probe.  rt_init reads
+/* Experiment / test switches, by name: tail_threshold, whole_frame, bounce_passes, tail_handoff, tail_rounds,
+ * tail_persistent, no_lds, no_cull, cull_lists, raster_order, bvh (-1 by scene size / 0 / 1) and scan_groups (0 / 1)
+ * (both read by rt_scene_upload), bvh_one_order, defer_gathers, gather_sort, gather_split, wave_gather, knn_heap,
+ * knn_radius_scale, knn_verbose, probe.  rt_init reads
  * RT355_<NAME> from the environment once; this call changes one switch of a live context.  The defaults are the
  * measured best; results do not depend on any of them (fp32 images: bit for bit).  No counterpart in the reference. */
 int rt_set_option(rt_ctx *ctx, const char *name, double value);
