@@ -146,7 +146,8 @@ int rt_set_option(rt_ctx *ctx, const char *name, double value);
  * serial by construction). */
 int rt_set_frames_in_flight(rt_ctx *ctx, int n);
 /* Per-kernel HIP-event timing (off by default).  rt_profile_get sums the launches of one
- * kernel name since the last reset; it synchronises the stream. */
+ * kernel name since the last reset; it synchronises the stream.  on = n > 1: only every n-th launch of a kernel
+ * name is timed (a sample: a launch that carries events does not overlap its neighbours as freely). */
 int rt_profile_enable(rt_ctx *ctx, int on);
 /* restrict event timing to the launches of the named kernels, comma-separated, e.g. "primary,tail"
  * (NULL or "" = all kernels again) */

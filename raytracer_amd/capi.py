@@ -185,7 +185,7 @@ class Context:
 
     # -- profiling
     def profile_enable(self, on=True):
-        self.check(self.lib.rt_profile_enable(self.h, int(on)))
+        self.check(self.lib.rt_profile_enable(self.h, int(on)))      # (an int n > 1: every n-th launch of a kernel name is timed)
 
     def profile_select(self, kernel=None):
         self.check(self.lib.rt_profile_select(self.h, kernel.encode() if kernel else None))

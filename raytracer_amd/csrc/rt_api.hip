@@ -188,7 +188,11 @@ int rt_set_frames_in_flight(rt_ctx *ctx, int n) {
   return RT_OK;
 }
 
-int rt_profile_enable(rt_ctx *ctx, int on) { if (!ctx) return RT_ERR_INVALID; ctx->profiling = on != 0; return RT_OK; }
+int rt_profile_enable(rt_ctx *ctx, int on) {
+  if (!ctx) return RT_ERR_INVALID;
+  ctx->profiling = on != 0; ctx->profile_every = on > 1 ? on : 1; ctx->profile_seen.clear();
+  return RT_OK;
+}
 int rt_profile_select(rt_ctx *ctx, const char *kernels) {
   if (!ctx) return RT_ERR_INVALID;
   ctx->profile_only = (kernels && *kernels) ? "," + std::string(kernels) + "," : "";

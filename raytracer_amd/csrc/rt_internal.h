@@ -64,6 +64,8 @@ struct rt_ctx {
   bool alt_used = false;                 // something was queued on streams[1..] since they were last synchronised
   std::string err;
   bool profiling = false;
+  int profile_every = 1;         // time every n-th launch of a selected kernel name (rt_profile_enable(ctx, n))
+  std::map<std::string, uint64_t> profile_seen;
   std::string profile_only;      // when non-empty: ",name1,name2," -- only launches under these names are timed
   std::map<std::string, std::vector<std::pair<hipEvent_t, hipEvent_t>>> events;
   std::vector<hipEvent_t> event_pool;   // events free for reuse (creating one per launch costs more than recording it)
@@ -99,18 +101,20 @@ int rt_stage_out_begin(rt_ctx *ctx, void *dst, size_t bytes, DevMem &tmp, void *
 // Copies `tmp` back to a host `dst` (no-op for device `dst`); synchronises the stream.
 int rt_stage_out_end(rt_ctx *ctx, void *dst, size_t bytes, DevMem &tmp);
 
+static inline bool rt_timing(rt_ctx *ctx, const char *name);
 struct KernelTimer {
   rt_ctx *ctx; hipEvent_t a = nullptr, b = nullptr; const char *name;
   KernelTimer(rt_ctx *c, const char *n) : ctx(c), name(n) {
-    if (ctx->profiling && (ctx->profile_only.empty() || ctx->profile_only.find("," + std::string(n) + ",") != std::string::npos)) { a = ctx->take_event(); b = ctx->take_event(); (void)hipEventRecord(a, ctx->stream); }   // (library routines: events around the call)
+    if (rt_timing(ctx, n)) { a = ctx->take_event(); b = ctx->take_event(); (void)hipEventRecord(a, ctx->stream); }   // (library routines: events around the call)
   }
   ~KernelTimer() {
     if (a) { (void)hipEventRecord(b, ctx->stream); ctx->events[name].push_back({ a, b }); }
   }
 };
 
-static inline bool rt_timing(const rt_ctx *ctx, const char *name) {
-  return ctx->profiling && (ctx->profile_only.empty() || ctx->profile_only.find("," + std::string(name) + ",") != std::string::npos);
+static inline bool rt_timing(rt_ctx *ctx, const char *name) {
+  if (!ctx->profiling || !(ctx->profile_only.empty() || ctx->profile_only.find("," + std::string(name) + ",") != std::string::npos)) return false;
+  return ctx->profile_every <= 1 || ctx->profile_seen[name]++ % (uint64_t)ctx->profile_every == 0;
 }
 
 // launch on the context's stream; when profiling is on for `name`, the dispatch itself carries the start/stop events
