@@ -204,6 +204,7 @@ def main():
     ap.add_argument("--independent-frames", action="store_true", help="N > 1: every rank renders whole frames of its own (weak scaling) instead of the one-job split")
     ap.add_argument("--photons-per-gpu", type=int, default=12_500_000, help="N > 1: stored photons per GPU of the sharded emission (half diffuse, half caustic)")
     ap.add_argument("--band", type=int, default=16, help="N > 1: rows per interleaved band")
+    ap.add_argument("--frames-per-gather", type=int, default=8, help="N > 1: frames whose bands travel to rank 0 in one collective")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -557,20 +558,27 @@ def main():
             reng = _RehearsalEngine(sc, p, device=dev, inner=reng)
         rows = ctx.band_rows(H, args.band, world, rank)
         st_full = sc.trace_tile(p, want=())["stats"]                     # the whole frame once, for its segment count (every rank, same number)
-        bufs = [torch.empty((rows, W, 4), dtype=torch.uint8, device=dev) for _ in range(2)]
-        frame0 = torch.empty((H, W, 4), dtype=torch.uint8, device=cdev) if rank == 0 else None
+        # frames go to rank 0 in batches: every rank traces its bands of up to G frames back to back (three in flight), then
+        # ONE gather brings them together -- a frame's bands take tens of microseconds, less than a collective's latency
+        G = max(1, args.frames_per_gather)
+        bufs = {}
+        frames0 = torch.empty((G, H, W, 4), dtype=torch.uint8, device=cdev) if rank == 0 else None
 
-        def frame_step(i):
-            reng.out = bufs[i % 2]
-            parallel.render_sharded(reng, W, H, band=args.band, out=frame0)
+        def frame_group(n):
+            if n not in bufs:
+                bufs[n] = torch.empty((n, rows, W, 4), dtype=torch.uint8, device=dev)
+            reng.out = bufs[n]
+            parallel.render_sharded_batch(reng, W, H, n, band=args.band, out=frames0[:n] if rank == 0 else None)
 
-        for i in range(max(args.warmup, 1)):
-            frame_step(i)
+        for g0 in range(0, max(args.warmup, 1), G):
+            frame_group(min(G, max(args.warmup, 1) - g0))
+        if args.steps % G and args.steps > G:
+            frame_group(args.steps % G)          # (the last, shorter batch's buffer exists before the clock starts)
         barrier()
         t0 = time.perf_counter()
         t_render = 0.0
-        for i in range(args.steps):
-            frame_step(i)
+        for g0 in range(0, args.steps, G):
+            frame_group(min(G, args.steps - g0))
         barrier()
         dt = time.perf_counter() - t0
         tmax = torch.tensor([dt], dtype=torch.float64, device=cdev)
@@ -591,7 +599,8 @@ def main():
             "allgather_bytes": ag_bytes, "allgather_gbps": (ag_bytes / T["exchange_s"] / 1e9) if T.get("exchange_s") else None,
             "kd_build": {"seconds": t_build, "photons": stored, "note": "both maps, built identically on every rank from its own copy of the lists"},
             "render": {"seconds": dt, "frames": args.steps, "ms_per_frame": dt / args.steps * 1e3, "band_rows": args.band,
-                       "gather_bytes_per_frame": W * H * 4, "note": "every frame: this rank's interleaved bands in one rt_trace_tile call, then gathered to rank 0"},
+                       "gather_bytes_per_frame": W * H * 4, "frames_per_gather": G,
+                       "note": "every frame: this rank's interleaved bands in one rt_trace_tile call (queued, three in flight); the bands of frames_per_gather frames gathered to rank 0 by one collective"},
         }
         parallelism = f"one job over {world} GPUs: emission by attempt range, photon all-gather, replicated kd build, frames split into interleaved {args.band}-row bands gathered to rank 0"
         scaling = "strong"
@@ -681,6 +690,10 @@ class _RehearsalEngine:
     def render_bands(self, width, height, band, world, rank):
         self.inner.out = self.out
         return self.inner.render_bands(width, height, band, world, rank).cpu()
+
+    def render_bands_batch(self, width, height, band, world, rank, n_frames):
+        self.inner.out = self.out
+        return self.inner.render_bands_batch(width, height, band, world, rank, n_frames).cpu()
 
 
 if __name__ == "__main__":

@@ -1344,3 +1344,15 @@ def test_row_bands_assemble_to_the_whole_frame(rt, size, band, count):
         assert same(got, whole["pre"]) and np.array_equal(got8, whole["rgba8"]) and rays == whole["stats"]["rays"]
     with pytest.raises(capi.RtError):
         sc.trace_tile(capi.default_params(band_rows=12, band_count=2, band_index=0))
+    # the multi-GPU protocol's batched form: every rank's bands of several frames queued back to back (frames in flight)
+    import torch
+    from raytracer_amd import parallel
+    p = capi.default_params(precision=capi.PRECISION_F32, seed=9, use_direct_light=0, use_photon_maps=0)
+    whole8 = sc.trace_tile(p, want=("rgba8",))["rgba8"]
+    eng = parallel.DeviceEngine(sc, p, device="cuda", with_lists=False)
+    for idx in range(count):
+        rows = parallel.band_rows_of(H, band, count, idx)
+        parts = eng.render_bands_batch(W, H, band, count, idx, 5)
+        assert tuple(parts.shape) == (5, rows.size, W, 4)
+        for f in parts.cpu().numpy():
+            assert np.array_equal(f, whole8[rows])

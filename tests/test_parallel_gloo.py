@@ -96,7 +96,9 @@ def _worker(rank, world, port, out_dir):
         lists = eng.state.result()
         eng.maps = ora.Maps(lists["diffuse"], lists["caustic"])
         frame = parallel.render_sharded(eng, W, H, band=8)
+        batch = parallel.render_sharded_batch(eng, W, H, 3, band=8)  # three frames' bands in one collective
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), frame=frame.numpy() if frame is not None else np.zeros(0),
+                 batch=batch.numpy() if batch is not None else np.zeros(0),
                  attempts1=res["attempts1"], attempts2=res["attempts2"], allgather_bytes=T["allgather_bytes"], **lists)
     finally:
         dist.destroy_process_group()
@@ -144,3 +146,7 @@ def test_world_size_2_matches_single_process(tmp_path):
     assert got.shape == post.shape
     assert ((got == post) | (np.isnan(got) & np.isnan(post))).all()
     assert r1["frame"].size == 0
+    # the batched gather: every frame of the batch is that same frame (the oracle engine renders one seed)
+    assert r0["batch"].shape == (3,) + post.shape and r1["batch"].size == 0
+    for f in r0["batch"]:
+        assert ((f == post) | (np.isnan(f) & np.isnan(post))).all()
