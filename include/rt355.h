@@ -164,7 +164,9 @@ void rt_scene_free(rt_scene *scene);
 int rt_intersect_pairs(rt_ctx *ctx, const rt_params *p, uint32_t n, const double *ray_o, const double *ray_d,
                        int normalize_dir, const uint8_t *shape_meta, const double *shape_geom, double *t_out);
 /* scene scans: the closest-hit loops (rayphoton.js:1642-1650, :1467-1475) and the any-hit
- * shadow loop (:1853-1857).  idx = -1 / t = +inf on a miss; mode RT_SCAN_ANY writes 0/1 to idx. */
+ * shadow loop (:1853-1857).  idx = -1 / t = +inf on a miss; mode RT_SCAN_ANY writes 0/1 to idx.
+ * ray_d: unit vectors, as the reference's Ray constructor leaves them (its sphere, hemisphere and cylinder tests
+ * assume a unit direction, and so does the fp32 scans' skipping of primitive groups out of a wave's reach). */
 int rt_intersect(rt_scene *scene, const rt_params *p, int mode, uint32_t n, const double *ray_o,
                  const double *ray_d, const double *source_dist, double *t_out, int32_t *idx_out);
 
