@@ -83,6 +83,7 @@ template <typename T> static PathSoA<T> carve_paths(void *base, size_t n, size_t
   P.acc_r = (T *)take(n * sizeof(T)); P.acc_g = (T *)take(n * sizeof(T)); P.acc_b = (T *)take(n * sizeof(T));
   P.hit_t = (T *)take(n * sizeof(T)); P.hit_idx = (int32_t *)take(n * 4);
   P.draw = (uint32_t *)take(n * 4); P.depth = (int32_t *)take(n * 4); P.stack = (uint64_t *)take(n * 8);
+  P.key = (uint32_t *)take(n * 4);
   P.out = (T *)take(n * 4 * sizeof(T));
   if (total) *total = (size_t)(p - (char *)base);
   return P;
@@ -397,6 +398,7 @@ __global__ void __launch_bounds__(64) k_trace_rays(DevScene<T> S, TraceCfg C, De
     st.importance = importance ? T(importance[p]) : T(1);
     st.acc = mk<T>(0, 0, 0);
     st.draw = first_draw ? first_draw[p] : 0u; st.depth = depth ? depth[p] & 0xFFFF : 0; st.blk_idx = 0xFFFFFFFFu;
+    st.key = path_key(S.width, C, p);
     MatStack ms; ms.init();
     st.stack = stacks ? stacks[p] : ms.bits;
     T o4[4] = { T(0), T(0), T(0), T(0) };                    // COL_BLACK: what a ray of importance < 0.01 returns (:1627)

@@ -23,6 +23,7 @@ template <typename T> struct PathSoA {
   uint32_t *draw;                     // RNG draws consumed by this path's stream
   int32_t *depth;                     // low 16 bits depth, bit 16: an opaque hit fixed alpha = 1
   uint64_t *stack;                    // MatStack bits
+  uint32_t *key;                      // the path's RNG stream: canvas pixel Y * width + X
   T *out;                             // n x 4: finished paths' colour
 };
 
@@ -30,6 +31,8 @@ template <typename T> struct PathSoA {
 template <typename T> struct PathState {
   V3<T> o, d; T max_dist, importance; V3<T> acc;
   uint32_t draw; int32_t depth; uint64_t stack;
+  uint32_t key;                       // canvas pixel Y * width + X: the first key word of the path's RNG stream (working it out from
+                                      // the path number at every bounce costs three divisions by run-time constants)
   Philox4 blk; uint32_t blk_idx;      // not stored: the stream's current Philox block, if a pass already computed it
 };
 template <typename T> RT_D PathState<T> load_path(const PathSoA<T> &P, uint32_t p) {
@@ -37,25 +40,25 @@ template <typename T> RT_D PathState<T> load_path(const PathSoA<T> &P, uint32_t 
   st.o = mk<T>(P.ox[p], P.oy[p], P.oz[p]); st.d = mk<T>(P.dx[p], P.dy[p], P.dz[p]);
   st.max_dist = P.max_dist[p]; st.importance = P.importance[p];
   st.acc = mk<T>(P.acc_r[p], P.acc_g[p], P.acc_b[p]);
-  st.draw = P.draw[p]; st.depth = P.depth[p]; st.stack = P.stack[p]; st.blk_idx = 0xFFFFFFFFu;
+  st.draw = P.draw[p]; st.depth = P.depth[p]; st.stack = P.stack[p]; st.key = P.key[p]; st.blk_idx = 0xFFFFFFFFu;
   return st;
 }
 template <typename T> RT_D void store_path(const PathSoA<T> &P, uint32_t p, const PathState<T> &st) {
   P.ox[p] = st.o.x; P.oy[p] = st.o.y; P.oz[p] = st.o.z; P.dx[p] = st.d.x; P.dy[p] = st.d.y; P.dz[p] = st.d.z;
   P.max_dist[p] = st.max_dist; P.importance[p] = st.importance;
   P.acc_r[p] = st.acc.x; P.acc_g[p] = st.acc.y; P.acc_b[p] = st.acc.z;
-  P.draw[p] = st.draw; P.depth[p] = st.depth; P.stack[p] = st.stack;
+  P.draw[p] = st.draw; P.depth[p] = st.depth; P.stack[p] = st.stack; P.key[p] = st.key;
 }
 
-// The same for a workgroup's own copy in LDS (fp32 builds): 15 words per path, field f of slot s at L[f * n + s].
-#define RT_LSTATE_WORDS 15
+// The same for a workgroup's own copy in LDS (fp32 builds): 16 words per path, field f of slot s at L[f * n + s].
+#define RT_LSTATE_WORDS 16
 RT_D PathState<float> load_path_lds(const uint32_t *L, uint32_t n, uint32_t s) {
   PathState<float> st;
   auto f = [&](int k) { return __uint_as_float(L[k * n + s]); };
   st.o = mk<float>(f(0), f(1), f(2)); st.d = mk<float>(f(3), f(4), f(5));
   st.max_dist = f(6); st.importance = f(7); st.acc = mk<float>(f(8), f(9), f(10));
   st.draw = L[11 * n + s]; st.depth = (int32_t)L[12 * n + s];
-  st.stack = (uint64_t)L[13 * n + s] | ((uint64_t)L[14 * n + s] << 32); st.blk_idx = 0xFFFFFFFFu;
+  st.stack = (uint64_t)L[13 * n + s] | ((uint64_t)L[14 * n + s] << 32); st.key = L[15 * n + s]; st.blk_idx = 0xFFFFFFFFu;
   return st;
 }
 RT_D void store_path_lds(uint32_t *L, uint32_t n, uint32_t s, const PathState<float> &st) {
@@ -63,7 +66,7 @@ RT_D void store_path_lds(uint32_t *L, uint32_t n, uint32_t s, const PathState<fl
   f(0, st.o.x); f(1, st.o.y); f(2, st.o.z); f(3, st.d.x); f(4, st.d.y); f(5, st.d.z);
   f(6, st.max_dist); f(7, st.importance); f(8, st.acc.x); f(9, st.acc.y); f(10, st.acc.z);
   L[11 * n + s] = st.draw; L[12 * n + s] = (uint32_t)st.depth;
-  L[13 * n + s] = (uint32_t)st.stack; L[14 * n + s] = (uint32_t)(st.stack >> 32);
+  L[13 * n + s] = (uint32_t)st.stack; L[14 * n + s] = (uint32_t)(st.stack >> 32); L[15 * n + s] = st.key;
 }
 
 struct TraceCfg {
@@ -199,7 +202,7 @@ RT_D PathState<T> raygen_path(const DevScene<T> &S, const TraceCfg &C, uint32_t 
   st.o = co; st.d = normalize<T>(xyz - co, T(C.epsilon));
   st.max_dist = T(C.max_trace_dist); st.importance = T(1);
   st.acc = mk<T>(0, 0, 0);
-  st.draw = rng.draw; st.depth = 0; st.blk = rng.block; st.blk_idx = rng.block_idx;
+  st.draw = rng.draw; st.depth = 0; st.key = (uint32_t)(Y * (int)S.width + X); st.blk = rng.block; st.blk_idx = rng.block_idx;
   MatStack ms; ms.init(); st.stack = ms.bits;
   return st;
 }
@@ -228,11 +231,17 @@ __global__ void __launch_bounds__(256) k_intersect_closest(DevScene<T> S, PathSo
   flush_tally(tally, ctr);
 }
 
-// stream of path p continued where its state left it: the key is (pixel, sub-sample)
-template <typename T> RT_D RngStream path_rng(uint32_t width, const TraceCfg &C, uint32_t p, const PathState<T> &st) {
+// first key word of path p's stream (what raygen_path leaves in the path state)
+RT_D uint32_t path_key(uint32_t width, const TraceCfg &C, uint32_t p) {
   int X, Y; uint32_t sub;
   path_pixel(C, p, X, Y, sub);
-  RngStream rng; rng.init(C.seed, RT_DOMAIN_RENDER, (uint32_t)(Y * (int)width + X), sub, st.draw);
+  return (uint32_t)(Y * (int)width + X);
+}
+// stream of path p continued where its state left it: the key is (pixel, sub-sample)
+template <typename T> RT_D RngStream path_rng(uint32_t width, const TraceCfg &C, uint32_t p, const PathState<T> &st) {
+  uint32_t sub = 0;
+  if (C.sub_sample != 1) (void)div_by(p, (uint32_t)(C.sub_sample * C.sub_sample), C.magic_ss, sub);
+  RngStream rng; rng.init(C.seed, RT_DOMAIN_RENDER, st.key, sub, st.draw);
   rng.block = st.blk; rng.block_idx = st.blk_idx;
   return rng;
 }
