@@ -6,7 +6,7 @@ gathers/s on a 1M-photon map, photon emission, the kd-tree build and the other B
   python bench.py --gpus N --steps K --warmup W      (N > 1: launched by torch.distributed.run, one rank per GPU)
 
 A step is one full-frame pass of the hot path.
-  N = 1   every step renders the frame on the one GPU (frames queued back to back, three in flight).
+  N = 1   every step renders the frame on the one GPU (frames queued back to back, four in flight).
   N > 1   ONE job over N ranks, the split of the north star: photon emission sharded by attempt range, the photon
           shards all-gathered from and into device memory (RCCL), the list caps applied and the kd-trees built
           identically on every rank, then every step's frame traced as interleaved row bands, one share per rank,
@@ -466,8 +466,9 @@ def main():
         extra, roof_gather, roof_build, roof_emit = other_legs()
 
     if not split:
-        # ---- frames of config[1] on this rank's GPU, queued back to back, three in flight
-        in_flight = 1 if os.environ.get("RT355_BENCH_SERIAL_FRAMES") else int(os.environ.get("RT355_BENCH_IN_FLIGHT", "3"))
+        # ---- frames of config[1] on this rank's GPU, queued back to back, four in flight (one per hardware queue of the process;
+        # five share queues: 25 % slower)
+        in_flight = 1 if os.environ.get("RT355_BENCH_SERIAL_FRAMES") else int(os.environ.get("RT355_BENCH_IN_FLIGHT", "4"))
         frames_out = [torch.empty((H, W, 4), dtype=torch.uint8, device=dev) for _ in range(in_flight)]   # outputs stay in HBM
         frame = frames_out[0]
 
@@ -498,7 +499,7 @@ def main():
         ctx.synchronize()
         ctx.profile_reset()                     # (the warm-up's timing events go back to the library's pool)
         # the timed frames are only queued (no statistics read back in between) and the clock stops after the library's
-        # streams have drained.  Three frames in flight: consecutive frames rotate through three streams, workspaces and output
+        # streams have drained.  Four frames in flight: consecutive frames rotate through four streams, workspaces and output
         # buffers, so the thinly occupied end of one frame's path tracing overlaps the start of the next; from three frames in
         # flight on the library follows the surviving paths with persistent lanes (fewer instructions per frame, a longer
         # serial chain: it needs the neighbours to fill the gaps).  A kernel's own duration, which the roofline block
@@ -633,7 +634,7 @@ def main():
                 "traffic": measured_traffic("k_tail_persistent" if in_flight >= 3 else "k_tail"), "algorithmic_flop_per_ray_pass": fl, "avg_launch_ms": t_avg * 1e3,
                 "segments_per_launch": int(tail_rays), "launches_per_step": 1.0, "timed_launches": int(tail_launches),
                 "primitive_tests_per_segment_executed": st["prim_tests"] / max(1, st["rays"]),
-                "note": "the timed frames overlap (three frames in flight), so a launch shares the chip with the neighbouring frames' kernels and its duration is not its cost; "
+                "note": "the timed frames overlap (four frames in flight), so a launch shares the chip with the neighbouring frames' kernels and its duration is not its cost; "
                         "`exclusive` has both kernels on frames run one at a time; `frame` is the whole frame against the driver's clock. "
                         "bound 'valu': this path is neither HBM- nor MFMA-bound; peak = fp32 vector FMA rate (the measured sustained v_fma_f32 "
                         "rate on this chip is 106 TFLOP/s, profiles/r02_valu_issue_rate.txt)",

@@ -297,7 +297,7 @@ class DeviceEngine:
             self.scene.ctx.synchronize()
         return out
 
-    def render_bands_batch(self, width, height, band, world, rank, n_frames, in_flight=3):
+    def render_bands_batch(self, width, height, band, world, rank, n_frames, in_flight=4):
         """this rank's bands of n_frames frames, (n_frames, rows, width, 4), queued back to back (up to in_flight of them
         overlap on the library's streams) and finished when this returns"""
         capi, ctx = self.capi, self.scene.ctx
