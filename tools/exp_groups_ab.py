@@ -7,7 +7,7 @@ from raytracer_amd import capi
 from raytracer_amd.scene import FlatScene
 ROOT = os.path.join(os.path.dirname(__file__), "..")
 W, H = 1920, 1080
-flat = FlatScene.from_json(os.path.join(ROOT, "tests", "golden", "scene_preset10_flat.json")).with_size(W, H)
+flat = FlatScene.from_json(os.path.join(ROOT, "tests", "golden", f"scene_preset{sys.argv[1] if len(sys.argv) > 1 else 10}_flat.json")).with_size(W, H)
 ctx = capi.Context(0)
 ctx.set_option("scan_groups", 0); sc0 = ctx.upload(flat)
 ctx.set_option("scan_groups", 1); sc1 = ctx.upload(flat)
