@@ -313,15 +313,20 @@ template <int TYPE> RT_D void load_origin_terms(const float *ot, float *out) {
   for (int k = 0; k < N; k++) out[k] = ot[k];
 }
 
-template <typename T> struct ScanSrc { const T *geom; const uint32_t *orig; const uint32_t *flags; const T *ot; const float4 *gsphere; const uint2 *gmask; };
+template <typename T> struct ScanSrc { const T *geom; const uint32_t *orig; const uint32_t *flags; const T *ot; const float4 *gsphere; const uint2 *gmask;
+                                       const HitRec<T> *hit; };      // hit: the hit records staged in LDS (fp32, small scenes), or nullptr: read S.hit
 
 // LDS bytes needed to stage n primitives
 // (fp32: + origin terms, + the list of primitives a workgroup's primary rays can reach: 9 segment bounds, n slots,
 // n flag bytes)
 // (fp32: + the scan groups' spheres and slot masks)
 constexpr size_t scan_lds_groups_offset(uint32_t n) { return (((size_t)n * (RT_GEOM_STRIDE * 4 + 8 + RT_OT_STRIDE * 4 + 3) + 64) + 15) & ~(size_t)15; }
+// (fp32, scenes of up to RT_LDS_HIT_MAX primitives: + the hit records -- shading reads a record per hit, and a round trip
+// to global memory per bounce is a large part of a path's latency)
+#define RT_LDS_HIT_MAX 128u
+constexpr size_t scan_lds_hits_offset(uint32_t n) { return scan_lds_groups_offset(n) + (RT_MAX_GROUPS + 1) * 24; }
 template <typename T> constexpr size_t scan_lds_bytes(uint32_t n) {
-  return sizeof(T) == 4 ? scan_lds_groups_offset(n) + (RT_MAX_GROUPS + 1) * 24
+  return sizeof(T) == 4 ? scan_lds_hits_offset(n) + (n <= RT_LDS_HIT_MAX ? (size_t)n * sizeof(HitRec<float>) : 0)
                         : (size_t)n * (RT_GEOM_STRIDE * sizeof(T) + 8);
 }
 // where that list lives in a workgroup's staging area
@@ -336,7 +341,7 @@ RT_D uint16_t *scan_lds_vis(uint32_t n, void *lds) { return (uint16_t *)(scan_ld
 // (S.sot_cam, computed at upload by this same code), else computed from the LDS copy.  `extra`: n_extra more words the
 // caller wants copied to `extra_dst` (LDS) in the same round trip.
 template <typename T> RT_D ScanSrc<T> stage_scene_lds(const DevScene<T> &S, void *lds, const V3<T> *origin = nullptr, const uint32_t *extra = nullptr,
-                                                      uint32_t *extra_dst = nullptr, uint32_t n_extra = 0) {
+                                                      uint32_t *extra_dst = nullptr, uint32_t n_extra = 0, bool with_hits = true) {
   T *lg = (T *)lds;
   uint32_t *lo = (uint32_t *)(lg + (size_t)S.n_shapes * RT_GEOM_STRIDE), *lf = lo + S.n_shapes;
   const uint32_t n = S.n_shapes, tid = threadIdx.x, nt = blockDim.x;
@@ -356,12 +361,18 @@ template <typename T> RT_D ScanSrc<T> stage_scene_lds(const DevScene<T> &S, void
     ot_copied = origin && S.sot_cam;
     if (ot_copied) t0 = S.sot_cam[tid < n * RT_OT_STRIDE ? tid : 0];
   }
-  for (uint32_t base = 0; base < n16; base += 4 * nt) {
+  // (fp32, small scenes: the hit records ride along as further 16-byte pieces)
+  uint32_t nh16 = 0; const uint4 *hsrc = src; uint4 *hdst = dst;
+  if constexpr (sizeof(T) == 4) {
+    if (with_hits && n <= RT_LDS_HIT_MAX) { nh16 = n * (uint32_t)(sizeof(HitRec<T>) / 16); hsrc = (const uint4 *)S.hit; hdst = (uint4 *)((char *)lds + scan_lds_hits_offset(n)); }
+  }
+  const uint32_t nall = n16 + nh16;
+  for (uint32_t base = 0; base < nall; base += 4 * nt) {
     uint4 v[4];
 #pragma unroll
-    for (int k = 0; k < 4; k++) { const uint32_t i = base + (uint32_t)k * nt + tid; v[k] = src[i < n16 ? i : 0]; }
+    for (int k = 0; k < 4; k++) { const uint32_t i = base + (uint32_t)k * nt + tid; v[k] = i < n16 ? src[i] : hsrc[i < nall ? i - n16 : 0]; }
 #pragma unroll
-    for (int k = 0; k < 4; k++) { const uint32_t i = base + (uint32_t)k * nt + tid; if (i < n16) dst[i] = v[k]; }
+    for (int k = 0; k < 4; k++) { const uint32_t i = base + (uint32_t)k * nt + tid; if (i < n16) dst[i] = v[k]; else if (i < nall) hdst[i - n16] = v[k]; }
   }
   if (tid < n) { lo[tid] = o0; lf[tid] = f0; }
   for (uint32_t i = tid + nt; i < n; i += nt) { lo[i] = S.sorig[i]; lf[i] = S.sflags32[i]; }
@@ -370,6 +381,7 @@ template <typename T> RT_D ScanSrc<T> stage_scene_lds(const DevScene<T> &S, void
     for (uint32_t i = tid + nt; i < n_extra; i += nt) extra_dst[i] = extra[i];
   }
   ScanSrc<T> G; G.geom = lg; G.orig = lo; G.flags = lf; G.ot = nullptr; G.gsphere = nullptr; G.gmask = nullptr;
+  G.hit = nh16 ? (const HitRec<T> *)hdst : nullptr;
   if constexpr (sizeof(T) == 4) {
     uint32_t *lsph = (uint32_t *)((char *)lds + scan_lds_groups_offset(n)), *lm = lsph + 4u * (RT_MAX_GROUPS + 1);
     if (tid < n_sphere_words) lsph[tid] = g0;
@@ -399,7 +411,7 @@ template <typename T> RT_D ScanSrc<T> stage_scene_lds(const DevScene<T> &S, void
   return G;
 }
 template <typename T> RT_D ScanSrc<T> global_scan_src(const DevScene<T> &S) {
-  ScanSrc<T> G; G.geom = S.sgeom; G.orig = S.sorig; G.flags = S.sflags32; G.ot = nullptr; G.gsphere = S.gsphere; G.gmask = S.gmask;
+  ScanSrc<T> G; G.geom = S.sgeom; G.orig = S.sorig; G.flags = S.sflags32; G.ot = nullptr; G.gsphere = S.gsphere; G.gmask = S.gmask; G.hit = nullptr;
   return G;
 }
 
@@ -632,9 +644,9 @@ template <typename T> RT_D V3<T> shape_normal(const DevScene<T> &S, int i, V3<T>
 }
 
 // The hit record of shape i in registers: all of it is requested before any of it is used.
-template <typename T> RT_D HitRec<T> load_hit(const DevScene<T> &S, int i) {
+template <typename T> RT_D HitRec<T> load_hit(const DevScene<T> &S, const ScanSrc<T> &G, int i) {
   HitRec<T> r;
-  const uint4 *src = (const uint4 *)(S.hit + i);
+  const uint4 *src = (const uint4 *)((G.hit ? G.hit : S.hit) + i);
   uint4 v[sizeof(HitRec<T>) / 16];
 #pragma unroll
   for (int k = 0; k < (int)(sizeof(HitRec<T>) / 16); k++) v[k] = src[k];

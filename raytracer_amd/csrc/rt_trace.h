@@ -461,7 +461,7 @@ RT_D bool shade_body(const DevScene<T> &S, const ScanSrc<T> &G, const TraceCfg &
   const V3<T> ZERO = mk<T>(0, 0, 0);
   if (idx < 0 || idx >= (int)S.n_shapes) {
     finish_path<T>(out, st.acc, mk<T>(16, 16, 16), T(1), alpha_fixed);                 // COL_VERY_DARK_GREY :1838
-  } else if (const HitRec<T> H = load_hit<T>(S, idx); H.flags() & RT_FLAG_LIGHT) {     // :1654-1656
+  } else if (const HitRec<T> H = load_hit<T>(S, G, idx); H.flags() & RT_FLAG_LIGHT) {     // :1654-1656
     int l = 0;
     for (uint32_t k = 0; k < S.n_lights; k++) if ((int)S.light_shape[k] == idx) l = (int)k;
     finish_path<T>(out, st.acc, mk<T>(S.light_data[l][3], S.light_data[l][4], S.light_data[l][5]), S.light_data[l][6], alpha_fixed);
@@ -577,7 +577,7 @@ template <typename T> RT_D V3<T> vec_perturb_a(V3<T> v, T eps, RngStream &rng) {
 // P.depth; k_resolve_a substitutes the terminal colour back up through the records.
 // Returns true when the path goes on with a new segment.
 template <typename T>
-RT_D bool shade_body_a(const DevScene<T> &S, const TraceCfg &C, T *levels, uint32_t p, PathState<T> &st, T t, int idx, T *out,
+RT_D bool shade_body_a(const DevScene<T> &S, const ScanSrc<T> &G, const TraceCfg &C, T *levels, uint32_t p, PathState<T> &st, T t, int idx, T *out,
                        int32_t *depth_out, ShadeTally &tally) {
   const T eps = T(C.epsilon);
   const int level = st.depth;
@@ -591,7 +591,7 @@ RT_D bool shade_body_a(const DevScene<T> &S, const TraceCfg &C, T *levels, uint3
   }
   const V3<T> d = st.d;
   const V3<T> hit = st.o + t * d;
-  const HitRec<T> H = load_hit<T>(S, idx);
+  const HitRec<T> H = load_hit<T>(S, G, idx);
   const V3<T> sc = shape_colour_g<T>(H.geom, H.colour, H.proc(), hit);
   const V3<T> n = shape_normal_g<T>(H.geom, H.type(), H.flags(), hit);
   const T refl = H.surf_refl;
@@ -673,7 +673,7 @@ template <typename T> RT_D void resolve_store(const TraceCfg &C, uint32_t pp, co
 template <typename T, bool WHITTED, bool FULL>
 RT_D bool shade_step(const DevScene<T> &S, const ScanSrc<T> &G, const PathSoA<T> &P, const TraceCfg &C, const DevMap &Md, const DevMap &Mc,
                      T *levels, uint32_t p, PathState<T> &st, T t, int idx, int bounce, ShadeTally &tally) {
-  if (WHITTED) return shade_body_a<T>(S, C, levels, p, st, t, idx, P.out + (size_t)p * 4, P.depth + p, tally);
+  if (WHITTED) return shade_body_a<T>(S, G, C, levels, p, st, t, idx, P.out + (size_t)p * 4, P.depth + p, tally);
   T o4[4];
   const bool alive = shade_body<T, FULL>(S, G, C, Md, Mc, p, st, t, idx, bounce, o4, tally);
   if (!alive) {
@@ -787,7 +787,7 @@ __global__ void __launch_bounds__(256) k_primary(DevScene<T> S, PathSoA<T> P, Tr
   }
   const bool listed = OT && culled && C.cull_lists;           // this workgroup's list comes ready-made, staged with the scene
   const ScanSrc<T> G = LDS ? stage_scene_lds<T>(S, rt_lds, OT ? &cam_o : nullptr, listed ? C.cull_lists + (size_t)blockIdx.x * C.cull_stride : nullptr,
-                                                vseg, listed ? C.cull_stride : 0u)
+                                                vseg, listed ? C.cull_stride : 0u, false)      // (one shade per lane: staging the hit records costs more than it saves)
                            : global_scan_src<T>(S);
   if constexpr (OT) {
     if (culled && !listed) cull_primitives(S, C, vis, vseg, first64);
