@@ -91,10 +91,8 @@ RT_D int photon_walk(const DevScene<T> &S, const ScanSrc<T> &G, const EmitCfg &C
 // has ended takes the next attempt of its workgroup that nobody has started (a counter in LDS) and joins the others at
 // their next segment.  Which lane runs an attempt does not matter: its stream is keyed by the attempt number and its
 // outputs go to the attempt's own slots.
+#define RT_EMIT_MIN_BLOCKS 5      // workgroups per CU the register allocation aims for (5 % faster than the four it reaches unasked)
 template <typename T, bool LDS>
-#ifndef RT_EMIT_MIN_BLOCKS
-#define RT_EMIT_MIN_BLOCKS 5      // (five workgroups per CU: 5 % faster than what the register count alone allows)
-#endif
 __global__ void __launch_bounds__(256, RT_EMIT_MIN_BLOCKS) k_emit(DevScene<T> S, EmitCfg C, int phase, unsigned long long a0, uint32_t count, uint32_t per_wg,
                                               uint8_t *kind, T *rec, uint8_t *nseg, EmitCounters *ctr) {
   extern __shared__ __align__(16) unsigned char rt_lds[];
