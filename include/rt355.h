@@ -108,6 +108,9 @@ typedef struct rt_trace_stats {
   uint64_t tail_rays;           /* of `rays`: segments traced after the first pass by the kernels that follow paths to their end */
   uint64_t prim_tests;          /* ray-primitive distance tests executed for `rays` (+ shadow rays when a hierarchy is used) */
   uint64_t prims_per_ray_brute_force;   /* primitives in the scene: rays * this = the tests of the reference's loops */
+  uint64_t gather_saturations;  /* queued photon gathers (fp32 frames, see rt_trace_tile): partial sums that left the range of a path's
+                                   fixed-point accumulator (|x| < 2^31 in steps of 2^-32 per colour channel) and were clamped to it,
+                                   or were NaN and left out.  0 on any scene whose radiance stays below 2e9 */
 } rt_trace_stats;
 
 typedef struct rt_emit_stats {
@@ -140,7 +143,7 @@ int rt_join(rt_ctx *ctx);
  * RT355_<NAME> from the environment once; this call changes one switch of a live context.  The defaults are the
  * measured best; results do not depend on any of them (fp32 images: bit for bit).  No counterpart in the reference. */
 int rt_set_option(rt_ctx *ctx, const char *name, double value);
-/* n = 2..4: up to n consecutive frames that rt_trace_tile only queues (see there) may overlap -- the long, thinly
+/* n = 2..8: up to n consecutive frames that rt_trace_tile only queues (see there) may overlap -- the long, thinly
  * occupied end of one frame's path tracing runs beside the start of the next; frames in flight together must not
  * share output buffers.  n = 1 (default): queued frames run one after the other.  No counterpart in the reference (its frames are
  * serial by construction). */
@@ -263,10 +266,11 @@ int rt_kd_knn(rt_photon_map *map, const float *queries, uint32_t nq, uint32_t k,
  * than the tree walk's; the same from run to run).  Option defer_gathers = 0: every query walks on its own. */
 int rt_gather_radiance(rt_photon_map *map, const float *hits, uint32_t nq, double r, uint32_t k, float *rgb_out);
 
-/* rt_gather_radiance for callers that cannot allocate device memory (code under HIP graph capture, tight serving
- * loops, harnesses that forbid hipMalloc).  NO COUNTERPART IN THE REFERENCE.  Same results as rt_gather_radiance, but the
- * call allocates nothing: `hits_dev` and `rgb_dev` must already be device memory of the context's GPU (a host array is
- * rejected with RT_ERR_INVALID), and the k-nearest gather's scratch (fallback flags and work lists) lives in a static
+/* rt_gather_radiance for callers that cannot allocate device memory (tight serving loops, harnesses that forbid
+ * hipMalloc, code between the captures of HIP graphs -- the call itself cannot be captured: it reads a few counters
+ * back to the host between its launches and ends with a stream synchronisation).  NO COUNTERPART IN THE REFERENCE.  Same results as rt_gather_radiance, but the
+ * call allocates nothing: `hits_dev` and `rgb_dev` must already be device memory of the context's GPU (a host array, or an
+ * array on another GPU, is rejected with RT_ERR_INVALID), and the k-nearest gather's scratch (fallback flags and work lists) lives in a static
  * device array of about 3.8 MB that each GPU the library runs on holds until the process ends.  nq may be at most
  * RT_GATHER_STATIC_MAX_QUERIES (RT_ERR_TOO_LARGE beyond: split the queries over several calls).  All calls on one GPU
  * share that array: calls that overlap in time on one GPU (two contexts, two host threads) race.  Returns when the

@@ -59,7 +59,7 @@ class Params(C.Structure):
 class TraceStats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("shadow_rays", C.c_uint64), ("gathers", C.c_uint64),
                 ("bounces", C.c_uint64), ("stack_overflows", C.c_uint64), ("tail_rays", C.c_uint64),
-                ("prim_tests", C.c_uint64), ("prims_per_ray_brute_force", C.c_uint64)]
+                ("prim_tests", C.c_uint64), ("prims_per_ray_brute_force", C.c_uint64), ("gather_saturations", C.c_uint64)]
 
 
 class EmitStats(C.Structure):

@@ -488,7 +488,8 @@ struct BvhBuild {
 // tests) get a hierarchy; `order` maps sorted slot -> original index.
 static bool rt_wants_bvh(const rt_ctx *ctx, uint32_t n) {
   const int knob = ctx->knobs.bvh;
-  return n > 0 && (knob >= 0 ? knob != 0 : (size_t)n * (RT_GEOM_STRIDE * 4 + 8 + RT_OT_STRIDE * 4) > 56 * 1024);
+  // (the same budget the fp32 scan kernels apply when they decide whether to stage the scene in LDS: no scene falls between the two)
+  return n > 0 && (knob >= 0 ? knob != 0 : scan_lds_bytes<float>(n) > 56 * 1024);
 }
 static int rt_build_bvh(rt_ctx *ctx, const rt_scene_desc *d, const std::vector<uint32_t> &order, rt_scene *sc, bool &built) {
   built = false;

@@ -263,15 +263,18 @@ template <int TYPE> RT_D float isect_fast(const float *f, const float *ot, V3<fl
     return ok0 ? t0 : (ok1 ? t1 : MISS);
   } else if (TYPE == RT_CYLINDER) {
     float da = dot3(f + 4, d);
-    float vd = d.x * ot[0] + d.y * ot[1] + d.z * ot[2];
-    float a = 1.0f - da * da;
-    float hb = vd - ot[3] * da;
+    // The quadratic through the part of d across the axis, dp = d - (d.axis) axis: a = |dp|^2 and halfB = v.dp are the
+    // reference's 1 - (d.axis)^2 and v.d - (v.axis)(d.axis) without their cancellation (for a ray 0.1 degrees off the
+    // axis 1 - da^2 is 3e-6 with 1.2e-7 of rounding: distances 4 % off; |dp|^2 has 2e-4 there).
+    float px = d.x - da * f[4], py = d.y - da * f[5], pz = d.z - da * f[6];
+    float a = px * px + py * py + pz * pz;
+    float hb = px * ot[0] + py * ot[1] + pz * ot[2];
     float sq = sqrt_fast(hb * hb - a * ot[4]);
     float ia = rcp_fast(a);
     float t0 = (-hb - sq) * ia, t1 = (-hb + sq) * ia;
-    // a == 0 is the reference's "ray parallel to the axis: miss" (qRoots, rayphoton.js:1884-1889); in fp32 a = 1 - da^2
-    // carries an absolute rounding error of about 1.2e-7, so anything below 4e-7 counts as parallel
-    const bool parallel = fabsf(a) < 4e-7f;
+    // a == 0 is the reference's "ray parallel to the axis: miss" (qRoots, rayphoton.js:1884-1889); dp carries about 1e-7
+    // of rounding per component, so a ray within 1e-5 rad of the axis (a < 1e-10) counts as parallel
+    const bool parallel = a < 1e-10f;
     if (flags & RT_FLAG_FIRST_ROOT) return (parallel | !(t0 > 0.0f)) ? MISS : t0;      // wave-uniform branch
     float hlim = f[7] - eps;
     const bool ok0 = (t0 > eps) & (fabsf(ot[3] + t0 * da) < hlim);
@@ -415,6 +418,10 @@ template <typename T> RT_D ScanSrc<T> global_scan_src(const DevScene<T> &S) {
   return G;
 }
 
+// bit mask of the sorted slots below s (s = 0 .. 64; a shift by 64 is undefined, and a type with no primitives behind the
+// last slot of a 64-primitive scene has s == 64 at both ends of its range)
+RT_D unsigned long long low_slots(uint32_t s) { return s >= 64u ? ~0ull : ((1ull << s) - 1ull); }
+
 #ifndef RT_SCAN_UNROLL
 #define RT_SCAN_UNROLL 2
 #endif
@@ -469,7 +476,7 @@ template <int MODE, bool OT> RT_D int scan_fast(const DevScene<float> &S, const 
 #define RT_FAST_LOOP(TYPE)                                                                              \
     {                                                                                                   \
       const uint32_t s0 = S.seg[TYPE], s1 = S.seg[TYPE + 1];                                            \
-      unsigned long long m = act & ((s1 >= 64u ? ~0ull : ((1ull << s1) - 1ull)) & ~((1ull << s0) - 1ull)); \
+      unsigned long long m = act & low_slots(s1) & ~low_slots(s0);                                      \
       while (m & (m - 1ull)) {                                                                          \
         const uint32_t sa = (uint32_t)__builtin_ctzll(m); m &= m - 1ull;                                \
         const uint32_t sb = (uint32_t)__builtin_ctzll(m); m &= m - 1ull;                                \

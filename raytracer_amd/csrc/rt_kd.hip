@@ -17,6 +17,7 @@
 // All accept/prune comparisons of the queries are evaluated in fp64 without FMA contraction on
 // the exactly converted fp32 coordinates, so the returned index sets are exactly the
 // reference's for the same (fp32-representable) photon positions.
+#include <mutex>
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <string.h>
@@ -1377,9 +1378,11 @@ static __device__ __align__(256) unsigned char scratch[RT_STATIC_SCRATCH_BYTES];
 // (rt_static_scratch_setup, called by rt_init with that device current) and host code uses that pointer from then on.
 #define RT_MAX_DEVICES 64
 static void *g_scratch_ptr[RT_MAX_DEVICES];
+static std::mutex g_scratch_lock;                   // (two host threads may call rt_init for one device at the same time)
 
 int rt_static_scratch_setup(rt_ctx *ctx) {
   if (ctx->device < 0 || ctx->device >= RT_MAX_DEVICES) return rt_fail(ctx, RT_ERR_NO_DEVICE, "device ordinal %d beyond %d", ctx->device, RT_MAX_DEVICES);
+  std::lock_guard<std::mutex> guard(g_scratch_lock);
   if (g_scratch_ptr[ctx->device]) return RT_OK;
   void *ptr = nullptr;
   RT_HIP(ctx, hipSetDevice(ctx->device));
@@ -1519,6 +1522,12 @@ extern "C" int rt_gather_radiance_static(rt_photon_map *m, const float *hits_dev
   RT_HIP(ctx, hipSetDevice(ctx->device));
   if (!rt_is_device_ptr(hits_dev) || !rt_is_device_ptr(rgb_dev))
     return rt_fail(ctx, RT_ERR_INVALID, "rt_gather_radiance_static: hits_dev and rgb_dev must be device memory (a host array would need a staging allocation)");
+  for (const void *ptr : { (const void *)hits_dev, (const void *)rgb_dev }) {      // ... of THIS context's GPU: the kernels and the scratch are on it
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, ptr) != hipSuccess) { (void)hipGetLastError(); return rt_fail(ctx, RT_ERR_INVALID, "rt_gather_radiance_static: cannot identify a device array"); }
+    if (attr.type == hipMemoryTypeDevice && attr.device != ctx->device)
+      return rt_fail(ctx, RT_ERR_INVALID, "rt_gather_radiance_static: an array lives on device %d, the context runs on device %d", attr.device, ctx->device);
+  }
   void *ws = g_scratch_ptr[ctx->device];
   if (!ws) return rt_fail(ctx, RT_ERR_HIP, "static scratch of device %d was not set up", ctx->device);
   if (knn_scratch_bytes(nq) > RT_STATIC_SCRATCH_BYTES) return rt_fail(ctx, RT_ERR_TOO_LARGE, "static scratch too small");      // (never: the limit above covers it)

@@ -138,7 +138,7 @@ static int trace_tile_mode(rt_scene *sc, int slot, const rt_params *p, DevMap md
   C.band_first = band_shift ? (uint32_t)(p->band_rows * p->band_index) : 0u;
   C.fuse_resolve = (!WHITTED && p->sub_sample == 1) ? 1 : 0; C.pre = pre; C.post = post; C.rgba8 = rgba8;
   if (!p->use_photon_maps) { md.n = 0; mc.n = 0; }
-  C.gq = nullptr; C.gq_count = nullptr; C.gq_cap = 0; C.gacc = nullptr; C.gq_order = nullptr;
+  C.gq = nullptr; C.gq_count = nullptr; C.gq_cap = 0; C.gacc = nullptr; C.gq_order = nullptr; C.gsat = &ctr->gather_saturations;
   bool defer = false;
   if constexpr (sizeof(T) == 4 && FULL && !WHITTED) {
     defer = p->use_photon_maps && (md.n || mc.n) && (K.defer_gathers < 0 ? (uint64_t)md.n + mc.n >= 200000u : K.defer_gathers != 0);
@@ -348,7 +348,7 @@ static int trace_tile_mode(rt_scene *sc, int slot, const rt_params *p, DevMap md
     for (int k = 0; k < RT_CTR_SLOTS; k++) { tail += hc.tail_rays[k]; iters = hc.max_iter[k] > iters ? hc.max_iter[k] : iters; }
     stats->rays = rays + tail; stats->bounces = (direct ? 1u : wave_bounces) + iters;
     stats->shadow_rays = hc.shadow_rays; stats->gathers = hc.gathers;
-    stats->stack_overflows = hc.stack_overflows;
+    stats->stack_overflows = hc.stack_overflows; stats->gather_saturations = hc.gather_saturations;
     stats->tail_rays = whole_frame ? tail - n_paths : tail;       // segments after the first pass that k_tail traced
     uint64_t tests = 0;
     for (int k = 0; k < RT_CTR_SLOTS; k++) tests += hc.prim_tests[k * 16];

@@ -95,9 +95,10 @@ struct TraceCfg {
   // fp32 frames with photon maps: hits after the first (and first hits a wave could not gather together) do not walk
   // the maps where they are shaded -- one lane walking for thousands of steps while the rest of its wave waits -- but
   // leave a request (3 x float4: point + path, normal, albedo / 255) in gq; k_gather_deferred serves the requests with
-  // every lane busy and adds the results to the path's entry of gacc (fixed point, 2^-24: the order of the additions
+  // every lane busy and adds the results to the path's entry of gacc (fixed point, steps of 2^-32: the order of the additions
   // does not matter), which the resolve pass adds to the path's colour.  gq == nullptr: gathers where they are shaded.
   float4 *gq; uint32_t *gq_count; uint32_t gq_cap; long long *gacc;
+  unsigned long long *gsat;      // counts the partial sums that left the accumulators' range (gather_accumulate), or nullptr
   const uint32_t *gq_order;      // requests in the order k_gather_deferred serves them (sorted by position), or nullptr
   // fp32 first pass: per workgroup the list of primitives its rays can reach (cull_stride words each: 16 segment words,
   // then the sorted slots as 16-bit entries), made once per scene and tile layout by k_cull_lists, or nullptr: every
@@ -119,7 +120,7 @@ RT_D uint32_t band_row(const TraceCfg &C, uint32_t row) {
 #define RT_MAX_BOUNCE_PASSES 2
 #define RT_MAX_TAIL_ROUNDS 3
 struct TraceCounters {
-  unsigned long long shadow_rays, gathers, stack_overflows, tail_rays[RT_CTR_SLOTS];
+  unsigned long long shadow_rays, gathers, stack_overflows, gather_saturations, tail_rays[RT_CTR_SLOTS];
   unsigned long long prim_tests[RT_CTR_SLOTS * 16];   // ray-primitive tests counted by the scans that skip primitives; slot s at [16 s]
   uint32_t max_iter[RT_CTR_SLOTS];          // iterations the longest-lived workgroup of k_tail ran
   // lengths of the sub-queues the first pass ([0]) and the bounce passes after it ([1], [2]) leave (s at [16 s])
@@ -1098,13 +1099,20 @@ __global__ void __launch_bounds__(256) k_tail_persistent(DevScene<T> S, PathSoA<
 
 // (diffuse sum / diffuse area + caustic sum / caustic area) x albedo (rayphoton.js:1808-1815) into the path's
 // fixed-point accumulators; partial sums of one request may arrive from several waves, in any order
+// A path's accumulator holds |x| < 2^31 in steps of 2^-32 (radiance is in 0..255 units, so the range is 8e6 times the
+// brightest displayable value).  A partial sum beyond +-2^30 is clamped to that and counted in the frame's gather_saturations,
+// a NaN is left out and counted (C.gsat) -- the gather-in-place path would return inf / NaN there, which the resolve clamps or
+// zeroes as well; the count tells a caller that the two routes may differ.
 RT_D void gather_accumulate(const TraceCfg &C, uint32_t p, float4 albedo, V3<float> sd, V3<float> sc) {
   const float PI_ = 3.141592653589793f;
   const float dArea = PI_ * (float)(C.diffuse_radius * C.diffuse_radius), cArea = PI_ * (float)(C.caustic_radius * C.caustic_radius);
   const float lc[3] = { albedo.x, albedo.y, albedo.z }, d3[3] = { sd.x, sd.y, sd.z }, c3[3] = { sc.x, sc.y, sc.z };
   for (int c = 0; c < 3; c++) {
     const double f = ((double)(d3[c] * lc[c] / dArea) + (double)(c3[c] * lc[c] / cArea)) * RT_GACC_SCALE;
-    const long long k = (f == f && f > -9.0e18 && f < 9.0e18) ? __double2ll_rn(f) : 0ll;
+    const double lim = 1073741824.0 * RT_GACC_SCALE;            // 2^30 units: two such partial sums still fit
+    const bool ok = f == f && f > -lim && f < lim;
+    const long long k = ok ? __double2ll_rn(f) : (f == f ? __double2ll_rn(f < 0 ? -lim : lim) : 0ll);
+    if (!ok && C.gsat) atomicAdd(C.gsat, 1ull);
     if (k) atomicAdd((unsigned long long *)&C.gacc[(size_t)p * 3 + c], (unsigned long long)k);
   }
 }

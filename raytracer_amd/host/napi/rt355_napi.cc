@@ -434,6 +434,7 @@ static napi_value TraceTile(napi_env env, napi_callback_info info) {
   set_num(env, stats, "rays", (double)st.rays); set_num(env, stats, "shadowRays", (double)st.shadow_rays);
   set_num(env, stats, "gathers", (double)st.gathers); set_num(env, stats, "bounces", (double)st.bounces);
   set_num(env, stats, "tailRays", (double)st.tail_rays); set_num(env, stats, "primTests", (double)st.prim_tests);
+  set_num(env, stats, "stackOverflows", (double)st.stack_overflows); set_num(env, stats, "gatherSaturations", (double)st.gather_saturations);
   napi_set_named_property(env, out, "stats", stats);
   return out;
 }

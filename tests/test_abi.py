@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layouts():
     assert C.sizeof(capi.SceneDesc) == 8 + 3 * 8 + 8 + 2 * 8 + 16 * 8 + 8 + 32 * 8 + 8
     assert C.sizeof(capi.Params) == 120 and C.sizeof(capi.ListsInfo) == 40
-    assert C.sizeof(capi.TraceStats) == 64 and C.sizeof(capi.EmitStats) == 40
+    assert C.sizeof(capi.TraceStats) == 72 and C.sizeof(capi.EmitStats) == 40
     p = capi.default_params()
     assert p.epsilon == 1e-6 and p.max_trace_dist == 20 and p.max_depth == 5          # rayphoton.js:6-9
     assert p.num_photons_diffuse == 20000 and p.num_photons_caustic == 50000          # rayphoton.js:16-17

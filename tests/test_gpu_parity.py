@@ -125,6 +125,115 @@ def test_scene_scans_f32(rt, preset):
     assert np.quantile(rel, 0.99) < 1e-4 and np.median(rel) < 1e-6
 
 
+def _slot_boundary_scene(n_prims, width=96, height=64):
+    """6 planes, spheres and boxes only -- no disc, no annulus: the types behind the last occupied one are empty and, with 64
+    primitives, start at sorted slot 64"""
+    from raytracer_amd import synth, scene as S
+    rng = np.random.default_rng(n_prims)
+    b = synth.SceneBuilder()
+    for o, n in (((0, 0, 0), (0, 0, 1)), ((0, 0, 9), (0, 0, -1)), ((-7, 0, 0), (1, 0, 0)), ((7, 0, 0), (-1, 0, 0)), ((0, -7, 0), (0, 1, 0)), ((0, 7, 0), (0, -1, 0))):
+        b.plane(o, n, (128, 128, 128), S.MAT_PLASTER)
+    mats = [S.MAT_PLASTER, S.MAT_COPPER, S.MAT_MIRROR, S.MAT_GLASS]
+    for k in range(8):
+        a = np.array([rng.uniform(-5, 4), rng.uniform(-5, 4), rng.uniform(0.2, 6)])
+        l = rng.uniform(0.5, 1.5, 3)
+        b.box(a, (l[0], 0, 0), (0, l[1], 0), (0, 0, l[2]), tuple(rng.integers(32, 256, 3).tolist()), mats[k % 4])
+    for k in range(n_prims - 6 - 48):
+        b.ball((rng.uniform(-5, 5), rng.uniform(-5, 5), rng.uniform(0.5, 7)), rng.uniform(0.2, 0.8), tuple(rng.integers(32, 256, 3).tolist()), mats[k % 4])
+    flat = b.finish((-6, -6, 5), 45, -15, width, height)
+    assert flat.n_shapes == n_prims and not (flat.shape_meta[:, 0] >= 6).any()
+    return flat
+
+
+@pytest.mark.parametrize("n_prims", [63, 64, 65])
+@pytest.mark.parametrize("groups", [0, 1])
+def test_scans_at_the_64_slot_boundary(rt, n_prims, groups):
+    """Scenes of 63, 64 and 65 primitives whose last primitive types are empty: the fp32 scans keep the slots to test as a
+    64-bit mask, and an empty type behind slot 63 must test nothing (its range is [64, 64)).  fp64 scans and frame against
+    the oracle bit for bit; fp32 scans against fp64 (same hit on all but grazing / on-surface rays, no spurious hits:
+    a wrongly tested slot would read another type's record) and the fp32 frame within the stated tolerance."""
+    capi, ctx = rt
+    flat = _slot_boundary_scene(n_prims)
+    with ctx.option("scan_groups", groups, 1):
+        sc = ctx.upload(flat)
+    osc = ora.Scene(flat)
+    rng = np.random.default_rng(7)
+    n = 20000
+    ro = np.column_stack([rng.uniform(-6.5, 6.5, n), rng.uniform(-6.5, 6.5, n), rng.uniform(0.1, 8.5, n)])
+    rd = rng.normal(size=(n, 3)); rd /= np.linalg.norm(rd, axis=1, keepdims=True)
+    ro[n // 2:] = np.repeat(ro[n // 2::64], 64, axis=0)[:n - n // 2] + 0.01 * rng.normal(size=(n - n // 2, 3))       # bundles: waves that skip groups
+    rd[n // 2:] = np.repeat(rd[n // 2::64], 64, axis=0)[:n - n // 2] + 0.02 * rng.normal(size=(n - n // 2, 3))
+    rd /= np.linalg.norm(rd, axis=1, keepdims=True)
+    sd = np.full(n, 6.0)
+    p64, p32 = capi.default_params(precision=capi.PRECISION_F64), capi.default_params(precision=capi.PRECISION_F32)
+    for mode in (capi.SCAN_CLOSEST, capi.SCAN_CLOSEST_NOLIGHT, capi.SCAN_ANY):
+        t64, i64 = sc.intersect(p64, mode, ro, rd, sd if mode == capi.SCAN_ANY else None)
+        to, io = ora.scan_batch(osc, mode, ro, rd, sd if mode == capi.SCAN_ANY else None)
+        assert np.array_equal(i64, io), mode
+        if mode != capi.SCAN_ANY:
+            assert same(t64, to)
+        t32, i32 = sc.intersect(p32, mode, ro, rd, sd if mode == capi.SCAN_ANY else None)
+        differ = i32 != i64
+        # random interior origins: only grazing rays (a hit within fp32 rounding of a rim or of another hit) may differ
+        assert differ.mean() < 2e-3, (mode, int(differ.sum()))
+        if mode != capi.SCAN_ANY:
+            hit = ~differ & (i64 >= 0)
+            assert np.abs(t32[hit] - t64[hit]).max() < 2e-3
+    q64 = capi.default_params(precision=capi.PRECISION_F64, use_direct_light=0, use_photon_maps=0, seed=3)
+    q32 = capi.default_params(precision=capi.PRECISION_F32, use_direct_light=0, use_photon_maps=0, seed=3)
+    a = sc.trace_tile(q64)
+    pre, post, rays, _ = ora.render(osc, ora.params(seed=3, use_direct_light=0, use_photon_maps=0), None, 0, 0, flat.width, flat.height)
+    assert same(a["pre"], pre) and a["stats"]["rays"] == rays
+    b = sc.trace_tile(q32)
+    err = np.abs(b["pre"][..., :3] - pre[..., :3]).max(axis=-1)
+    assert (err <= 1e-3 * 255).mean() >= 0.99, (err <= 1e-3 * 255).mean()
+
+
+def test_cylinder_rays_near_the_axis_f32(rt):
+    """Rays within a fraction of a degree of a cylinder's axis, from inside a finite tube and an infinite one.  The reference
+    misses only at a == 0 exactly (qRoots, rayphoton.js:1884-1889).  The fp32 test solves the quadratic through the part of
+    the direction across the axis (no cancellation), whose components carry about 1e-7 of rounding, and calls a ray within
+    1e-5 rad (0.0006 degrees) of the axis parallel.  Stated tolerance: from 0.01 degrees on every hit / miss decision is the
+    fp64 one and the distance is within 1e-3 relative (1e-4 from 0.06 degrees on; measured 3.5e-4 / 2e-5); below 0.0005 degrees the fp32 build
+    reports a miss where fp64 hits the wall more than 50 000 radii down the tube -- for a finite cylinder shorter than that
+    it is a miss in fp64 too."""
+    capi, ctx = rt
+    rng = np.random.default_rng(21)
+    n = 4096
+    axis = np.array([0.3, -0.2, 0.93]); axis /= np.linalg.norm(axis)
+    ang = np.radians(np.concatenate([rng.uniform(0.0, 0.0005, n // 4), rng.uniform(0.01, 0.06, n // 4), rng.uniform(0.06, 5.0, n // 2)]))
+    perp = np.cross(axis, rng.normal(size=(n, 3))); perp /= np.linalg.norm(perp, axis=1, keepdims=True)
+    d = np.cos(ang)[:, None] * axis + np.sin(ang)[:, None] * perp
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    centre = np.array([1.0, 2.0, 3.0])
+    o = centre + 0.3 * rng.uniform(-1, 1, (n, 1)) * perp + rng.uniform(-1, 1, (n, 1)) * axis      # inside the tube (radius 0.5)
+    for finite in (True, False):
+        meta = np.zeros((n, 4), np.uint8)
+        meta[:, 0] = 3
+        meta[:, 2] = 1 | (8 if finite else 0)
+        g = np.zeros((n, 12))
+        g[:, 0:3], g[:, 3:6], g[:, 6], g[:, 7] = centre, axis, 0.5, 2000.0
+        t64 = ctx.intersect_pairs(capi.default_params(precision=capi.PRECISION_F64), o, d, meta, g)
+        t32 = ctx.intersect_pairs(capi.default_params(precision=capi.PRECISION_F32), o, d, meta, g)
+        assert same(t64, ora.intersect_batch(o, d, meta, g))
+        mid, wide = (ang >= np.radians(0.01)) & (ang < np.radians(0.06)), ang >= np.radians(0.06)
+        for sel, tol in ((mid, 1e-3), (wide, 1e-4)):
+            flips = np.isnan(t32[sel]) != np.isnan(t64[sel])
+            # (a hit within rounding of the tube's end may fall on the other side of `|z| < halfHeight - eps`)
+            assert flips.sum() <= 2, (finite, tol, int(flips.sum()))
+            both = sel & ~np.isnan(t64) & ~np.isnan(t32)
+            assert both.sum() > n // 8
+            rel = np.abs(t32[both] - t64[both]) / t64[both]
+            print(f"finite={finite} angles {'0.01-0.06' if tol > 1e-4 else '>= 0.06'} deg: relative distance error max {rel.max():.2e}, median {np.median(rel):.2e}")
+            assert rel.max() < tol, (finite, tol)
+        narrow = ang < np.radians(0.0005)
+        assert np.isnan(t32[narrow]).all()                                  # the fp32 rule: parallel, a miss
+        if finite:
+            assert np.isnan(t64[narrow]).all()                              # ... which is fp64's answer too: the wall lies beyond the tube's ends
+        else:
+            assert (t64[narrow][~np.isnan(t64[narrow])] > 0.2 / np.sin(np.radians(0.0005))).all()
+
+
 # ------------------------------------------------------------------ photon emission
 @pytest.fixture(scope="module")
 def c1_emit(rt):
@@ -710,6 +819,7 @@ def test_queued_photon_gathers_equal_the_gathers_in_place(rt):
         got3 = sc3.trace_tile(p3, md3, mc3, want=("pre",))
         assert (np.abs(got3["pre"][..., :3] - ref3["pre"][..., :3]) <= 3e-5 * np.maximum(1.0, np.abs(ref3["pre"][..., :3]))).all()
         assert got3["stats"]["gathers"] == ref3["stats"]["gathers"] > 4_000_000 and got3["stats"]["rays"] == ref3["stats"]["rays"]
+        assert got3["stats"]["gather_saturations"] == 0 and got2["stats"]["gather_saturations"] == 0   # no partial sum left the accumulators' range
         assert same(sc3.trace_tile(p3, md3, mc3, want=("pre",))["pre"], got3["pre"])
         del lists3, md3, mc3, sc3, ref3, got3
         # rt_gather_radiance with k = 0 takes the same queue for many queries on a large map
