@@ -128,6 +128,21 @@ def _c(a, dtype):
     return np.ascontiguousarray(a, dtype=dtype)
 
 
+class _DeviceArray:
+    """device memory owned by the library, described for torch.as_tensor (no copy); keeps `owner` alive"""
+
+    def __init__(self, ptr, shape, typestr, owner):
+        self.owner = owner
+        self.__cuda_array_interface__ = {"shape": tuple(int(x) for x in shape), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+
+
+def device_tensor(ptr, shape, typestr, owner=None):
+    import torch
+    if not ptr or any(int(x) == 0 for x in shape):
+        return torch.empty(tuple(int(x) for x in shape), dtype={"<f4": torch.float32, "<f8": torch.float64, "<i4": torch.int32, "<u1": torch.uint8}[typestr], device="cuda")
+    return torch.as_tensor(_DeviceArray(ptr, shape, typestr, owner), device="cuda")
+
+
 class Context:
     def __init__(self, device: int = 0):
         self.lib = load_library()
@@ -447,6 +462,28 @@ class PhotonLists:
         self.ctx.check(self.ctx.lib.rt_lists_export(self.h, C.c_int(which), _ptr(rec), _ptr(att)))
         return rec, att
 
+    def view(self, which):
+        """the list's records where they are: (device pointer, n, words per record, precision)"""
+        ptr, n, w, prec = C.c_void_p(), C.c_uint32(), C.c_uint32(), C.c_int()
+        self.ctx.check(self.ctx.lib.rt_lists_view(self.h, C.c_int(which), C.byref(ptr), C.byref(n), C.byref(w), C.byref(prec)))
+        return ptr.value or 0, n.value, w.value, prec.value
+
+    def records_tensor(self, which):
+        """the list's records as a torch tensor ALIASING the library's device memory (valid while this object lives and no
+        further batch is applied): (n, W) float32, or float64 for full fp64 lists"""
+        ptr, n, w, prec = self.view(which)
+        f64 = self.fmt == SHARD_FULL and prec == PRECISION_F64
+        return device_tensor(ptr, (n, w // 2 if f64 else w), "<f8" if f64 else "<f4", owner=self)
+
+    def attempts_tensor(self, which, device="cuda"):
+        """(phase, attempt) of every stored photon as an (n, 2) int64 tensor on the device (a copy)"""
+        import torch
+        n = self.counts()[which]
+        att = torch.empty((n, 2), dtype=torch.int64, device=device)
+        if n:
+            self.ctx.check(self.ctx.lib.rt_lists_export(self.h, C.c_int(which), C.c_void_p(None), _ptr(att)))
+        return att
+
     def photon_map(self, which) -> "PhotonMap":
         h = C.c_void_p()
         self.ctx.check(self.ctx.lib.rt_photon_map_build_lists(self.h, C.c_int(which), C.byref(h)))
@@ -478,9 +515,15 @@ class PhotonMap:
     def __del__(self):
         self.close()
 
-    def nodes(self):
-        perm = np.empty(self.n, np.int32)
-        dim = np.empty(self.n, np.uint8)
+    def nodes(self, device=None):
+        """perm, dim of nodes[1..n] as numpy arrays, or (device given) as torch tensors on that device"""
+        if device is not None:
+            import torch
+            perm = torch.empty(self.n, dtype=torch.int32, device=device)
+            dim = torch.empty(self.n, dtype=torch.uint8, device=device)
+        else:
+            perm = np.empty(self.n, np.int32)
+            dim = np.empty(self.n, np.uint8)
         self.ctx.check(self.ctx.lib.rt_photon_map_nodes(self.h, _ptr(perm), _ptr(dim)))
         return perm, dim
 
