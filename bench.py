@@ -557,34 +557,62 @@ def main():
         reng = parallel.DeviceEngine(sc, p, device=dev, with_lists=False)      # config[1] frames: no maps, no lists
         if rehearsal:
             reng = _RehearsalEngine(sc, p, device=dev, inner=reng)
-        rows = ctx.band_rows(H, args.band, world, rank)
         st_full = sc.trace_tile(p, want=())["stats"]                     # the whole frame once, for its segment count (every rank, same number)
-        # frames go to rank 0 in batches: every rank traces its bands of up to G frames back to back (three in flight), then
+        # frames go to rank 0 in batches: every rank traces its bands of up to G frames back to back (four in flight), then
         # ONE gather brings them together -- a frame's bands take tens of microseconds, less than a collective's latency
         G = max(1, args.frames_per_gather)
-        bufs = {}
-        frames0 = torch.empty((G, H, W, 4), dtype=torch.uint8, device=cdev) if rank == 0 else None
 
-        def frame_group(n):
-            if n not in bufs:
-                bufs[n] = torch.empty((n, rows, W, 4), dtype=torch.uint8, device=dev)
-            reng.out = bufs[n]
-            parallel.render_sharded_batch(reng, W, H, n, band=args.band, out=frames0[:n] if rank == 0 else None)
+        def split_frames(engine, Wd, Hd, n_frames, group, n_warm):
+            """n_frames frames of the engine's scene, each traced as interleaved row bands (one share per rank) and gathered
+            to rank 0 in groups of `group`; seconds for all of them, the maximum over the ranks"""
+            rows_ = ctx.band_rows(Hd, args.band, world, rank)
+            bufs_ = {}
+            frames0_ = torch.empty((group, Hd, Wd, 4), dtype=torch.uint8, device=cdev) if rank == 0 else None
 
-        for g0 in range(0, max(args.warmup, 1), G):
-            frame_group(min(G, max(args.warmup, 1) - g0))
-        if args.steps % G and args.steps > G:
-            frame_group(args.steps % G)          # (the last, shorter batch's buffer exists before the clock starts)
-        barrier()
-        t0 = time.perf_counter()
-        t_render = 0.0
-        for g0 in range(0, args.steps, G):
-            frame_group(min(G, args.steps - g0))
-        barrier()
-        dt = time.perf_counter() - t0
-        tmax = torch.tensor([dt], dtype=torch.float64, device=cdev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        t_total = float(tmax.item())
+            def frame_group(n):
+                if n not in bufs_:
+                    bufs_[n] = torch.empty((n, rows_, Wd, 4), dtype=torch.uint8, device=dev)
+                engine.out = bufs_[n]
+                parallel.render_sharded_batch(engine, Wd, Hd, n, band=args.band, out=frames0_[:n] if rank == 0 else None)
+
+            for g0 in range(0, max(n_warm, 1), group):
+                frame_group(min(group, max(n_warm, 1) - g0))
+            if n_frames % group and n_frames > group:
+                frame_group(n_frames % group)    # (the last, shorter batch's buffer exists before the clock starts)
+            barrier()
+            t0_ = time.perf_counter()
+            for g0 in range(0, n_frames, group):
+                frame_group(min(group, n_frames - g0))
+            barrier()
+            dt_ = time.perf_counter() - t0_
+            tm_ = torch.tensor([dt_], dtype=torch.float64, device=cdev)
+            dist.all_reduce(tm_, op=dist.ReduceOp.MAX)
+            return float(tm_.item())
+
+        t_total = split_frames(reng, W, H, args.steps, G, args.warmup)
+        dt = t_total
+        # ---- the two configurations BASELINE names for 8 GPUs, in the same split job (reported under "phases", never `value`)
+        # configs[4]'s full render: direct light and both radius gathers on the all-gathered maps this job has just built
+        pf = capi.default_params(precision=capi.PRECISION_F32, num_photons_diffuse=nd, num_photons_caustic=nc, seed=seed, shadow_bias=1e-4)
+        feng = parallel.DeviceEngine(sc, pf, device=dev, with_lists=False)
+        feng.maps = eng.maps
+        st5 = sc.trace_tile(pf, eng.maps[0], eng.maps[1], want=())["stats"]
+        if rehearsal:
+            feng = _RehearsalEngine(sc, pf, device=dev, inner=feng)
+        n5 = max(1, min(args.steps, 4))
+        t5 = split_frames(feng, W, H, n5, min(G, n5), 1)
+        # configs[3]: the 10 012-primitive scene at 3840x2160, paths of up to 8 segments
+        W4, H4 = (3840, 2160) if not rehearsal else (960, 540)
+        flat4 = synth.many_primitive_scene(10000, seed=42, width=W4, height=H4)
+        sc4 = ctx.upload(flat4)
+        p4 = capi.default_params(precision=capi.PRECISION_F32, use_direct_light=0, use_photon_maps=0, seed=seed, sub_sample=1, max_bounces=8)
+        eng4 = parallel.DeviceEngine(sc4, p4, device=dev, with_lists=False)
+        st4 = sc4.trace_tile(p4, want=())["stats"]
+        if rehearsal:
+            eng4 = _RehearsalEngine(sc4, p4, device=dev, inner=eng4)
+        n4 = max(1, min(args.steps, 8))
+        t4 = split_frames(eng4, W4, H4, n4, min(2, n4), 2)
+        del eng4, sc4
         rays = st_full["rays"] * args.steps
         rays_total = float(rays)
         bounces = st_full["bounces"] * args.steps
@@ -601,7 +629,17 @@ def main():
             "kd_build": {"seconds": t_build, "photons": stored, "note": "both maps, built identically on every rank from its own copy of the lists"},
             "render": {"seconds": dt, "frames": args.steps, "ms_per_frame": dt / args.steps * 1e3, "band_rows": args.band,
                        "gather_bytes_per_frame": W * H * 4, "frames_per_gather": G,
-                       "note": "every frame: this rank's interleaved bands in one rt_trace_tile call (queued, three in flight); the bands of frames_per_gather frames gathered to rank 0 by one collective"},
+                       "note": "every frame: this rank's interleaved bands in one rt_trace_tile call (queued, four in flight); the bands of frames_per_gather frames gathered to rank 0 by one collective"},
+            "config5_render": {"seconds": t5, "frames": n5, "ms_per_frame": t5 / n5 * 1e3, "Mrays_per_s": st5["rays"] * n5 / t5 / 1e6, "rays_per_frame": st5["rays"],
+                               "shadow_rays_per_frame": st5["shadow_rays"], "gathers_per_frame": st5["gathers"], "gathers_per_s": st5["gathers"] * n5 / t5,
+                               "photons": stored, "resolution": [W, H], "band_rows": args.band, "gather_bytes_per_frame": W * H * 4,
+                               "note": "BASELINE configs[4]'s full render on the maps of this job (emitted in shards, all-gathered, built on every rank): direct light, diffuse (r = 0.40) "
+                                       "and caustic (r = 0.15) radius gathers, every frame's interleaved row bands traced on their rank and gathered to rank 0"},
+            "config4": {"seconds": t4, "frames": n4, "ms_per_frame": t4 / n4 * 1e3, "Mrays_per_s": st4["rays"] * n4 / t4 / 1e6, "rays_per_frame": st4["rays"],
+                        "primitives": int(flat4.n_shapes), "resolution": [W4, H4], "band_rows": args.band, "gather_bytes_per_frame": W4 * H4 * 4, "frames_per_gather": min(2, n4),
+                        "prim_tests_per_frame": st4["prim_tests"], "tests_avoided_frac": 1.0 - st4["prim_tests"] / max(1, st4["rays"] * st4["prims_per_ray_brute_force"]),
+                        "note": f"BASELINE configs[3]: the synthetic 10 012-primitive scene at {W4}x{H4}, paths of up to 8 segments, through the hierarchy; "
+                                "interleaved row bands per rank, gathered to rank 0"},
         }
         parallelism = f"one job over {world} GPUs: emission by attempt range, photon all-gather, replicated kd build, frames split into interleaved {args.band}-row bands gathered to rank 0"
         scaling = "strong"
