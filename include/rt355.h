@@ -137,7 +137,7 @@ int rt_synchronize(rt_ctx *ctx);            /* host wait for everything the cont
  * instead of calling rt_synchronize().  No counterpart in the reference. */
 int rt_join(rt_ctx *ctx);
 /* Experiment / test switches, by name: tail_threshold, whole_frame, bounce_passes, tail_handoff, tail_rounds,
- * tail_persistent, no_lds, no_cull, cull_lists, raster_order, bvh (-1 by scene size / 0 / 1) and scan_groups (0 / 1)
+ * tail_persistent, no_lds, no_cull, cull_lists, primary_tiles, raster_order, bvh (-1 by scene size / 0 / 1) and scan_groups (0 / 1)
  * (both read by rt_scene_upload), bvh_one_order, defer_gathers, gather_sort, gather_split, wave_gather, knn_heap,
  * knn_radius_scale, knn_verbose, probe.  rt_init reads
  * RT355_<NAME> from the environment once; this call changes one switch of a live context.  The defaults are the

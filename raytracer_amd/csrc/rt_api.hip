@@ -84,6 +84,7 @@ int rt_init(const int *device_ids, int n, rt_ctx **out) {
     return RT_ERR_HIP;
   }
   ctx->stream = ctx->streams[0];
+  { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) ctx->n_cu = cus; else (void)hipGetLastError(); }
   for (int i = 1; i < RT_MAX_IN_FLIGHT; i++)
     if (hipEventCreateWithFlags(&ctx->frame_done[i], hipEventDisableTiming) != hipSuccess) {
       rt_fail(nullptr, RT_ERR_HIP, "context creation failed: %s", hipGetErrorString(hipGetLastError()));
@@ -91,7 +92,7 @@ int rt_init(const int *device_ids, int n, rt_ctx **out) {
       return RT_ERR_HIP;
     }
   // the experiment switches: the environment is read here, once per context
-  static const char *names[] = { "tail_threshold", "whole_frame", "bounce_passes", "tail_handoff", "tail_rounds", "tail_persistent", "no_lds", "no_cull", "cull_lists", "scan_groups", "raster_order", "bvh", "bvh_one_order", "wave_gather", "defer_gathers", "gather_sort", "gather_split", "knn_heap",
+  static const char *names[] = { "tail_threshold", "whole_frame", "bounce_passes", "tail_handoff", "tail_rounds", "tail_persistent", "no_lds", "no_cull", "cull_lists", "primary_tiles", "scan_groups", "raster_order", "bvh", "bvh_one_order", "wave_gather", "defer_gathers", "gather_sort", "gather_split", "knn_heap", "knn_sort",
                                  "knn_verbose", "probe", "knn_radius_scale" };
   for (const char *nm : names) {
     std::string env = "RT355_";
@@ -128,6 +129,7 @@ int rt_set_option(rt_ctx *ctx, const char *name, double value) {
   else if (n == "no_lds") K.no_lds = value != 0;
   else if (n == "no_cull") K.no_cull = value != 0;
   else if (n == "cull_lists") K.cull_lists = value != 0;
+  else if (n == "primary_tiles") K.primary_tiles = (int)value;
   else if (n == "scan_groups") K.scan_groups = value != 0;
   else if (n == "raster_order") K.raster_order = value != 0;
   else if (n == "bvh") K.bvh = (int)value;
@@ -137,6 +139,7 @@ int rt_set_option(rt_ctx *ctx, const char *name, double value) {
   else if (n == "gather_sort") K.gather_sort = value != 0;
   else if (n == "gather_split") K.gather_split = (int)value;
   else if (n == "knn_heap") K.knn_heap = value != 0;
+  else if (n == "knn_sort") K.knn_sort = (int)value;
   else if (n == "knn_verbose") K.knn_verbose = value != 0;
   else if (n == "probe") K.probe = value != 0;
   else if (n == "knn_radius_scale") K.knn_radius_scale = value;

@@ -22,20 +22,22 @@ struct EmitCounters { unsigned long long segments, errors, overflows; };
 // `st`) is followed to its next hit.  Returns -1 when the photon goes on (ph, st, depth updated), else how it ended:
 // 0 nothing stored (left the scene, dropped, or the reference would have thrown), 1 a diffuse photon stored, 2 a caustic
 // one -- then its record (hit3, -dir3, power / list cap, rgba) is in r[0..10].
-template <typename T>
-RT_D int photon_step(const DevScene<T> &S, const ScanSrc<T> &G, const EmitCfg &C, RngStream &rng, PhotonState<T> &ph, MatStack &st, int &depth,
+template <typename T, typename RNG>
+RT_D int photon_step(const DevScene<T> &S, const ScanSrc<T> &G, const EmitCfg &C, RNG &rng, PhotonState<T> &ph, MatStack &st, int &depth,
                      bool track_only_caustic, T *r, unsigned long long &errors, unsigned long long &overflows) {
   const T eps = T(C.epsilon);
   T t;
   int idx = scan_scene<T, 1>(S, G, ph.o, ph.d, eps, T(0), t);
   if (idx < 0) return 0;                                                     // left the scene
   V3<T> hit = ph.o + t * ph.d;
-  V3<T> local = shape_colour<T>(S, idx, hit);
-  V3<T> n = shape_normal<T>(S, idx, hit);
+  // everything about the shape in one batch of loads (from the workgroup's LDS copy where the scene is staged there)
+  const HitRec<T> H = load_hit<T>(S, G, idx);
+  V3<T> local = shape_colour_g<T>(H.geom, H.colour, H.proc(), hit);
+  V3<T> n = shape_normal_g<T>(H.geom, H.type(), H.flags(), hit);
   const T cos1 = -dot(ph.d, n);
-  const bool has_mat = S.meta[4 * idx + 1] < 8;
-  const int mat = S.meta[4 * idx + 1] & 7;
-  if (has_mat && S.mat[0][mat] == T(1) && depth < C.max_depth) {             // :1484
+  const bool has_mat = H.mat_byte() < 8;
+  const int mat = H.mat_byte() & 7;
+  if (has_mat && H.transparent == T(1) && depth < C.max_depth) {             // :1484
     V3<T> ndir; bool ovf = false;
     if (!fresnel_bounce<T>(S, mat, ph.d, n, cos1, st, rng, ndir, ovf)) { errors++; return 0; }   // :1487-1490 throws
     if (ovf) overflows++;
@@ -45,10 +47,10 @@ RT_D int photon_step(const DevScene<T> &S, const ScanSrc<T> &G, const EmitCfg &C
     return -1;
   }
   // opaque, or transparent at depth >= MAX_DEPTH where reflectance is undefined (never "< U")
-  const bool opaque_mat = has_mat && S.mat[0][mat] != T(1);
-  if (rng.next_k() < (opaque_mat ? S.refl_k[mat] : 0u)) {                    // :1523
+  // (H.refl_k is 0 without a material and for the transparent ones, whose reflectance is undefined)
+  if (rng.next_k() < H.refl_k) {                                             // :1523
     if (depth < C.max_depth) {
-      if (rng.next_k() < S.spec_k[mat]) {                                    // :1525-1533 specular
+      if (rng.next_k() < H.spec_k) {                                         // :1525-1533 specular
         ph.o = hit; ph.d = normalize<T>(ph.d + (T(2) * cos1) * n, eps);
         if (ph.caustic < 0) ph.caustic = 1;
         depth++;
@@ -86,43 +88,61 @@ RT_D int photon_walk(const DevScene<T> &S, const ScanSrc<T> &G, const EmitCfg &C
   }
 }
 
-// A workgroup takes `per_wg` consecutive attempts.  Walks differ a lot in length (3.6 segments on average, 20 and more
-// for photons caught in glass), so a lane does not idle until the longest walk of its wave is over: a lane whose walk
-// has ended takes the next attempt of its workgroup that nobody has started (a counter in LDS) and joins the others at
-// their next segment.  Which lane runs an attempt does not matter: its stream is keyed by the attempt number and its
-// outputs go to the attempt's own slots.
-#define RT_EMIT_MIN_BLOCKS 5      // workgroups per CU the register allocation aims for (5 % faster than the four it reaches unasked)
+// Persistent waves, each with its own contiguous share of the batch: wave w runs attempts [w * per_wave, (w + 1) * per_wave).
+// A lane runs one attempt at a time; a lane whose walk has ended takes the next attempt of its wave's share that nobody has
+// started -- the lanes that need one are counted with a ballot and numbered with a prefix count, no atomic -- and joins
+// the others at their next segment (walks differ in length: one to max_depth + 1 segments).  A share is about a thousand
+// attempts, so the lanes that wait for the longest walks of its last iterations are a few per cent (shares could be
+// claimed from a batch-wide cursor instead, but device-wide atomics on one address from five thousand waves cost more
+// than those lanes: measured 3.2 against 2.5 ms).
+// Which lane runs an attempt does not matter: its stream is keyed by the attempt number and its outputs go to the
+// attempt's own slots.
+// (Tried: a two-block window of the stream filled at one place per iteration instead of a conditional generator
+// evaluation at every draw site -- 12 % fewer instructions, but 13 more registers, which spill at five workgroups per CU:
+// 2.7 against 2.2 ms.)
+#ifndef RT_EMIT_MIN_BLOCKS
+#define RT_EMIT_MIN_BLOCKS 5      // workgroups per CU the register allocation aims for
+#endif
 template <typename T, bool LDS>
-__global__ void __launch_bounds__(256, RT_EMIT_MIN_BLOCKS) k_emit(DevScene<T> S, EmitCfg C, int phase, unsigned long long a0, uint32_t count, uint32_t per_wg,
+__global__ void __launch_bounds__(256, RT_EMIT_MIN_BLOCKS) k_emit(DevScene<T> S, EmitCfg C, int phase, unsigned long long a0, uint32_t count, uint32_t per_wave,
                                               uint8_t *kind, T *rec, uint8_t *nseg, EmitCounters *ctr) {
   extern __shared__ __align__(16) unsigned char rt_lds[];
-  __shared__ uint32_t next_attempt;
   const ScanSrc<T> G = LDS ? stage_scene_lds<T>(S, rt_lds) : global_scan_src<T>(S);
-  const uint32_t wg_first = blockIdx.x * per_wg, wg_end = min(count, wg_first + per_wg);      // (count <= 2^31: no overflow)
-  if (threadIdx.x == 0) next_attempt = wg_first + blockDim.x;
-  __syncthreads();
   unsigned long long segments = 0, errors = 0, overflows = 0;
   const T eps = T(C.epsilon);
-  uint32_t i = wg_first + threadIdx.x;
-  RngStream rng; PhotonState<T> ph; MatStack st; int depth = 0; uint32_t my_segments = 0;
-  auto start = [&](uint32_t attempt_i) {
-    const unsigned long long attempt = a0 + attempt_i;
-    rng.init(C.seed, phase == 1 ? RT_DOMAIN_EMIT_PHASE1 : RT_DOMAIN_EMIT_PHASE2, (uint32_t)attempt, (uint32_t)(attempt >> 32));
-    create_photon<T>(S, eps, rng, ph);
-    st.init(); depth = 0; my_segments = 0;
-  };
-  bool have = i < wg_end;
-  if (have) start(i);
-  while (have) {
-    my_segments++;
-    const int k = photon_step<T>(S, G, C, rng, ph, st, depth, phase == 2, rec + (size_t)i * RT_REC_STRIDE, errors, overflows);
-    if (k >= 0) {                                            // this attempt is over: record it, take the next one
-      kind[i] = (uint8_t)k;
-      nseg[i] = (uint8_t)(my_segments < 255 ? my_segments : 255);
-      segments += my_segments;
-      i = atomicAdd(&next_attempt, 1u);
-      have = i < wg_end;
-      if (have) start(i);
+  const int lane = threadIdx.x & 63;
+  const unsigned long long below = ((unsigned long long)1 << lane) - 1;
+  const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const unsigned long long first = (unsigned long long)wave * per_wave;
+  uint32_t cur = (uint32_t)min(first, (unsigned long long)count);          // this wave's unstarted attempts: [cur, end) (wave-uniform)
+  const uint32_t end = (uint32_t)min(first + per_wave, (unsigned long long)count);
+  bool have = false;
+  uint32_t i = 0, my_segments = 0;
+  RngStream rng; PhotonState<T> ph; MatStack st; int depth = 0;
+  rng.init(0, 0, 0, 0);
+  for (;;) {
+    const unsigned long long need = __ballot(!have);
+    if (need != 0ull && cur != end) {
+      const uint32_t r = (uint32_t)__popcll(need & below), left = end - cur;
+      if (!have && r < left) {
+        i = cur + r; have = true;
+        const unsigned long long attempt = a0 + i;
+        rng.init(C.seed, phase == 1 ? RT_DOMAIN_EMIT_PHASE1 : RT_DOMAIN_EMIT_PHASE2, (uint32_t)attempt, (uint32_t)(attempt >> 32));
+        create_photon<T>(S, eps, rng, ph);
+        st.init(); depth = 0; my_segments = 0;
+      }
+      cur += min((uint32_t)__popcll(need), left);
+    }
+    if (!__any(have)) break;
+    if (have) {
+      my_segments++;
+      const int k = photon_step<T>(S, G, C, rng, ph, st, depth, phase == 2, rec + (size_t)i * RT_REC_STRIDE, errors, overflows);
+      if (k >= 0) {                                          // this attempt is over: record it
+        kind[i] = (uint8_t)k;
+        nseg[i] = (uint8_t)(my_segments < 255 ? my_segments : 255);
+        segments += my_segments;
+        have = false;
+      }
     }
   }
   // one atomic per wave for the statistics

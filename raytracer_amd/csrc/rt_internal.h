@@ -40,6 +40,8 @@ struct RtKnobs {
   int no_lds = 0;                // 1: scans read the primitives through scalar loads instead of the LDS copy
   int no_cull = 0;               // 1: the first pass scans every primitive (no per-workgroup culling)
   int scan_groups = 1;           // 0: scenes are uploaded without scan groups (every fp32 all-primitives scan tests every primitive)
+  int primary_tiles = -1;        // the first pass with persistent workgroups over several 256-path tiles each (1), one workgroup per tile (0),
+                                 // or (-1) by the number of frames in flight (persistent workgroups pay from three on)
   int cull_lists = 1;            // 0: every workgroup of the first pass works out its own list of reachable primitives, every frame
   int raster_order = 0;          // 1: paths numbered row by row even where 32x8 tiles would fit
   int bvh = -1;                  // hierarchy at upload: -1 by scene size, 0 never, 1 always
@@ -52,12 +54,15 @@ struct RtKnobs {
   int gather_sort = 1;           // the requests are served in the order of their positions
   int gather_split = 4096;       // ... and subtrees of the maps of at most this many photons are work items of their own (0: one wave per 64 requests does it all)
   int knn_heap = 0;              // 1: k-nearest gathers use the per-lane heap kernel only
+  int knn_sort = -1;             // rt_gather_radiance, k > 0: the queries are first put in the order of their positions (1), taken as they come (0),
+                                 // or (-1) sorted when 64 consecutive ones lie far apart compared with the distance to a k-th neighbour
   int knn_verbose = 0;
   int probe = 0;
   double knn_radius_scale = 0;   // > 1: the wave-cooperative k-nearest gather searches balls this much larger than needed (tests)
 };
 struct rt_ctx {
   int device = 0;
+  int n_cu = 256;                        // compute units of the device (persistent kernels size their grids by it)
   hipStream_t stream = nullptr;          // the stream launches go to: streams[0], except while a queued frame is put on another
   hipStream_t streams[RT_MAX_IN_FLIGHT] = {};
   int frames_in_flight = 1;              // n > 1: consecutive queued frames rotate through n streams (rt_set_frames_in_flight)
@@ -154,7 +159,9 @@ struct rt_photon_map {
   DevMem node, pay, rec64, perm, dim;
   DevMem ws_flags;                 // per-workgroup fallback flags of the k-nearest gather (grow-only)
   DevMem ws_queue, ws_sort;        // request queue, accumulators and sort buffers of the queued radius gather (grow-only)
+  DevMem ws_knn_sort;              // keys, order, reordered queries and results of a k-nearest gather that sorts its queries (grow-only)
   float bbox[6] = { 0, 0, 0, 0, 0, 0 };   // min xyz, max xyz of the photon positions
+  float core[6] = { 0, 0, 0, 0, 0, 0 };   // the same without the outermost 2 % on either side of every axis (from the nodes of the tree's top levels)
   DevMap view() const {
     DevMap m; m.n = n; m.node = node.as<float4>(); m.pay = pay.as<float>(); m.rec64 = rec64.as<double>(); m.perm = perm.as<int32_t>();
     return m;

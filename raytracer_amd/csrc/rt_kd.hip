@@ -18,6 +18,8 @@
 // the exactly converted fp32 coordinates, so the returned index sets are exactly the
 // reference's for the same (fp32-representable) photon positions.
 #include <mutex>
+#include <vector>
+#include <algorithm>
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <string.h>
@@ -458,6 +460,22 @@ int rt_map_build_device(rt_ctx *ctx, const void *src, int src_kind, uint32_t n, 
   else if (src_kind == MAP_SRC_FULL32) RT_LAUNCH(ctx, "map_permute", k_map_permute<MAP_SRC_FULL32>, grid, 256, n, src, m->perm.as<int32_t>(), m->dim.as<uint8_t>(), m->node.as<float4>(), m->pay.as<float>(), r64);
   else RT_LAUNCH(ctx, "map_permute", k_map_permute<MAP_SRC_PACKED>, grid, 256, n, src, m->perm.as<int32_t>(), m->dim.as<uint8_t>(), m->node.as<float4>(), m->pay.as<float>(), r64);
   if (hipStreamSynchronize(ctx->stream) != hipSuccess) { delete m; return rt_fail(ctx, RT_ERR_HIP, "photon map build failed"); }
+  {
+    // The box of the map's core: the nodes of the tree's top levels are the medians of ever smaller regions -- a
+    // sample of the photons spread like the photons themselves -- and the box drops the outermost 2 % of them on
+    // either side of every axis.  (The full bounding box of an emitted map is set by a handful of photons that
+    // left the scene through a gap and landed far out on a plane.)
+    const uint32_t ns = std::min<uint32_t>(n, 4095u);
+    std::vector<float4> top(ns);
+    if (hipMemcpy(top.data(), m->node.p, (size_t)ns * 16, hipMemcpyDeviceToHost) != hipSuccess) { delete m; return rt_fail(ctx, RT_ERR_HIP, "photon map build failed"); }
+    std::vector<float> v(ns);
+    for (int d = 0; d < 3; d++) {
+      for (uint32_t i = 0; i < ns; i++) v[i] = d == 0 ? top[i].x : (d == 1 ? top[i].y : top[i].z);
+      std::sort(v.begin(), v.end());
+      const uint32_t cut = ns / 50;
+      m->core[d] = v[cut]; m->core[3 + d] = v[ns - 1 - cut];
+    }
+  }
   *out = m;
   return RT_OK;
 }
@@ -877,9 +895,13 @@ __device__ __forceinline__ uint32_t knn_load_subtree(const DevMap &M, uint32_t t
   return cnt > cap ? cap : cnt;                                            // (never cut: the host's depth keeps subtrees within the buffer)
 }
 
+// CAP: candidates a wave can hold.  (Tried: units of 64 whose candidates do not fit KNN2_CAP again as a whole with a
+// buffer of 2048 before they are cut up -- a wave's passes grow with its candidates and few such waves fit a CU: the
+// eighths serve a query in 7 ns, that launch took 12.)
+template <int CAP>
 __global__ void __launch_bounds__(64) k_gather_knn_wave(DevMap M, const float *hits, uint32_t nq, uint32_t k, float radius_scale, uint32_t t_depth, float *rgb,
                                                         const uint2 *units, const uint32_t *n_units, KnnQueues Q) {
-  __shared__ float4 cand[KNN2_CAP];                  // x y z, slot (as bits)
+  __shared__ float4 cand[CAP];                       // x y z, slot (as bits)
   __shared__ uint32_t front[KNN2_FRONT];             // the walk's queue of tree nodes (a ring)
   const int lane = threadIdx.x;
   uint32_t u_first = blockIdx.x * 64u, u_count = 64u;
@@ -910,7 +932,7 @@ __global__ void __launch_bounds__(64) k_gather_knn_wave(DevMap M, const float *h
   unsigned long long path = 0;                       // split axes along the descent, two bits a level
   knn_descend(M, 0.5f * (wave_min_f(qx) + wave_max_f(qx)), 0.5f * (wave_min_f(qy) + wave_max_f(qy)), 0.5f * (wave_min_f(qz) + wave_max_f(qz)),
               t_depth, (float4 *)&front[0], lane, t_pos, path, plane_val);
-  auto load_subtree = [&]() { return knn_load_subtree(M, t_pos, cand, lane); };
+  auto load_subtree = [&]() { return knn_load_subtree(M, t_pos, cand, lane, (uint32_t)CAP < KNN2_CAP ? (uint32_t)CAP : KNN2_CAP); };
   const uint32_t mt = load_subtree();
   __syncthreads();
   float rq;                                          // radius of this query's search ball
@@ -931,6 +953,8 @@ __global__ void __launch_bounds__(64) k_gather_knn_wave(DevMap M, const float *h
   bool overflow = false, ok = false, why_front = false;
   uint32_t c = 0, pc1 = 0, pc2 = 0, pc3 = 0;
   double b64 = 0.0, pt1 = 0.0, pt2 = 0.0, pt3 = 0.0;
+  bool fast = false;                                 // the first pass settled `ok` in fp32: the fp32 search below may run
+  float fbl = 0.f, fp1 = 0.f, fp2 = 0.f, fp3 = 0.f; uint32_t fc = 0, fc1 = 0, fc2 = 0, fc3 = 0;      // its threshold and pivots, and the counts below them
   for (int attempt = 0; attempt < 2 && !ok; attempt++) {
     overflow = false;                                // (a first try that found too many candidates was too wide: the second may fit)
     if (attempt == 1) {                              // the guaranteed radius: k-th smallest distance to T's photons
@@ -974,7 +998,7 @@ __global__ void __launch_bounds__(64) k_gather_knn_wave(DevMap M, const float *h
       const float b0 = hi0 - lo0, b1 = hi1 - lo1, b2 = hi2 - lo2;
       const float bmax = fmaxf(b0, fmaxf(b1, b2)), bmin = fminf(b0, fminf(b1, b2));
       const float predicted = rho * bmax * (b0 + b1 + b2 - bmax - bmin);
-      if (predicted > 3.0f * KNN2_CAP) { knn_give_up(Q, u_first, u_count, nq, lane, 0, predicted > 6.0f * KNN2_CAP); return; }
+      if (predicted > 3.0f * CAP) { knn_give_up(Q, u_first, u_count, nq, lane, 0, predicted > 6.0f * CAP); return; }
     }
     __syncthreads();                                 // (T has been consumed)
     m = 0;
@@ -1009,7 +1033,7 @@ __global__ void __launch_bounds__(64) k_gather_knn_wave(DevMap M, const float *h
                             ddx * ddx + ddy * ddy + ddz * ddz <= reach2;
         const unsigned long long mi = __ballot(inside);
         const uint32_t ci = (uint32_t)__popcll(mi);
-        if (m + ci > KNN2_CAP) { overflow = true; why_front = false; break; }
+        if (m + ci > (uint32_t)CAP) { overflow = true; why_front = false; break; }
         if (inside) cand[m + lanes_below(mi, lane)] = make_float4(nd.x, nd.y, nd.z, __uint_as_float(pos - 1));
         m += ci;
         const int dim = node_dim(nd);
@@ -1030,17 +1054,157 @@ __global__ void __launch_bounds__(64) k_gather_knn_wave(DevMap M, const float *h
     __syncthreads();
     if (overflow) continue;
     KNN_PROBE(0)
-    // ---- 2. first counting pass: candidates inside the query's own ball and at three pivots
-    c = 0; pc1 = 0; pc2 = 0; pc3 = 0;
-    for (uint32_t j = 0; j < m; j++) {
-      const float4 cd = cand[j];
-      const double d2 = sq_dist(x0, x1, x2, (double)cd.x, (double)cd.y, (double)cd.z);
-      c += d2 < b64 ? 1u : 0u; pc1 += d2 < pt1 ? 1u : 0u; pc2 += d2 < pt2 ? 1u : 0u; pc3 += d2 < pt3 ? 1u : 0u;
+    // ---- 2. first counting pass: candidates inside the query's own ball and at three pivots.  In fp32: the squared
+    // distance of two fp32 points evaluated in fp32 is within 3e-7 (relative) of the fp64 one, so a candidate whose fp32
+    // distance is below (1 - 1e-6) r^2 IS inside the ball and one above (1 + 1e-6) r^2 is not.  If the candidates that
+    // certainly are inside number k or more for every query, the k nearest of every query are among the candidates;
+    // if even the possible ones fall short for some query, they are not; in between the fp64 pass decides.
+    {
+      const float bl = __double2float_rd(b64 * (1.0 - 1e-6)), bh = __double2float_ru(b64 * (1.0 + 1e-6));
+      const float p1f = (float)pt1, p2f = (float)pt2, p3f = (float)pt3;
+      uint32_t c_lo = 0, c_hi = 0, f1 = 0, f2 = 0, f3 = 0;
+      for (uint32_t j = 0; j < m; j++) {
+        const float4 cd = cand[j];
+        const float dx = qx - cd.x, dy = qy - cd.y, dz = qz - cd.z;
+        const float d = dx * dx + dy * dy + dz * dz;
+        c_lo += d < bl ? 1u : 0u; c_hi += d <= bh ? 1u : 0u; f1 += d < p1f ? 1u : 0u; f2 += d < p2f ? 1u : 0u; f3 += d < p3f ? 1u : 0u;
+      }
+      fast = __all(c_lo >= k);
+      fbl = bl; fc = c_lo; fp1 = p1f; fp2 = p2f; fp3 = p3f; fc1 = f1; fc2 = f2; fc3 = f3;
+      if (fast) ok = true;
+      else if (__any(c_hi < k)) ok = false;
+      else {
+        c = 0;
+        for (uint32_t j = 0; j < m; j++) {
+          const float4 cd = cand[j];
+          c += sq_dist(x0, x1, x2, (double)cd.x, (double)cd.y, (double)cd.z) < b64 ? 1u : 0u;
+        }
+        ok = __all(c >= k);                          // then every query's k nearest photons are among the candidates, exactly
+      }
     }
     KNN_PROBE(1)
-    ok = __all(c >= k);                              // then every query's k nearest photons are among the candidates, exactly
   }
   if (!ok) { knn_give_up(Q, u_first, u_count, nq, lane, overflow ? (why_front ? 1 : 0) : 2); return; }
+  // ---- 3 (fp32). The same search as the fp64 one below on the fp32 distances, ending with the k-th smallest fp32
+  // distance (lmaxf) and the next one above it (rminf).  If those two lie more than 1e-6 (relative) apart -- the fp32
+  // error is 3e-7 -- the k candidates up to lmaxf ARE the k nearest in fp64 too, and step 4 (fp32) sums them.  A wave
+  // with a lane where they do not (1.7 % of the waves at k = 64: a gap of 1e-6 where neighbours are 1 / k apart) or where
+  // fp32 distances tie at the k-th place runs the exact search instead.
+  float sr = 0, sg = 0, sb = 0; double dk2 = 0.0;
+  float *pay_lds = (float *)&front[0];                        // 64 x 6 floats; the frontier buffers are free now
+  static_assert(KNN2_FRONT * sizeof(uint32_t) >= 64 * 6 * sizeof(float), "payload staging needs 1536 bytes");
+  bool exact = !fast;
+  if (fast) {
+    auto d2f = [&](float4 cd) { const float dx = qx - cd.x, dy = qy - cd.y, dz = qz - cd.z; return dx * dx + dy * dy + dz * dz; };
+    const uint32_t kk = k;
+    float af = 0.f, bf = fbl; uint32_t fa = 0, fb = fc;          // #(d < af) = fa < k <= fb = #(d < bf)
+    float t_hit = -1.f;                                          // >= 0: a value with exactly k candidates below it is known; next: the tracking pass there
+    if (fb == kk) t_hit = bf;
+    else if (fc1 == kk) t_hit = fp1;
+    else if (fc2 == kk) t_hit = fp2;
+    else if (fc3 == kk) t_hit = fp3;
+    else {
+      if (fc3 < kk) { af = fp3; fa = fc3; } else if (fc2 < kk) { af = fp2; fa = fc2; } else if (fc1 < kk) { af = fp1; fa = fc1; }
+      if (fc1 > kk) { bf = fp1; fb = fc1; } else if (fc2 > kk) { bf = fp2; fb = fc2; } else if (fc3 > kk) { bf = fp3; fb = fc3; }
+    }
+    bool donef = false, failf = false; float lmaxf = 0.f, rminf = 0.f;
+    for (int pass = 0; pass < 64 && !__all(donef || failf); pass++) {
+      const float span = (float)fb - (float)fa;                  // candidates in [af, bf), > 0
+      const bool narrow = t_hit >= 0.f || span <= 6.f || pass >= 5;
+      float t = (pass % 3 == 2) ? 0.5f * (af + bf) : af + (bf - af) * (((float)kk + 0.5f - (float)fa) / span);
+      if (!(t > af && t < bf)) t = 0.5f * (af + bf);
+      if (__any(!(donef || failf) && !narrow)) {                 // counting pass, pivots t1 < t < t3
+        const float dt = (bf - af) / span * (1.0f + 0.6f * sqrtf(span));
+        float t1 = t - dt, t3 = t + dt;
+        if (!(t1 > af)) t1 = 0.5f * (af + t);
+        if (!(t3 < bf)) t3 = 0.5f * (t + bf);
+        uint32_t c1 = 0, c2 = 0, c3 = 0;
+        for (uint32_t j = 0; j < m; j++) { const float d = d2f(cand[j]); c1 += d < t1 ? 1u : 0u; c2 += d < t ? 1u : 0u; c3 += d < t3 ? 1u : 0u; }
+        if (donef || failf || t_hit >= 0.f || !(t1 > af && t1 < t && t < t3 && t3 < bf)) continue;
+        if (c1 == kk) t_hit = t1; else if (c2 == kk) t_hit = t; else if (c3 == kk) t_hit = t3;
+        else {
+          if (c3 < kk) { af = t3; fa = c3; } else if (c2 < kk) { af = t; fa = c2; } else if (c1 < kk) { af = t1; fa = c1; }
+          if (c1 > kk) { bf = t1; fb = c1; } else if (c2 > kk) { bf = t; fb = c2; } else if (c3 > kk) { bf = t3; fb = c3; }
+        }
+        continue;
+      }
+      // tracking pass: the count below t and the candidate values next to t on either side
+      if (t_hit >= 0.f) t = t_hit; else if (!(t > af && t < bf)) t = bf;
+      uint32_t cnt = 0, ties = 0, rties = 0; float lmax = -1.f, rmin = 3.4e38f;
+      for (uint32_t j = 0; j < m; j++) {
+        const float d = d2f(cand[j]);
+        const bool lt = d < t, up = lt && d > lmax, eq = lt && d == lmax, dn = !lt && d < rmin, req = !lt && d == rmin;
+        cnt += lt ? 1u : 0u;
+        ties = up ? 1u : ties + (eq ? 1u : 0u); lmax = up ? d : lmax;
+        rties = dn ? 1u : rties + (req ? 1u : 0u); rmin = dn ? d : rmin;
+      }
+      if (donef || failf) continue;
+      t_hit = -1.f;
+      if (cnt == kk) { donef = true; lmaxf = lmax; rminf = rmin; }
+      else if (cnt < kk) {
+        const float above = __uint_as_float(__float_as_uint(rmin) + 1u);    // next float after rmin (>= 0, finite while candidates remain)
+        if (!(rmin < 3.0e38f)) failf = true;                       // (never: fb >= k candidates lie below bf)
+        else if (cnt + rties == kk) t_hit = above;                 // d < above  <=>  d <= rmin: k below it
+        else if (cnt + rties > kk) failf = true;                   // fp32 distances tie at the k-th place
+        else { af = above; fa = cnt + rties; }
+      }
+      else if (cnt - ties == kk) t_hit = lmax;                     // #(d < lmax) = cnt - ties
+      else if (cnt - ties < kk) failf = true;
+      else { bf = lmax; fb = cnt - ties; }
+    }
+    exact = __any(!(donef && rminf > lmaxf * 1.000001f));
+    KNN_PROBE(2)
+    if (!exact) {
+#ifdef RT_KNN_PROBE
+      if (lane == 0) { atomicAdd(&knn_probe[6], 1ull); atomicAdd(&knn_probe[8], (unsigned long long)m); }
+#endif
+      // ---- 4 (fp32). radiance of the k candidates up to lmaxf; the k-th squared distance itself (the estimate's area) in fp64
+      uint32_t j_kth = 0, n_kth = 0;
+      for (uint32_t base = 0; base < m; base += 64) {
+        __syncthreads();                                           // the previous chunk has been consumed
+        if (base + lane < m) {
+          const uint32_t slot = __float_as_uint(cand[base + lane].w);
+          const float2 *pp = (const float2 *)(M.pay + (size_t)slot * 6);      // 24-byte records: 8-byte aligned
+          const float2 p0 = pp[0], p1 = pp[1], p2 = pp[2];
+          float *dst = pay_lds + lane * 6;
+          dst[0] = p0.x; dst[1] = p0.y; dst[2] = p1.x; dst[3] = p1.y; dst[4] = p2.x; dst[5] = p2.y;
+        }
+        __syncthreads();
+        const uint32_t nc = min(64u, m - base);
+        for (uint32_t jj = 0; jj < nc; jj++) {
+          const float4 cd = cand[base + jj];
+          const float d = d2f(cd);
+          const float *pl = pay_lds + jj * 6;
+          const float w = d <= lmaxf ? fmaxf(0.0f, pl[0] * nx + pl[1] * ny + pl[2] * nz) : 0.0f;
+          sr += pl[3] * w; sg += pl[4] * w; sb += pl[5] * w;
+          const bool kth = d == lmaxf;                            // the k-th nearest (or, with an fp32 tie below the next value, several)
+          j_kth = kth ? base + jj : j_kth; n_kth += kth ? 1u : 0u;
+        }
+      }
+      // the k-th squared distance in fp64: of the one candidate at lmaxf, or the largest of several
+      if (__any(n_kth != 1u)) {
+        for (uint32_t j = 0; j < m; j++) {
+          const float4 cd = cand[j];
+          if (d2f(cd) == lmaxf) dk2 = fmax(dk2, sq_dist(x0, x1, x2, (double)cd.x, (double)cd.y, (double)cd.z));
+        }
+      } else {
+        const float4 cd = cand[j_kth < m ? j_kth : 0u];
+        dk2 = sq_dist(x0, x1, x2, (double)cd.x, (double)cd.y, (double)cd.z);
+      }
+      KNN_PROBE(4)
+    }
+  }
+  if (exact) {
+  if (fast) {                                                    // (the fp32 pass stood in for the exact first counting pass: here it is)
+    c = 0;
+    for (uint32_t j = 0; j < m; j++) { const float4 cd = cand[j]; c += sq_dist(x0, x1, x2, (double)cd.x, (double)cd.y, (double)cd.z) < b64 ? 1u : 0u; }
+  }
+  pc1 = 0; pc2 = 0; pc3 = 0;
+  for (uint32_t j = 0; j < m; j++) {
+    const float4 cd = cand[j];
+    const double d2 = sq_dist(x0, x1, x2, (double)cd.x, (double)cd.y, (double)cd.z);
+    pc1 += d2 < pt1 ? 1u : 0u; pc2 += d2 < pt2 ? 1u : 0u; pc3 += d2 < pt3 ? 1u : 0u;
+  }
   // ---- 3. per lane: t with exactly k candidates closer than t (or a tie group at the k-th distance)
   double a = 0.0, b = b64; uint32_t fa = 0, fb = c;             // #(d2 < a) = fa < k,  #(d2 < b) = fb >= k
   bool done = (fb == k); double tau = b; bool tie = false; double tie_v = 0.0; uint32_t need = 0;
@@ -1121,7 +1285,7 @@ __global__ void __launch_bounds__(64) k_gather_knn_wave(DevMap M, const float *h
   int32_t idx_thr = -1;
   if (__any(tie)) {
     uint32_t left = tie ? need : 0;
-    for (int guard = 0; guard < (int)KNN2_CAP && __any(left > 0); guard++) {
+    for (int guard = 0; guard < CAP && __any(left > 0); guard++) {
       int32_t best = 0x7FFFFFFF;
       for (uint32_t j = 0; j < m; j++) {
         const float4 cd = cand[j];
@@ -1136,9 +1300,6 @@ __global__ void __launch_bounds__(64) k_gather_knn_wave(DevMap M, const float *h
   // ---- 4. radiance of the selected candidates
   // The candidates' payloads (direction, power * colour) come in through LDS, 64 at a time: one scattered load per
   // lane and chunk instead of one dependent global load per candidate.
-  float sr = 0, sg = 0, sb = 0; double dk2 = 0.0;
-  float *pay_lds = (float *)&front[0];                        // 64 x 6 floats; the frontier buffers are free now
-  static_assert(KNN2_FRONT * sizeof(uint32_t) >= 64 * 6 * sizeof(float), "payload staging needs 1536 bytes");
   for (uint32_t base = 0; base < m; base += 64) {
     __syncthreads();                                             // the previous chunk has been consumed
     if (base + lane < m) {
@@ -1162,6 +1323,7 @@ __global__ void __launch_bounds__(64) k_gather_knn_wave(DevMap M, const float *h
     }
   }
   KNN_PROBE(4)
+  }                                                              // (exact)
   if (valid) {
     const double r2 = dk2;                                       // squared distance of the k-th nearest
     const float inv_area = (float)(1.0 / (3.141592653589793 * r2));
@@ -1415,46 +1577,50 @@ static int gather_knn_run(rt_photon_map *m, const float *dh, uint32_t nq, uint32
   uint32_t t_depth = 0;
   while (t_depth < 30 && subtree_size((uint64_t)1 << t_depth) > std::min<uint64_t>(4ull * k, KNN2_CAP)) t_depth++;
   while (t_depth > 0 && subtree_size(((uint64_t)2 << t_depth) - 1) < k) t_depth--;
-  // level 0: one wave per 64 consecutive queries.  Level 1: the units whose candidates did not fit, cut into eight (one
+  // Level 0: one wave per 64 consecutive queries.  Level 1: the units whose candidates did not fit, cut into eight (one
   // row of an 8x8 tile each).  Level 2: the queries of the eighths that did not fit either, one wave each, streaming.
   // What is left then goes to the per-lane heap kernel.
-  uint32_t *counters = (uint32_t *)ws;                                     // [0..1] units queued for level 1..2, [3] queries for the heap kernel, [4..7] units given up by cause
+  uint32_t *counters = (uint32_t *)ws;                                     // [0] eighths queued, [1] single queries queued, [3] queries for the heap kernel, [4..7] units given up by cause
   uint2 *queue[2] = { (uint2 *)((char *)ws + 256), nullptr };
   queue[1] = queue[0] + (size_t)blocks * 8;
   uint32_t *heap_list = (uint32_t *)(queue[1] + (size_t)blocks * 64);
   RT_HIP(ctx, hipMemsetAsync(counters, 0, 32, ctx->stream));
   uint32_t launched[3] = { blocks, 0, 0 };
-  for (int level = 0; level < 3; level++) {
-    if (level > 0) {                                         // what the levels before have queued for this one
-      const uint32_t queued = ctx->pinned[level - 1], cap_level = level == 1 ? blocks * KNN_SPLIT : nq;
-      launched[level] = queued <= cap_level ? queued : cap_level;
-      if (launched[level] == 0) continue;
-    }
-    KnnQueues Q; Q.next = level < 2 ? queue[level] : nullptr; Q.next_count = level < 2 ? counters + level : nullptr;
-    Q.single = queue[1]; Q.single_count = counters + 1;
-    Q.heap_list = heap_list; Q.heap_count = counters + 3; Q.why = counters + 4;
-    if (level < 2) {
-      RT_LAUNCH(ctx, level == 0 ? "gather_knn" : "gather_knn_split", k_gather_knn_wave, launched[level], 64, m->view(), dh, nq, k, scale, t_depth, dout,
-                level == 0 ? (const uint2 *)nullptr : (const uint2 *)queue[level - 1], level == 0 ? (const uint32_t *)nullptr : (const uint32_t *)(counters + level - 1), Q);
-    } else {                                                               // single queries: one wave each, streaming
-      if (4 * k <= 256) {
-        RT_LAUNCH(ctx, "gather_knn_single", k_gather_knn_single<256>, launched[level], 64, m->view(), dh, nq, k, t_depth, dout,
-                  (const uint2 *)queue[1], (const uint32_t *)(counters + 1), heap_list, counters + 3);
-      } else {
-        RT_LAUNCH(ctx, "gather_knn_single", k_gather_knn_single<KNN2_CAP>, launched[level], 64, m->view(), dh, nq, k, t_depth, dout,
-                  (const uint2 *)queue[1], (const uint32_t *)(counters + 1), heap_list, counters + 3);
-      }
-    }
+  auto read_counters = [&]() -> int {
     RT_HIP(ctx, hipMemcpyAsync(ctx->pinned, counters, 32, hipMemcpyDeviceToHost, ctx->stream));
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+  };
+  KnnQueues Q; Q.single = queue[1]; Q.single_count = counters + 1; Q.heap_list = heap_list; Q.heap_count = counters + 3; Q.why = counters + 4;
+  Q.next = queue[0]; Q.next_count = counters;
+  RT_LAUNCH(ctx, "gather_knn", k_gather_knn_wave<KNN2_CAP>, blocks, 64, m->view(), dh, nq, k, scale, t_depth, dout, (const uint2 *)nullptr, (const uint32_t *)nullptr, Q);
+  RT_TRY(read_counters());
+  // One host wait, after the first launch.  The later launches' grids are upper bounds from what is known then (an
+  // eighth leaves at most eight single queries, a single query at most itself for the heap kernel); their kernels read
+  // the true counts on the device and surplus workgroups exit at once.
+  launched[1] = std::min(ctx->pinned[0], blocks * KNN_SPLIT);
+  if (launched[1]) {
+    Q.next = queue[1]; Q.next_count = counters + 1;
+    RT_LAUNCH(ctx, "gather_knn_split", k_gather_knn_wave<KNN2_CAP>, launched[1], 64, m->view(), dh, nq, k, scale, t_depth, dout, (const uint2 *)queue[0], (const uint32_t *)counters, Q);
   }
-  const uint32_t left = ctx->pinned[3] <= nq ? ctx->pinned[3] : nq;
+  launched[2] = std::min(ctx->pinned[1] + launched[1] * KNN_SPLIT, nq);
+  if (launched[2]) {                                                       // single queries: one wave each, streaming
+    if (4 * k <= 256) {
+      RT_LAUNCH(ctx, "gather_knn_single", k_gather_knn_single<256>, launched[2], 64, m->view(), dh, nq, k, t_depth, dout,
+                (const uint2 *)queue[1], (const uint32_t *)(counters + 1), heap_list, counters + 3);
+    } else {
+      RT_LAUNCH(ctx, "gather_knn_single", k_gather_knn_single<KNN2_CAP>, launched[2], 64, m->view(), dh, nq, k, t_depth, dout,
+                (const uint2 *)queue[1], (const uint32_t *)(counters + 1), heap_list, counters + 3);
+    }
+  }
+  const uint32_t left = std::min(ctx->pinned[3] + launched[2], nq);       // (upper bound)
   if (left > 0) {
     RT_HIP(ctx, hipFuncSetAttribute((const void *)k_gather_knn, hipFuncAttributeMaxDynamicSharedMemorySize, knn_lds_bytes(k)));
     KernelTimer timer_(ctx, "gather_knn_heap_fallback");
     hipLaunchKernelGGL(k_gather_knn, dim3(div_up(left, KNN_LANES)), dim3(KNN_LANES), knn_lds_bytes(k), ctx->stream, m->view(),
                        dh, nq, k, dout, (const uint32_t *)heap_list, (const uint32_t *)(counters + 3));
   }
+  if (K.knn_verbose) RT_TRY(read_counters());
   RT_HIP(ctx, hipGetLastError());
 #ifdef RT_KNN_PROBE
   if (K.knn_verbose) {
@@ -1474,7 +1640,108 @@ static int gather_knn_run(rt_photon_map *m, const float *dh, uint32_t nq, uint32
 #endif
   if (K.knn_verbose)
     fprintf(stderr, "rt_gather_radiance: %u units of 64 queries, then %u of 8, %u of 1; given up for candidates %u, frontier %u, short %u, search %u; %u queries left to the heap kernel\n",
-            launched[0], launched[1], launched[2], ctx->pinned[4], ctx->pinned[5], ctx->pinned[6], ctx->pinned[7], left);
+            launched[0], ctx->pinned[0], ctx->pinned[1], ctx->pinned[4], ctx->pinned[5], ctx->pinned[6], ctx->pinned[7], ctx->pinned[3]);
+  return RT_OK;
+}
+
+// ---- putting the queries of a k-nearest gather in the order of their positions
+// The wave kernel serves 64 consecutive queries with one walk over the box of their search balls: that pays while they
+// are neighbours (a caller that orders hit points by 8x8 image tile gets there by itself) and falls apart when they are
+// not -- row by row, 64 consecutive pixels are a strip whose box holds several times the photons of its balls, and
+// nearly every unit ends up cut into eighths.  So rt_gather_radiance looks at the queries first: the mean diagonal of
+// the box around 64 consecutive query points against the distance at which a query finds its k-th photon at the map's
+// mean density; beyond 1.5 of those the queries are sorted by the Morton code of their positions (10 bits an axis over
+// the map's bounding box), gathered in that order and the results put back where the caller wants them.
+// (every `stride`-th group of 64 is looked at: a few thousand atomics on one address, not tens of thousands)
+__global__ void __launch_bounds__(256) k_knn_spread(const float *hits, uint32_t nq, uint32_t stride, float *sum) {
+  const uint32_t q = ((blockIdx.x * blockDim.x + threadIdx.x) >> 6) * 64u * stride + (threadIdx.x & 63u);
+  const bool have = q < nq;
+  const float *h = hits + (size_t)(have ? q : 0) * 9;
+  const float x = h[0], y = h[1], z = h[2], inf = 3.4e38f;
+  const float l0 = wave_min_f(have ? x : inf), l1 = wave_min_f(have ? y : inf), l2 = wave_min_f(have ? z : inf);
+  const float h0 = wave_max_f(have ? x : -inf), h1 = wave_max_f(have ? y : -inf), h2 = wave_max_f(have ? z : -inf);
+  if ((threadIdx.x & 63) == 0 && have) {
+    const float d = sqrtf((h0 - l0) * (h0 - l0) + (h1 - l1) * (h1 - l1) + (h2 - l2) * (h2 - l2));
+    if (d == d && d < 1e30f) { atomicAdd(sum, d); atomicAdd(sum + 1, 1.0f); }
+  }
+}
+__device__ __forceinline__ uint32_t spread10(uint32_t v) {
+  v &= 1023u; v = (v | (v << 16)) & 0x030000FFu; v = (v | (v << 8)) & 0x0300F00Fu; v = (v | (v << 4)) & 0x030C30C3u; v = (v | (v << 2)) & 0x09249249u;
+  return v;
+}
+__global__ void __launch_bounds__(256) k_knn_keys(const float *hits, uint32_t nq, float lo0, float lo1, float lo2, float inv_cell, uint32_t *keys, uint32_t *vals) {
+  const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= nq) return;
+  const float *h = hits + (size_t)q * 9;
+  auto cell = [&](float v, float lo) { const float c = (v - lo) * inv_cell; return (uint32_t)(c < 0.f ? 0.f : (c > 1023.f ? 1023.f : c)); };   // (NaN -> 0)
+  keys[q] = spread10(cell(h[0], lo0)) | (spread10(cell(h[1], lo1)) << 1) | (spread10(cell(h[2], lo2)) << 2);
+  vals[q] = q;
+}
+// dst[i] = src[order[i]] (GATHER) or dst[order[i]] = src[i] (!GATHER), rows of W floats
+template <int W, bool GATHER> __global__ void __launch_bounds__(256) k_knn_reorder(const float *src, const uint32_t *order, uint32_t nq, float *dst) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nq) return;
+  const uint32_t o = order[i];
+  if (o >= nq) return;                                       // (never true)
+  const float *a = src + (size_t)(GATHER ? o : i) * W;
+  float *b = dst + (size_t)(GATHER ? i : o) * W;
+#pragma unroll
+  for (int c = 0; c < W; c++) b[c] = a[c];
+}
+static int rt_sort_pairs_u32(rt_ctx *ctx, DevMem &temp, const uint32_t *keys_in, uint32_t *keys_out, const uint32_t *vals_in, uint32_t *vals_out, uint32_t n, int bits) {
+  if (n == 0) return RT_OK;
+  size_t bytes = 0;
+  RT_HIP(ctx, rocprim::radix_sort_pairs(nullptr, bytes, keys_in, keys_out, vals_in, vals_out, n, 0, bits, ctx->stream));
+  RT_HIP(ctx, temp.reserve(bytes ? bytes : 16));
+  RT_HIP(ctx, rocprim::radix_sort_pairs(temp.p, bytes, keys_in, keys_out, vals_in, vals_out, n, 0, bits, ctx->stream));
+  return RT_OK;
+}
+
+// the k-nearest gather of rt_gather_radiance: in the caller's order, or sorted first (see above)
+static int gather_knn_ordered(rt_photon_map *m, const float *dh, uint32_t nq, uint32_t k, float *dout) {
+  rt_ctx *ctx = m->ctx;
+  const RtKnobs &K = ctx->knobs;
+  bool sort = K.knn_sort > 0;
+  if (K.knn_sort < 0 && nq >= 4096 && m->n >= 2 * KNN2_CAP && m->n >= k && !K.knn_heap) {
+    RT_HIP(ctx, m->ws_flags.reserve(knn_scratch_bytes(nq)));
+    float *sum = (float *)m->ws_flags.p;
+    RT_HIP(ctx, hipMemsetAsync(sum, 0, 8, ctx->stream));
+    const uint32_t groups = div_up(nq, 64), stride = std::max(1u, groups / 2048u), sampled = div_up(groups, stride);
+    RT_LAUNCH(ctx, "gather_knn_spread", k_knn_spread, div_up(sampled, 4), 256, dh, nq, stride, sum);
+    RT_HIP(ctx, hipMemcpyAsync(ctx->pinned, sum, 8, hipMemcpyDeviceToHost, ctx->stream));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    float total[2]; memcpy(total, ctx->pinned, 8);
+    const double mean_diag = total[1] > 0 ? (double)total[0] / (double)total[1] : 0.0;
+    // (the map's extent without its stragglers -- a photon that left through a gap in the scene lands far out on a plane:
+    // the box of its core, see rt_photon_map::core)
+    const double e0 = m->core[3] - m->core[0], e1 = m->core[4] - m->core[1], e2 = m->core[5] - m->core[2];
+    const double emax = std::max(e0, std::max(e1, e2));
+    const double area = std::max(2.0 * (e0 * e1 + e1 * e2 + e2 * e0), 1e-6 * emax * emax);
+    const double r_k = sqrt((double)k * area / (3.141592653589793 * (double)m->n));      // photons lie on surfaces: k of them in pi r^2 at the mean density
+    sort = mean_diag > 1.5 * r_k;
+    if (K.knn_verbose) fprintf(stderr, "rt_gather_radiance: 64 consecutive queries span %.4g on average, a k-th neighbour is about %.4g away: %s\n", mean_diag, r_k, sort ? "sorting the queries" : "taking them as they come");
+  }
+  if (!sort) {
+    RT_HIP(ctx, m->ws_flags.reserve(knn_scratch_bytes(nq)));
+    return gather_knn_run(m, dh, nq, k, dout, m->ws_flags.p);
+  }
+  size_t off = 0;
+  auto carve = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+  const size_t o_kin = carve((size_t)nq * 4), o_kout = carve((size_t)nq * 4), o_vin = carve((size_t)nq * 4), o_vout = carve((size_t)nq * 4),
+               o_hits = carve((size_t)nq * 36), o_rgb = carve((size_t)nq * 12);
+  RT_HIP(ctx, m->ws_knn_sort.reserve(off));
+  char *base = (char *)m->ws_knn_sort.p;
+  uint32_t *kin = (uint32_t *)(base + o_kin), *kout = (uint32_t *)(base + o_kout), *vin = (uint32_t *)(base + o_vin), *vout = (uint32_t *)(base + o_vout);
+  float *hs = (float *)(base + o_hits), *rs = (float *)(base + o_rgb);
+  const double emax = std::max((double)m->core[3] - m->core[0], std::max((double)m->core[4] - m->core[1], (double)m->core[5] - m->core[2]));
+  const float inv_cell = emax > 0 ? (float)(1024.0 / emax) : 1.0f;      // (queries outside the core box share its outermost cells)
+  RT_LAUNCH(ctx, "gather_knn_keys", k_knn_keys, div_up(nq, 256), 256, dh, nq, m->core[0], m->core[1], m->core[2], inv_cell, kin, vin);
+  { KernelTimer timer_(ctx, "gather_knn_sort"); RT_TRY(rt_sort_pairs_u32(ctx, m->ws_sort, kin, kout, vin, vout, nq, 30)); }
+  RT_LAUNCH(ctx, "gather_knn_reorder", (k_knn_reorder<9, true>), div_up(nq, 256), 256, dh, (const uint32_t *)vout, nq, hs);
+  RT_HIP(ctx, m->ws_flags.reserve(knn_scratch_bytes(nq)));
+  RT_TRY(gather_knn_run(m, hs, nq, k, rs, m->ws_flags.p));
+  RT_LAUNCH(ctx, "gather_knn_reorder", (k_knn_reorder<3, false>), div_up(nq, 256), 256, (const float *)rs, (const uint32_t *)vout, nq, dout);
+  RT_HIP(ctx, hipGetLastError());
   return RT_OK;
 }
 
@@ -1499,8 +1766,7 @@ extern "C" int rt_gather_radiance(rt_photon_map *m, const float *hits, uint32_t 
     else RT_LAUNCH(ctx, "gather_radius", k_gather_radius, div_up(nq, 256), 256, m->view(), (const float *)dh, nq, r, (float *)dout);
     RT_HIP(ctx, hipGetLastError());
   } else {
-    RT_HIP(ctx, m->ws_flags.reserve(knn_scratch_bytes(nq)));
-    RT_TRY(gather_knn_run(m, (const float *)dh, nq, k, (float *)dout, m->ws_flags.p));
+    RT_TRY(gather_knn_ordered(m, (const float *)dh, nq, k, (float *)dout));
   }
   RT_TRY(rt_stage_out_end(ctx, rgb_out, (size_t)nq * 12, to));
   return RT_OK;

@@ -267,7 +267,18 @@ static int trace_tile_mode(rt_scene *sc, int slot, const rt_params *p, DevMap md
       break;
     }
     if (wave_bounces == 0) {
-      if (lds) RT_LAUNCH_SMEM(ctx, "primary", (k_primary<T, true, WHITTED, FULL>), blocks, 256, smem, S, P, C, md, mc, levels, q_cur, cnt, wave_mask, block_count, ctr);
+      bool tiles_done = false;
+      if constexpr (sizeof(T) == 4) {
+        // persistent workgroups where everything they rely on is there: the scene in LDS, ready-made lists, sub-queues
+        if (lds && C.cull_lists && C.subq_cap && (K.primary_tiles >= 0 ? K.primary_tiles != 0 : ctx->frames_in_flight >= 3) && S.n_shapes <= RT_LDS_HIT_MAX) {
+          const uint32_t resident = (uint32_t)ctx->n_cu * 8u;
+          const uint32_t per_block = std::min<uint32_t>(div_up(blocks, resident), RT_PT_MAX_TILES);
+          RT_LAUNCH_SMEM(ctx, "primary", (k_primary_tiles<WHITTED, FULL>), div_up(blocks, per_block), 256, smem, S, P, C, md, mc, levels, q_cur, cnt, ctr, blocks, per_block);
+          tiles_done = true;
+        }
+      }
+      if (tiles_done) {}
+      else if (lds) RT_LAUNCH_SMEM(ctx, "primary", (k_primary<T, true, WHITTED, FULL>), blocks, 256, smem, S, P, C, md, mc, levels, q_cur, cnt, wave_mask, block_count, ctr);
       else RT_LAUNCH_SMEM(ctx, "primary", (k_primary<T, false, WHITTED, FULL>), blocks, 256, 0, S, P, C, md, mc, levels, q_cur, cnt, wave_mask, block_count, ctr);
     } else {
       if (lds) RT_LAUNCH_SMEM(ctx, "intersect_closest", (k_intersect_closest<T, true, WHITTED>), blocks, 256, smem, S, P, C, q_cur, cnt, ctr);
@@ -514,16 +525,16 @@ int pl_emit_batch(rt_scene *sc, const rt_params *p, int phase, uint64_t a0, uint
   if (!sc->ws_misc.p) { RT_HIP(ctx, sc->ws_misc.alloc(256)); RT_HIP(ctx, hipMemsetAsync(sc->ws_misc.p, 0, 256, ctx->stream)); }
   EmitCfg C; C.epsilon = working_eps<T>(p); C.max_depth = p->max_depth; C.num_diffuse = p->num_photons_diffuse;
   C.num_caustic = p->num_photons_caustic; C.seed = p->seed;
-  // attempts per workgroup: 16 a lane when the batch is large enough to fill the chip several times over, fewer otherwise
-  uint32_t per_lane = 16;
-  while (per_lane > 1 && (uint64_t)count < (uint64_t)per_lane * 256 * 2048) per_lane /= 2;
-  const uint32_t per_wg = per_lane * 256;
+  // persistent waves: as many workgroups as stay resident (RT_EMIT_MIN_BLOCKS per CU), fewer for a small batch; every
+  // wave takes an equal contiguous share of the batch (a multiple of 64 attempts)
+  const uint32_t wgs = std::max<uint32_t>(1u, std::min<uint32_t>(div_up(count, 256), (uint32_t)ctx->n_cu * RT_EMIT_MIN_BLOCKS));
+  const uint32_t per_wave = div_up(div_up(count, wgs * 4), 64) * 64;
   if (!S.bvh && scene_fits_lds<T>(S.n_shapes))
-    RT_LAUNCH_SMEM(ctx, "photon_emit_bounce", (k_emit<T, true>), div_up(count, per_wg), 256, scan_lds_bytes<T>(S.n_shapes), S, C, phase,
-                   (unsigned long long)a0, count, per_wg, sc->ws_emit_kind.as<uint8_t>(), sc->ws_emit_rec.as<T>(), sc->ws_emit_seg.as<uint8_t>(), sc->ws_misc.as<EmitCounters>());
+    RT_LAUNCH_SMEM(ctx, "photon_emit_bounce", (k_emit<T, true>), wgs, 256, scan_lds_bytes<T>(S.n_shapes), S, C, phase,
+                   (unsigned long long)a0, count, per_wave, sc->ws_emit_kind.as<uint8_t>(), sc->ws_emit_rec.as<T>(), sc->ws_emit_seg.as<uint8_t>(), sc->ws_misc.as<EmitCounters>());
   else
-    RT_LAUNCH_SMEM(ctx, "photon_emit_bounce", (k_emit<T, false>), div_up(count, per_wg), 256, 0, S, C, phase,
-                   (unsigned long long)a0, count, per_wg, sc->ws_emit_kind.as<uint8_t>(), sc->ws_emit_rec.as<T>(), sc->ws_emit_seg.as<uint8_t>(), sc->ws_misc.as<EmitCounters>());
+    RT_LAUNCH_SMEM(ctx, "photon_emit_bounce", (k_emit<T, false>), wgs, 256, 0, S, C, phase,
+                   (unsigned long long)a0, count, per_wave, sc->ws_emit_kind.as<uint8_t>(), sc->ws_emit_rec.as<T>(), sc->ws_emit_seg.as<uint8_t>(), sc->ws_misc.as<EmitCounters>());
   RT_HIP(ctx, hipGetLastError());
   return RT_OK;
 }

@@ -7,6 +7,14 @@
 
 template <typename T> RT_D T two_pi() { return T(2) * T(3.141592653589793); }
 
+// sin and cos of the angle 2 pi u, u in [0, 1): the reference's `Math.sin(2 * Math.PI * Math.random())` pairs
+// (rayphoton.js:134-136, :1923-1925).  fp64: exactly that expression (the parity build lands on the reference's bits).
+// fp32: the hardware's v_sin_f32 / v_cos_f32, which take their argument in turns -- two instructions instead of the
+// library routines' range reduction and polynomials (about a hundred), absolute error below 1e-6, inside the fp32
+// build's stated tolerance.
+RT_D void sincos_turns(double u, double &s, double &c) { const double phi = two_pi<double>() * u; s = rt_sin(phi); c = rt_cos(phi); }
+RT_D void sincos_turns(float u, float &s, float &c) { s = __builtin_amdgcn_sinf(u); c = __builtin_amdgcn_cosf(u); }
+
 template <typename T> RT_D void orthonormal(V3<T> v, T eps, V3<T> &m, V3<T> &n) {
   V3<T> v2 = normalize<T>(v, eps);
   V3<T> m0 = mk<T>(1, 0, 0);
@@ -16,21 +24,21 @@ template <typename T> RT_D void orthonormal(V3<T> v, T eps, V3<T> &m, V3<T> &n) 
 }
 
 // cosine-weighted direction around v (maxDeviation undefined: lower bound 0). 2 draws.
-template <typename T> RT_D V3<T> vec_perturb(V3<T> v, T eps, RngStream &rng) {
+template <typename T, typename RNG> RT_D V3<T> vec_perturb(V3<T> v, T eps, RNG &rng) {
   V3<T> m, n; orthonormal<T>(v, eps, m, n);
-  T x = rng.next<T>();
+  T x = rng.template next<T>();
   T cosT = rt_sqrt(x);
   T sinT = rt_sqrt(T(1) - cosT * cosT);
-  T phi = two_pi<T>() * rng.next<T>();
-  return (cosT * v + (sinT * rt_cos(phi)) * m) + (sinT * rt_sin(phi)) * n;
+  T sinP, cosP; sincos_turns(rng.template next<T>(), sinP, cosP);
+  return (cosT * v + (sinT * cosP) * m) + (sinT * sinP) * n;
 }
 
 // uniform point on a disc. 2 draws.
-template <typename T> RT_D V3<T> disc_sample(V3<T> centre, T radius, V3<T> normal_dir, T eps, RngStream &rng) {
-  T r = rt_sqrt(rng.next<T>()) * radius;
-  T theta = two_pi<T>() * rng.next<T>();
+template <typename T, typename RNG> RT_D V3<T> disc_sample(V3<T> centre, T radius, V3<T> normal_dir, T eps, RNG &rng) {
+  T r = rt_sqrt(rng.template next<T>()) * radius;
+  T sinT, cosT; sincos_turns(rng.template next<T>(), sinT, cosT);
   V3<T> m, n; orthonormal<T>(normal_dir, eps, m, n);
-  return (centre + (r * rt_cos(theta)) * m) + (r * rt_sin(theta)) * n;
+  return (centre + (r * cosT) * m) + (r * sinT) * n;
 }
 
 template <typename T> struct PhotonState {
@@ -42,8 +50,8 @@ template <typename T> struct PhotonState {
 // createPhoton(source) (rayphoton.js:1326-1344): without a source (< 0) the light is chosen by walking the cumulative
 // probabilities; the draw for that choice is made either way.  Always 5 draws.  Returns the light index (clamped
 // where the reference would run off the end of the list and throw).
-template <typename T> RT_D int create_photon(const DevScene<T> &S, T eps, RngStream &rng, PhotonState<T> &ph, int source = -1) {
-  T r = rng.next<T>();
+template <typename T, typename RNG> RT_D int create_photon(const DevScene<T> &S, T eps, RNG &rng, PhotonState<T> &ph, int source = -1) {
+  T r = rng.template next<T>();
   uint32_t l = 0;
   if (source >= 0) l = (uint32_t)source;
   else while (l < S.n_lights && r > S.light_data[l][2]) { r -= S.light_data[l][2]; l++; }
@@ -81,8 +89,8 @@ struct MatStack {
 // Returns 0 when eta2 is undefined (caller decides what that means), 1 otherwise with the new
 // direction in `ndir` (not yet normalised) and the stack updated.  Consumes one draw unless the
 // surface reflects totally.
-template <typename T>
-RT_D int fresnel_bounce(const DevScene<T> &S, int mat, V3<T> d, V3<T> n, T cos1, MatStack &st, RngStream &rng,
+template <typename T, typename RNG>
+RT_D int fresnel_bounce(const DevScene<T> &S, int mat, V3<T> d, V3<T> n, T cos1, MatStack &st, RNG &rng,
                         V3<T> &ndir, bool &overflow) {
   // (the indices differ from lane to lane and the table sits in the kernel arguments: selects, not indexed loads)
   T eta1 = pick8<T>(S.mat[1], st.top());
@@ -99,7 +107,7 @@ RT_D int fresnel_bounce(const DevScene<T> &S, int mat, V3<T> d, V3<T> n, T cos1,
   T a2 = (eta1 * cos2 - eta2 * cos1) / (eta1 * cos2 + eta2 * cos1);
   T rS = a1 * a1, rP = a2 * a2;
   if (cos1 < T(0)) { rS = T(1) / rS; rP = T(1) / rP; }
-  if (rng.next<T>() < T(0.5) * (rS + rP)) { ndir = d + (T(2) * cos1) * n; return 1; }
+  if (rng.template next<T>() < T(0.5) * (rS + rP)) { ndir = d + (T(2) * cos1) * n; return 1; }
   T pm = (cos1 < T(0)) ? T(-1) : T(1);
   ndir = ratio * d + (ratio * cos1 - pm * cos2) * n;
   if (cos1 < T(0)) st.pop();

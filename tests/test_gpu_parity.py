@@ -1180,9 +1180,18 @@ def test_culling_and_tile_order_are_exact(rt, size):
             c = sc.trace_tile(p, want=("pre", "rgba8"))
         with ctx.option("cull_lists", 0, 1):               # every workgroup culls for itself instead of reading the kept lists
             d = sc.trace_tile(p, want=("pre", "rgba8"))
+        with ctx.option("primary_tiles", 1, -1):           # the first pass with persistent workgroups (by itself: from three frames in flight on)
+            e_ = sc.trace_tile(p, want=("pre", "rgba8"))
+        with ctx.option("primary_tiles", 1, -1), ctx.option("tail_persistent", 4, -1):
+            f_ = sc.trace_tile(p, want=("pre", "rgba8"))
+        for name, x in (("primary_tiles", e_), ("primary_tiles + persistent tail", f_)):
+            assert same(x["pre"], ref["pre"]) and np.array_equal(x["rgba8"], ref["rgba8"]), (name, kw)
+            for k in ("rays", "shadow_rays", "tail_rays", "bounces"):
+                assert x["stats"][k] == ref["stats"][k], (name, k)
+            assert abs(x["stats"]["prim_tests"] - ref["stats"]["prim_tests"]) < 0.04 * ref["stats"]["prim_tests"]
         # (the first pass tests the same lists; later segments skip the groups no ray of their wave reaches, and which
         # paths share a wave there is not fixed from run to run)
-        assert abs(d["stats"]["prim_tests"] - ref["stats"]["prim_tests"]) < 0.01 * ref["stats"]["prim_tests"]
+        assert abs(d["stats"]["prim_tests"] - ref["stats"]["prim_tests"]) < 0.04 * ref["stats"]["prim_tests"]     # (and the two first-pass kernels queue the survivors in different orders)
         for name, x in (("no_cull", a), ("raster_order", b), ("no_cull+raster_order", c), ("cull_lists=0", d)):
             assert same(x["pre"], ref["pre"]) and np.array_equal(x["rgba8"], ref["rgba8"]), (name, kw)
             for k in ("rays", "shadow_rays", "tail_rays", "bounces"):
