@@ -138,7 +138,8 @@ int rt_synchronize(rt_ctx *ctx);            /* host wait for everything the cont
 int rt_join(rt_ctx *ctx);
 /* Experiment / test switches, by name: tail_threshold, whole_frame, bounce_passes, tail_handoff, tail_rounds,
  * tail_persistent, no_lds, no_cull, cull_lists, primary_tiles, raster_order, bvh (-1 by scene size / 0 / 1) and scan_groups (0 / 1)
- * (both read by rt_scene_upload), bvh_one_order, defer_gathers, gather_sort, gather_split, wave_gather, knn_heap,
+ * (both read by rt_scene_upload), bvh_one_order, defer_gathers, gather_sort, gather_split, wave_gather, knn_heap, knn_sort (-1: order the k-nearest queries
+ * by position when they arrive scattered / 0 never / 1 always),
  * knn_radius_scale, knn_verbose, probe.  rt_init reads
  * RT355_<NAME> from the environment once; this call changes one switch of a live context.  The defaults are the
  * measured best; results do not depend on any of them (fp32 images: bit for bit).  No counterpart in the reference. */
@@ -148,6 +149,14 @@ int rt_set_option(rt_ctx *ctx, const char *name, double value);
  * share output buffers.  n = 1 (default): queued frames run one after the other.  No counterpart in the reference (its frames are
  * serial by construction). */
 int rt_set_frames_in_flight(rt_ctx *ctx, int n);
+/* Device memory of the context's GPU for hosts without a HIP binding of their own (the Node addon: N-API has no device
+ * arrays): buffers for the outputs of queued frames, for shards and for gather inputs.  rt_device_copy copies between
+ * any two of host and device memory and returns when the bytes are there; it first waits for everything the context has
+ * queued (so a queued frame's output can be read straight after queueing it), and rt_device_free does too.  A caller that
+ * has hipMalloc (or torch) uses that instead: the library accepts any device pointer.  No counterpart in the reference. */
+int rt_device_alloc(rt_ctx *ctx, uint64_t bytes, void **out);
+int rt_device_free(rt_ctx *ctx, void *ptr);
+int rt_device_copy(rt_ctx *ctx, void *dst, const void *src, uint64_t bytes);
 /* Per-kernel HIP-event timing (off by default).  rt_profile_get sums the launches of one
  * kernel name since the last reset; it synchronises the stream.  on = n > 1: only every n-th launch of a kernel
  * name is timed (a sample: a launch that carries events does not overlap its neighbours as freely). */

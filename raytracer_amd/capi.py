@@ -22,7 +22,7 @@ MODE_PHOTON, MODE_WHITTED = 0, 1
 SCAN_CLOSEST, SCAN_CLOSEST_NOLIGHT, SCAN_ANY = 0, 1, 2
 
 EXPORTS = [
-    "rt_default_params", "rt_init", "rt_shutdown", "rt_last_error", "rt_stream", "rt_synchronize", "rt_join", "rt_set_option", "rt_set_frames_in_flight",
+    "rt_default_params", "rt_init", "rt_shutdown", "rt_last_error", "rt_stream", "rt_synchronize", "rt_join", "rt_set_option", "rt_set_frames_in_flight", "rt_device_alloc", "rt_device_free", "rt_device_copy",
     "rt_profile_enable", "rt_profile_select", "rt_profile_reset", "rt_profile_get", "rt_scene_upload", "rt_scene_free",
     "rt_intersect_pairs", "rt_intersect", "rt_emit_photons", "rt_emit_many", "rt_emit_many_lists", "rt_emit_shard",
     "rt_lists_create", "rt_lists_free", "rt_lists_record_words", "rt_lists_apply", "rt_lists_counts", "rt_lists_export", "rt_lists_view",

@@ -183,6 +183,33 @@ int rt_synchronize(rt_ctx *ctx) {
   return RT_OK;
 }
 
+// Plain device memory of the context's GPU for hosts that have no HIP binding of their own (the Node addon): outputs of
+// queued frames, shards, gather inputs.  The copy waits for everything the context has queued first.
+int rt_device_alloc(rt_ctx *ctx, uint64_t bytes, void **out) {
+  if (!ctx || !out) return RT_ERR_INVALID;
+  *out = nullptr;
+  if (bytes == 0) return rt_fail(ctx, RT_ERR_INVALID, "rt_device_alloc: zero bytes");
+  RT_HIP(ctx, hipSetDevice(ctx->device));
+  hipError_t e = hipMalloc(out, (size_t)bytes);
+  if (e != hipSuccess) { (void)hipGetLastError(); *out = nullptr; return rt_fail(ctx, RT_ERR_HIP, "rt_device_alloc(%llu bytes): %s", (unsigned long long)bytes, hipGetErrorString(e)); }
+  return RT_OK;
+}
+int rt_device_free(rt_ctx *ctx, void *ptr) {
+  if (!ctx) return RT_ERR_INVALID;
+  if (!ptr) return RT_OK;
+  RT_HIP(ctx, hipSetDevice(ctx->device));
+  RT_TRY(rt_synchronize(ctx));                       // queued frames may still write to it
+  RT_HIP(ctx, hipFree(ptr));
+  return RT_OK;
+}
+int rt_device_copy(rt_ctx *ctx, void *dst, const void *src, uint64_t bytes) {
+  if (!ctx || ((!dst || !src) && bytes)) return RT_ERR_INVALID;
+  RT_HIP(ctx, hipSetDevice(ctx->device));
+  RT_TRY(rt_synchronize(ctx));
+  if (bytes) RT_HIP(ctx, hipMemcpy(dst, src, (size_t)bytes, hipMemcpyDefault));
+  return RT_OK;
+}
+
 int rt_set_frames_in_flight(rt_ctx *ctx, int n) {
   if (!ctx) return RT_ERR_INVALID;
   if (n < 1 || n > RT_MAX_IN_FLIGHT) return rt_fail(ctx, RT_ERR_INVALID, "frames in flight must be in 1..%d", RT_MAX_IN_FLIGHT);

@@ -27,6 +27,18 @@ function context(device) {
 }
 
 const PRECISION = { F32: 0, F64: 1 };
+// record formats of device-resident photon lists and shards: FULL = the 11 record values in the working precision,
+// PACKED = position, direction, power * colour as 9 floats (what the photon map keeps)
+const SHARD = { FULL: 0, PACKED: 1 };
+
+// Plain GPU memory: where a queued frame's pixels, a shard or a batch of gather points live until somebody reads them.
+class DeviceBuffer {
+  constructor(bytes, ctx) { this.bytes = bytes; this.handle = addon().deviceAlloc(ctx || context(), bytes); }
+  // copies out.byteLength bytes from byteOffset into `out` (any typed array); waits for queued frames first
+  read(out, byteOffset) { return addon().deviceRead(this.handle, out, byteOffset || 0); }
+  write(src, byteOffset) { addon().deviceWrite(this.handle, src, byteOffset || 0); return this; }
+  free() { addon().deviceFree(this.handle); }
+}
 
 // the reference's top-of-file constants (rayphoton.js:6-23) as overridable defaults
 const DEFAULTS = {
@@ -78,17 +90,30 @@ function recordsToPhotons(rec, isCaustic) {
 
 class KdTree {
   // photons: array of {origin, dir, power, colour} (anything with .origin works for pure queries),
-  // or a Float64Array of 11-double records
+  // a Float64Array of 11-double records, or {lists, which, n}: one of the two device-resident lists of an emission
+  // (the tree is then built where the photons are; records and photon objects cross to the host only if somebody looks)
   constructor(data) {
-    const n = ArrayBuffer.isView(data) ? data.length / 11 : data.length;
+    const fromLists = data && data.lists !== undefined;
+    const n = fromLists ? data.n : (ArrayBuffer.isView(data) ? data.length / 11 : data.length);
     console.log(`building a k-d tree with ${n} elements`);                 // kdtree.js:3
     if (n === 0) throw new Error('tried to build a k-d tree with no data!');   // kdtree.js:6
-    this.photons = ArrayBuffer.isView(data) ? null : data;
-    this.records = ArrayBuffer.isView(data) ? data : photonsToRecords(data);
-    this.map = addon().photonMapBuild(context(), this.records);
+    this._n = n;
     this._nodes = null;
+    if (fromLists) {
+      this.photons = null; this._records = null; this._lists = data.lists; this._which = data.which;
+      this.map = addon().photonMapBuildLists(data.lists, data.which);
+      return;
+    }
+    this.photons = ArrayBuffer.isView(data) ? null : data;
+    this._records = ArrayBuffer.isView(data) ? data : photonsToRecords(data);
+    this.map = addon().photonMapBuild(context(), this._records);
   }
-  get length() { return this.records.length / 11; }
+  // the 11-double records (of a device-resident list: exported on first use; such lists must be in the FULL format)
+  get records() {
+    if (!this._records) this._records = addon().listsExport(this._lists, this._which).records;
+    return this._records;
+  }
+  get length() { return this._n; }
   photonAt(i) {
     if (!this.photons) this.photons = recordsToPhotons(this.records, undefined);
     return this.photons[i];
@@ -173,7 +198,7 @@ class Scene {
   // All thirteen scenes of rayphoton.js:731-1305, built with this host's constructors (presets.js).  Those that place
   // or colour things at random draw from random(): the keyed stream (seed, AUX, 1000 + id; 1099 for the named presets),
   // so a preset is the same scene on every run and on every rank.
-  loadPreset(def) {
+  loadPreset(def, emit) {
     const build = presets[String(def)];
     if (build && String(def) !== 'helpers') {
       this.lights = [];
@@ -181,7 +206,7 @@ class Scene {
       build(this, S);
     } else { console.log('No such scene!'); }                                // rayphoton.js:1306
     this.initLights();
-    this.emitManyPhotons();
+    if (emit !== false) this.emitManyPhotons();          // (false: a rank of a multi-GPU job emits its share itself)
   }
   // the next number of the scene's own random stream (what Math.random() is to the reference's scene code)
   random() {
@@ -204,29 +229,64 @@ class Scene {
   }
   invalidate() { this._device = null; }
 
-  // emitManyPhotons (rayphoton.js:1354-1383): both phases on the GPU, then both kd-trees
+  // emitManyPhotons (rayphoton.js:1354-1383): both phases on the GPU, then both kd-trees.  The two photon lists stay in
+  // GPU memory (scene.photonLists) and the trees are built from them there; photonListDiffuse / photonListCaustic and the
+  // record arrays are fetched when somebody reads them.  params.listFormat = SHARD.PACKED keeps 36-byte photons only
+  // (enough for the maps and for rendering; the photon objects and `records` are then not available).
   emitManyPhotons() {
     if (this.lights.length === 0) { console.log("No lights! Can't emit photons."); return; }
-    const res = addon().emitMany(this._scene(), this.params);
+    const format = this.params.listFormat === undefined ? SHARD.FULL : this.params.listFormat;
+    const res = addon().emitManyLists(this._scene(), this.params, format);
     this.emitStats = res.stats;
+    this.photonLists = res.lists;
+    const lazyRecords = (which, n) => { let rec = null; return () => (rec = rec || (n ? addon().listsExport(res.lists, which).records : new Float64Array(0))); };
+    const recD = lazyRecords(0, res.stats.nDiffuse), recC = lazyRecords(1, res.stats.nCaustic);
+    Object.defineProperty(this, '_recD', { configurable: true, get: recD });
+    Object.defineProperty(this, '_recC', { configurable: true, get: recC });
+    let listD = null, listC = null;     // photon object lists are materialised only if somebody looks
+    Object.defineProperty(this, 'photonListDiffuse', { configurable: true, get: () => (listD = listD || recordsToPhotons(recD(), false)) });
+    Object.defineProperty(this, 'photonListCaustic', { configurable: true, get: () => (listC = listC || recordsToPhotons(recC(), true)) });
     if (res.stats.capped) {
       console.log(`I tried many times but only created ${res.stats.nDiffuse} diffuse / ${res.stats.nCaustic} caustic photons.`);
-      if (res.stats.nDiffuse < this.params.numPhotonsDiffuse) { this._recD = res.diffuse; this._recC = res.caustic; return; }
+      if (res.stats.nDiffuse < this.params.numPhotonsDiffuse) return;         // rayphoton.js:1365-1368: no trees
     }
-    this._recD = res.diffuse; this._recC = res.caustic;
-    this.photonKdTDiffuse = new KdTree(res.diffuse);
-    if (!res.stats.capped) this.photonKdTCaustic = new KdTree(res.caustic);
-    let listD = null, listC = null;     // photon object lists are materialised only if somebody looks
-    Object.defineProperty(this, 'photonListDiffuse', { configurable: true, get: () => (listD = listD || recordsToPhotons(res.diffuse, false)) });
-    Object.defineProperty(this, 'photonListCaustic', { configurable: true, get: () => (listC = listC || recordsToPhotons(res.caustic, true)) });
+    this.photonKdTDiffuse = new KdTree({ lists: res.lists, which: 0, n: res.stats.nDiffuse });
+    if (!res.stats.capped) this.photonKdTCaustic = new KdTree({ lists: res.lists, which: 1, n: res.stats.nCaustic });
   }
 
   // pixels [x0,x0+w) x [y0,y0+h): {pre, post: Float64Array(w*h*4), rgba8: Uint8Array, stats}
   render(x0, y0, w, h, overrides) {
-    const md = this.photonKdTDiffuse instanceof KdTree ? this.photonKdTDiffuse.map : null;
-    const mc = this.photonKdTCaustic instanceof KdTree ? this.photonKdTCaustic.map : null;
+    const [md, mc] = this._maps();
     return addon().traceTile(this._scene(), Object.assign({}, this.params, overrides || {}), md, mc, x0, y0, w, h);
   }
+  // The same tile, only QUEUED on the GPU: out = {rgba8, pre, post}, DeviceBuffers (any subset; 4 bytes a pixel for rgba8,
+  // 32 for pre / post).  Returns at once; the pixels are there after Scene.synchronize() or a read() of the buffer.
+  // Frames queued one after the other run back to back without the host in between, and after
+  // Scene.setFramesInFlight(n) up to n of them overlap (give those separate buffers).
+  renderQueued(x0, y0, w, h, out, overrides) {
+    const [md, mc] = this._maps();
+    const dev = {};
+    for (const k of ['pre', 'post', 'rgba8']) if (out[k]) dev[k] = out[k].handle || out[k];
+    addon().traceTile(this._scene(), Object.assign({}, this.params, overrides || {}), md, mc, x0, y0, w, h, dev);
+  }
+  // n frames of the whole canvas, queued with up to inFlight of them overlapping -> [Uint8Array(w*h*4)] (rgba8).
+  // perFrame(i) may return parameter overrides for frame i (a seed per frame, say).
+  renderFrames(n, perFrame, inFlight) {
+    const w = this.canvasWidth, h = this.canvasHeight, ctx = context();
+    const bufs = [];
+    for (let i = 0; i < n; i++) bufs.push(new DeviceBuffer(w * h * 4, ctx));
+    addon().setFramesInFlight(ctx, Math.max(1, Math.min(inFlight || 3, n, 8)));
+    try {
+      for (let i = 0; i < n; i++) this.renderQueued(0, 0, w, h, { rgba8: bufs[i] }, perFrame ? perFrame(i) : undefined);
+      addon().synchronize(ctx);
+      return bufs.map((b) => b.read(new Uint8Array(w * h * 4)));
+    } finally {
+      addon().setFramesInFlight(ctx, 1);
+      bufs.forEach((b) => b.free());
+    }
+  }
+  static setFramesInFlight(n) { addon().setFramesInFlight(context(), n); }
+  static synchronize() { addon().synchronize(context()); }
 
   // ---- the reference's single-item methods: batches of one on the GPU entry points that take explicit items.
   // The reference draws from Math.random(); here every call names a keyed stream and a position in it: `stream` is
@@ -441,5 +501,5 @@ function writePPM(file, rgba8, width, height) {
   fs.writeFileSync(file, Buffer.concat([head, body]));
 }
 
-module.exports = Object.assign({}, S, { Whitted: W, Scene, FlatFileScene, WhittedScene, Ray, Photon, KdTree, PRECISION, DEFAULTS, WHITTED_DEFAULTS,
+module.exports = Object.assign({}, S, { Whitted: W, Scene, FlatFileScene, WhittedScene, Ray, Photon, KdTree, DeviceBuffer, PRECISION, SHARD, DEFAULTS, WHITTED_DEFAULTS,
   context, addon, photonsToRecords, recordsToPhotons, writePPM });

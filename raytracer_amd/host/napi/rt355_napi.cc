@@ -22,6 +22,7 @@ static napi_value fail(napi_env env, rt_ctx *ctx, int code) {
 struct Args {
   napi_env env; size_t argc; napi_value argv[16];
   Args(napi_env e, napi_callback_info info) : env(e), argc(16) { napi_get_cb_info(e, info, &argc, argv, nullptr, nullptr); }
+  Args(napi_env e, napi_value one) : env(e), argc(1) { argv[0] = one; }          // a single value, for the checks below
   bool has(size_t i) const {
     if (i >= argc) return false;
     napi_valuetype t; napi_typeof(env, argv[i], &t);
@@ -93,6 +94,9 @@ static void read_params(napi_env env, napi_value o, rt_params *p) {
   p->epsilon_f32 = prop_num(env, o, "epsilonF32", p->epsilon_f32);
   p->max_bounces = (int32_t)prop_num(env, o, "maxBounces", p->max_bounces);
   p->super_sample_block = (int32_t)prop_num(env, o, "superSampleBlock", p->super_sample_block);
+  p->band_rows = (int32_t)prop_num(env, o, "bandRows", p->band_rows);           // one rank's share of a tile (multi-GPU)
+  p->band_count = (int32_t)prop_num(env, o, "bandCount", p->band_count);
+  p->band_index = (int32_t)prop_num(env, o, "bandIndex", p->band_index);
 }
 
 static void set_num(napi_env env, napi_value obj, const char *name, double v) { napi_value n; napi_create_double(env, v, &n); napi_set_named_property(env, obj, name, n); }
@@ -100,9 +104,9 @@ static void set_num(napi_env env, napi_value obj, const char *name, double v) { 
 // Handles.  Scenes and maps point into their context, and the collector orders nothing: a scene may be finalised long
 // after shutdown(ctx).  So the context's box is shared: it knows its live scenes and maps, shutdown() frees them first
 // and marks them dead, and the box itself lives until the last handle that refers to it has been finalised.
-struct SceneBox; struct MapBox;
+struct SceneBox; struct MapBox; struct ListsBox; struct DevBox;
 struct CtxBox {
-  uint64_t tag; rt_ctx *ctx; int refs; std::set<SceneBox *> scenes; std::set<MapBox *> maps;
+  uint64_t tag; rt_ctx *ctx; int refs; std::set<SceneBox *> scenes; std::set<MapBox *> maps; std::set<ListsBox *> lists; std::set<DevBox *> bufs;
   static constexpr uint64_t TAG = 0x7274333535637478ull;
   static const char *what() { return "rt355: a context handle (from init) is expected"; }
   bool live() const { return ctx != nullptr; }
@@ -112,22 +116,50 @@ struct SceneBox {
   static constexpr uint64_t TAG = 0x7274333535736365ull;
   static const char *what() { return "rt355: a scene handle (from sceneUpload) is expected"; }
   bool live() const { return scene != nullptr; }
+  void drop() { if (scene) { rt_scene_free(scene); scene = nullptr; cb->scenes.erase(this); } }
 };
 struct MapBox {
   uint64_t tag; CtxBox *cb; rt_photon_map *map;
   static constexpr uint64_t TAG = 0x72743335356d6170ull;
   static const char *what() { return "rt355: a photon map handle (from photonMapBuild) is expected"; }
   bool live() const { return map != nullptr; }
+  void drop() { if (map) { rt_photon_map_free(map); map = nullptr; cb->maps.erase(this); } }
+};
+// photon lists that stay in GPU memory (emitManyLists, listsCreate)
+struct ListsBox {
+  uint64_t tag; CtxBox *cb; rt_photon_lists *lists;
+  static constexpr uint64_t TAG = 0x72743335356c7374ull;
+  static const char *what() { return "rt355: a photon lists handle (from emitManyLists or listsCreate) is expected"; }
+  bool live() const { return lists != nullptr; }
+  void drop() { if (lists) { rt_lists_free(lists); lists = nullptr; cb->lists.erase(this); } }
+};
+// plain device memory (deviceAlloc): where queued frames, shards and gather inputs live on the Node side
+struct DevBox {
+  uint64_t tag; CtxBox *cb; void *ptr; size_t bytes;
+  static constexpr uint64_t TAG = 0x7274333535627566ull;
+  static const char *what() { return "rt355: a device buffer handle (from deviceAlloc) is expected"; }
+  bool live() const { return ptr != nullptr; }
+  void drop() { if (ptr) { rt_device_free(cb->ctx, ptr); ptr = nullptr; cb->bufs.erase(this); } }
 };
 static void ctx_close(CtxBox *cb) {                          // frees everything made from the context, then the context
   if (!cb->ctx) return;
-  for (SceneBox *b : cb->scenes) { rt_scene_free(b->scene); b->scene = nullptr; }
-  for (MapBox *b : cb->maps) { rt_photon_map_free(b->map); b->map = nullptr; }
-  cb->scenes.clear(); cb->maps.clear();
+  while (!cb->scenes.empty()) (*cb->scenes.begin())->drop();
+  while (!cb->maps.empty()) (*cb->maps.begin())->drop();
+  while (!cb->lists.empty()) (*cb->lists.begin())->drop();
+  while (!cb->bufs.empty()) (*cb->bufs.begin())->drop();
   rt_shutdown(cb->ctx);
   cb->ctx = nullptr;
 }
 static void ctx_release(CtxBox *cb) { if (--cb->refs == 0) { ctx_close(cb); cb->tag = 0; delete cb; } }
+// a box that is already in its context's set -> the JS handle that owns it
+template <typename B> static napi_value make_handle(napi_env env, B *box) {
+  box->cb->refs++;
+  napi_value out;
+  auto fin = [](napi_env, void *p, void *) { B *b = (B *)p; CtxBox *cb = b->cb; b->drop(); b->tag = 0; delete b; ctx_release(cb); };
+  if (napi_create_external(env, box, fin, nullptr, &out) != napi_ok) { fin(env, box, nullptr); napi_throw_error(env, nullptr, "N-API call failed: napi_create_external"); return nullptr; }
+  return out;
+}
+static bool pending(napi_env env) { bool p = false; napi_is_exception_pending(env, &p); return p; }
 
 // init([deviceId]) -> ctx
 static napi_value Init(napi_env env, napi_callback_info info) {
@@ -193,15 +225,8 @@ static napi_value SceneUpload(napi_env env, napi_callback_info info) {
   int rc = rt_scene_upload(ctx, &d, &sc);
   if (rc != RT_OK) return fail(env, ctx, rc);
   SceneBox *box = new SceneBox{ SceneBox::TAG, cb, sc };
-  cb->scenes.insert(box); cb->refs++;
-  napi_value out;
-  auto fin = [](napi_env, void *p, void *) {
-    SceneBox *b = (SceneBox *)p;
-    if (b->scene) { rt_scene_free(b->scene); b->cb->scenes.erase(b); }
-    ctx_release(b->cb); b->tag = 0; delete b;
-  };
-  if (napi_create_external(env, box, fin, nullptr, &out) != napi_ok) { fin(env, box, nullptr); napi_throw_error(env, nullptr, "N-API call failed: napi_create_external"); return nullptr; }
-  return out;
+  cb->scenes.insert(box);
+  return make_handle(env, box);
 }
 
 // intersectPairs(ctx, params, rayO, rayD, normalizeDir, shapeMeta, shapeGeom) -> Float64Array t (NaN = undefined)
@@ -276,6 +301,12 @@ static napi_value EmitMany(napi_env env, napi_callback_info info) {
   return out;
 }
 
+static napi_value map_handle(napi_env env, CtxBox *cb, rt_photon_map *m) {
+  MapBox *box = new MapBox{ MapBox::TAG, cb, m };
+  cb->maps.insert(box);
+  return make_handle(env, box);
+}
+
 // photonMapBuild(ctx, rec Float64Array(n*11)) -> map
 static napi_value PhotonMapBuild(napi_env env, napi_callback_info info) {
   Args a(env, info);
@@ -288,16 +319,7 @@ static napi_value PhotonMapBuild(napi_env env, napi_callback_info info) {
   rt_photon_map *m = nullptr;
   int rc = rt_photon_map_build(ctx, rec, (uint32_t)(n / 11), &m);
   if (rc != RT_OK) return fail(env, ctx, rc);
-  MapBox *box = new MapBox{ MapBox::TAG, cb, m };
-  cb->maps.insert(box); cb->refs++;
-  napi_value out;
-  auto fin = [](napi_env, void *p, void *) {
-    MapBox *b = (MapBox *)p;
-    if (b->map) { rt_photon_map_free(b->map); b->cb->maps.erase(b); }
-    ctx_release(b->cb); b->tag = 0; delete b;
-  };
-  if (napi_create_external(env, box, fin, nullptr, &out) != napi_ok) { fin(env, box, nullptr); napi_throw_error(env, nullptr, "N-API call failed: napi_create_external"); return nullptr; }
-  return out;
+  return map_handle(env, cb, m);
 }
 
 // photonMapNodes(map) -> {perm: Int32Array, dim: Uint8Array}
@@ -410,25 +432,53 @@ static napi_value GatherRadianceAdaptive(napi_env env, napi_callback_info info) 
 }
 
 // traceTile(scene, params, diffuseMap|null, causticMap|null, x0, y0, w, h) -> {pre, post: Float64Array(w*h*4), rgba8: Uint8Array, stats}
+// traceTile(scene, params, diffuseMap|null, causticMap|null, x0, y0, w, h, {pre, post, rgba8: device buffers or absent}) -> undefined:
+//   the frame is only QUEUED (rt_trace_tile without stats into device memory); its pixels are complete after synchronize(ctx)
+//   or a deviceRead of the buffer, and up to setFramesInFlight(ctx, n) such frames overlap on the GPU
 static napi_value TraceTile(napi_env env, napi_callback_info info) {
   Args a(env, info);
   SceneBox *sb = a.ext<SceneBox>(0);
   if (!sb) return nullptr;
   rt_params p; read_params(env, a.argv[1], &p);
   MapBox *md = a.ext<MapBox>(2), *mc = a.ext<MapBox>(3);
-  { bool pending = false; napi_is_exception_pending(env, &pending); if (pending) return nullptr; }
+  if (pending(env)) return nullptr;
   if ((md && md->cb != sb->cb) || (mc && mc->cb != sb->cb)) { napi_throw_error(env, nullptr, "traceTile: the maps belong to another context"); return nullptr; }
   int x0 = (int)a.num(4), y0 = (int)a.num(5), w = (int)a.num(6), h = (int)a.num(7);
   if (w <= 0 || h <= 0) { napi_throw_range_error(env, nullptr, "traceTile: empty tile"); return nullptr; }
   const int blk = p.super_sample_block > 1 ? p.super_sample_block : 1;
-  size_t npx = (size_t)((w + blk - 1) / blk) * (size_t)((h + blk - 1) / blk);      // one value per block
+  const size_t rows = p.band_count > 1 ? rt_band_rows((uint32_t)h, p.band_rows, p.band_count, p.band_index) : (size_t)h;   // (a rank's share of the tile)
+  size_t npx = (size_t)((w + blk - 1) / blk) * (size_t)((rows + blk - 1) / blk);      // one value per block
+  if (a.has(8)) {
+    void *dev[3] = { nullptr, nullptr, nullptr };
+    const char *names[3] = { "pre", "post", "rgba8" };
+    const size_t need[3] = { npx * 32, npx * 32, npx * 4 };
+    for (int i = 0; i < 3; i++) {
+      bool has = false; napi_has_named_property(env, a.argv[8], names[i], &has);
+      if (!has) continue;
+      napi_value v = get_prop(env, a.argv[8], names[i]); napi_valuetype t; napi_typeof(env, v, &t);
+      if (t == napi_undefined || t == napi_null) continue;
+      Args one(env, v);
+      DevBox *b = one.ext<DevBox>(0);
+      if (!b) return nullptr;
+      if (b->cb != sb->cb) { napi_throw_error(env, nullptr, "traceTile: an output buffer belongs to another context"); return nullptr; }
+      if (b->bytes < need[i]) { napi_throw_range_error(env, nullptr, "traceTile: an output buffer is smaller than the tile (32 bytes per pixel for pre / post, 4 for rgba8)"); return nullptr; }
+      dev[i] = b->ptr;
+    }
+    if (!dev[0] && !dev[1] && !dev[2]) { napi_throw_type_error(env, nullptr, "traceTile: the output object names no device buffer (pre, post, rgba8)"); return nullptr; }
+    if (npx == 0) return nullptr;
+    int rc = rt_trace_tile(sb->scene, &p, md ? md->map : nullptr, mc ? mc->map : nullptr, x0, y0, w, h, (double *)dev[0], (double *)dev[1], (uint8_t *)dev[2], nullptr);
+    if (rc != RT_OK) return fail(env, sb->cb->ctx, rc);
+    return nullptr;
+  }
   napi_value ab1, ab2, ab3, pre, post, r8, out, stats; void *d1, *d2, *d3;
   NAPI_OK(napi_create_arraybuffer(env, npx * 32, &d1, &ab1)); NAPI_OK(napi_create_typedarray(env, napi_float64_array, npx * 4, ab1, 0, &pre));
   NAPI_OK(napi_create_arraybuffer(env, npx * 32, &d2, &ab2)); NAPI_OK(napi_create_typedarray(env, napi_float64_array, npx * 4, ab2, 0, &post));
   NAPI_OK(napi_create_arraybuffer(env, npx * 4, &d3, &ab3)); NAPI_OK(napi_create_typedarray(env, napi_uint8_array, npx * 4, ab3, 0, &r8));
-  rt_trace_stats st;
-  int rc = rt_trace_tile(sb->scene, &p, md ? md->map : nullptr, mc ? mc->map : nullptr, x0, y0, w, h, (double *)d1, (double *)d2, (uint8_t *)d3, &st);
-  if (rc != RT_OK) return fail(env, sb->cb->ctx, rc);
+  rt_trace_stats st; memset(&st, 0, sizeof st);
+  if (npx) {
+    int rc = rt_trace_tile(sb->scene, &p, md ? md->map : nullptr, mc ? mc->map : nullptr, x0, y0, w, h, (double *)d1, (double *)d2, (uint8_t *)d3, &st);
+    if (rc != RT_OK) return fail(env, sb->cb->ctx, rc);
+  }
   NAPI_OK(napi_create_object(env, &out)); NAPI_OK(napi_create_object(env, &stats));
   napi_set_named_property(env, out, "pre", pre); napi_set_named_property(env, out, "post", post); napi_set_named_property(env, out, "rgba8", r8);
   set_num(env, stats, "rays", (double)st.rays); set_num(env, stats, "shadowRays", (double)st.shadow_rays);
@@ -557,6 +607,374 @@ static napi_value WalkPhotons(napi_env env, napi_callback_info info) {
   return out;
 }
 
+
+// ---- the throughput path: device buffers, photon lists that stay in GPU memory, queued frames, shards ----
+
+static size_t elem_size(napi_typedarray_type t) {
+  switch (t) {
+    case napi_int8_array: case napi_uint8_array: case napi_uint8_clamped_array: return 1;
+    case napi_int16_array: case napi_uint16_array: return 2;
+    case napi_int32_array: case napi_uint32_array: case napi_float32_array: return 4;
+    default: return 8;
+  }
+}
+// argument i as memory: a typed array of element type `want` (host memory, borrowed for the call; it may sit on a
+// SharedArrayBuffer) or a device buffer of context cb -> pointer and size in bytes; throws and returns nullptr otherwise
+static void *mem_arg(const Args &a, size_t i, napi_typedarray_type want, CtxBox *cb, size_t *bytes, const char *who) {
+  *bytes = 0;
+  if (!a.has(i)) { napi_throw_type_error(a.env, nullptr, (std::string(who) + ": a typed array or a device buffer is expected").c_str()); return nullptr; }
+  napi_valuetype t; napi_typeof(a.env, a.argv[i], &t);
+  if (t == napi_external) {
+    DevBox *b = a.ext<DevBox>(i);
+    if (!b) return nullptr;
+    if (cb && b->cb != cb) { napi_throw_error(a.env, nullptr, (std::string(who) + ": the device buffer belongs to another context").c_str()); return nullptr; }
+    *bytes = b->bytes;
+    return b->ptr;
+  }
+  size_t n = 0;
+  void *p = a.typed(i, want, &n);
+  if (!p && !pending(a.env)) napi_throw_range_error(a.env, nullptr, (std::string(who) + ": empty array").c_str());
+  *bytes = n * elem_size(want);
+  return p;
+}
+
+// deviceAlloc(ctx, bytes) -> buffer
+static napi_value DeviceAlloc(napi_env env, napi_callback_info info) {
+  Args a(env, info);
+  CtxBox *cb = a.ext<CtxBox>(0);
+  if (!cb) return nullptr;
+  const double bytes = a.num(1, 0);
+  if (!(bytes >= 1) || bytes > 9.0e15) { napi_throw_range_error(env, nullptr, "deviceAlloc(ctx, bytes): bytes must be positive"); return nullptr; }
+  void *ptr = nullptr;
+  int rc = rt_device_alloc(cb->ctx, (uint64_t)bytes, &ptr);
+  if (rc != RT_OK) return fail(env, cb->ctx, rc);
+  DevBox *box = new DevBox{ DevBox::TAG, cb, ptr, (size_t)bytes };
+  cb->bufs.insert(box);
+  return make_handle(env, box);
+}
+// deviceFree(buffer): now rather than when the collector gets to it
+static napi_value DeviceFree(napi_env env, napi_callback_info info) {
+  Args a(env, info);
+  DevBox *b = a.ext<DevBox>(0);
+  if (b) b->drop();
+  return nullptr;
+}
+static napi_value DeviceBytes(napi_env env, napi_callback_info info) {
+  Args a(env, info);
+  DevBox *b = a.ext<DevBox>(0);
+  if (!b) return nullptr;
+  napi_value out; napi_create_double(env, (double)b->bytes, &out);
+  return out;
+}
+// deviceRead(buffer, out typed array[, byteOffset]) -> out;  deviceWrite(buffer, src typed array[, byteOffset])
+// Both wait for everything the context has queued (a queued frame can be read straight after queueing it).
+static napi_value device_io(napi_env env, napi_callback_info info, bool read) {
+  Args a(env, info);
+  DevBox *b = a.ext<DevBox>(0);
+  if (!b) return nullptr;
+  bool is = false;
+  if (a.has(1)) napi_is_typedarray(env, a.argv[1], &is);
+  if (!is) { napi_throw_type_error(env, nullptr, read ? "deviceRead(buffer, out, byteOffset)" : "deviceWrite(buffer, src, byteOffset)"); return nullptr; }
+  napi_typedarray_type t; size_t n; void *data; napi_value ab; size_t off;
+  napi_get_typedarray_info(env, a.argv[1], &t, &n, &data, &ab, &off);
+  const size_t bytes = n * elem_size(t);
+  const double at = a.num(2, 0);
+  if (at < 0 || at + (double)bytes > (double)b->bytes) { napi_throw_range_error(env, nullptr, "device buffer access out of range"); return nullptr; }
+  char *dev = (char *)b->ptr + (size_t)at;
+  int rc = read ? rt_device_copy(b->cb->ctx, data, dev, bytes) : rt_device_copy(b->cb->ctx, dev, data, bytes);
+  if (rc != RT_OK) return fail(env, b->cb->ctx, rc);
+  return read ? a.argv[1] : nullptr;
+}
+static napi_value DeviceRead(napi_env env, napi_callback_info info) { return device_io(env, info, true); }
+static napi_value DeviceWrite(napi_env env, napi_callback_info info) { return device_io(env, info, false); }
+
+// setOption(ctx, name, value) / setFramesInFlight(ctx, n) / join(ctx) / synchronize(ctx) / stream(ctx) -> BigInt (the hipStream_t)
+static napi_value SetOption(napi_env env, napi_callback_info info) {
+  Args a(env, info);
+  CtxBox *cb = a.ext<CtxBox>(0);
+  if (!cb) return nullptr;
+  char name[64]; size_t len = 0;
+  if (!a.has(1) || napi_get_value_string_utf8(env, a.argv[1], name, sizeof name, &len) != napi_ok) { napi_throw_type_error(env, nullptr, "setOption(ctx, name, value)"); return nullptr; }
+  int rc = rt_set_option(cb->ctx, name, a.num(2, 0));
+  if (rc != RT_OK) return fail(env, cb->ctx, rc);
+  return nullptr;
+}
+static napi_value SetFramesInFlight(napi_env env, napi_callback_info info) {
+  Args a(env, info);
+  CtxBox *cb = a.ext<CtxBox>(0);
+  if (!cb) return nullptr;
+  int rc = rt_set_frames_in_flight(cb->ctx, (int)a.num(1, 1));
+  if (rc != RT_OK) return fail(env, cb->ctx, rc);
+  return nullptr;
+}
+static napi_value Join(napi_env env, napi_callback_info info) {
+  Args a(env, info);
+  CtxBox *cb = a.ext<CtxBox>(0);
+  if (!cb) return nullptr;
+  int rc = rt_join(cb->ctx);
+  if (rc != RT_OK) return fail(env, cb->ctx, rc);
+  return nullptr;
+}
+static napi_value Synchronize(napi_env env, napi_callback_info info) {
+  Args a(env, info);
+  CtxBox *cb = a.ext<CtxBox>(0);
+  if (!cb) return nullptr;
+  int rc = rt_synchronize(cb->ctx);
+  if (rc != RT_OK) return fail(env, cb->ctx, rc);
+  return nullptr;
+}
+static napi_value Stream(napi_env env, napi_callback_info info) {
+  Args a(env, info);
+  CtxBox *cb = a.ext<CtxBox>(0);
+  if (!cb) return nullptr;
+  napi_value out; NAPI_OK(napi_create_bigint_uint64(env, (uint64_t)(uintptr_t)rt_stream(cb->ctx), &out));
+  return out;
+}
+// bandRows(height, bandRows, bandCount, bandIndex) -> rows of a tile that one rank's interleaved bands hold
+static napi_value BandRows(napi_env env, napi_callback_info info) {
+  Args a(env, info);
+  napi_value out; napi_create_uint32(env, rt_band_rows((uint32_t)a.num(0, 0), (int)a.num(1, 0), (int)a.num(2, 0), (int)a.num(3, 0)), &out);
+  return out;
+}
+
+static napi_value emit_stats_object(napi_env env, const rt_emit_stats &st) {
+  napi_value stats; napi_create_object(env, &stats);
+  set_num(env, stats, "attemptsPhase1", (double)st.attempts_phase1); set_num(env, stats, "attemptsPhase2", (double)st.attempts_phase2);
+  set_num(env, stats, "segments", (double)st.segments); set_num(env, stats, "nDiffuse", st.n_diffuse); set_num(env, stats, "nCaustic", st.n_caustic);
+  set_num(env, stats, "capped", st.capped); set_num(env, stats, "errors", st.errors);
+  return stats;
+}
+static napi_value lists_handle(napi_env env, CtxBox *cb, rt_photon_lists *L) {
+  ListsBox *box = new ListsBox{ ListsBox::TAG, cb, L };
+  cb->lists.insert(box);
+  return make_handle(env, box);
+}
+
+// emitManyLists(scene, params, format) -> {lists, stats}: emitManyPhotons with both lists left in GPU memory
+// (format 0: full records in the working precision, 1: the 36-byte photons of the map)
+static napi_value EmitManyLists(napi_env env, napi_callback_info info) {
+  Args a(env, info);
+  SceneBox *sb = a.ext<SceneBox>(0);
+  if (!sb) return nullptr;
+  rt_params p; read_params(env, a.argv[1], &p);
+  rt_photon_lists *L = nullptr; rt_emit_stats st; memset(&st, 0, sizeof st);
+  int rc = rt_emit_many_lists(sb->scene, &p, (int)a.num(2, RT_SHARD_FULL), &L, &st);
+  if (rc != RT_OK && !(rc == RT_ERR_ATTEMPT_CAP && L)) { if (L) rt_lists_free(L); return fail(env, sb->cb->ctx, rc); }   // the cap only logs in the reference (rayphoton.js:1366)
+  napi_value out, lists = lists_handle(env, sb->cb, L);
+  if (!lists) return nullptr;
+  NAPI_OK(napi_create_object(env, &out));
+  napi_set_named_property(env, out, "lists", lists); napi_set_named_property(env, out, "stats", emit_stats_object(env, st));
+  return out;
+}
+// listsCreate(ctx, params, format) -> lists (empty, with the caps numPhotonsDiffuse / numPhotonsCaustic)
+static napi_value ListsCreate(napi_env env, napi_callback_info info) {
+  Args a(env, info);
+  CtxBox *cb = a.ext<CtxBox>(0);
+  if (!cb) return nullptr;
+  rt_params p; read_params(env, a.argv[1], &p);
+  rt_photon_lists *L = nullptr;
+  int rc = rt_lists_create(cb->ctx, &p, (int)a.num(2, RT_SHARD_FULL), &L);
+  if (rc != RT_OK) return fail(env, cb->ctx, rc);
+  return lists_handle(env, cb, L);
+}
+// listsFree(lists): now rather than at collection
+static napi_value ListsFree(napi_env env, napi_callback_info info) {
+  Args a(env, info);
+  ListsBox *lb = a.ext<ListsBox>(0);
+  if (lb) lb->drop();
+  return nullptr;
+}
+static napi_value ListsRecordWords(napi_env env, napi_callback_info info) {
+  Args a(env, info);
+  ListsBox *lb = a.ext<ListsBox>(0);
+  if (!lb) return nullptr;
+  napi_value out; napi_create_uint32(env, rt_lists_record_words(lb->lists), &out);
+  return out;
+}
+// listsCounts(lists) -> {nDiffuse, nCaustic}
+static napi_value ListsCounts(napi_env env, napi_callback_info info) {
+  Args a(env, info);
+  ListsBox *lb = a.ext<ListsBox>(0);
+  if (!lb) return nullptr;
+  uint32_t nd = 0, nc = 0;
+  int rc = rt_lists_counts(lb->lists, &nd, &nc);
+  if (rc != RT_OK) return fail(env, lb->cb->ctx, rc);
+  napi_value out; NAPI_OK(napi_create_object(env, &out));
+  set_num(env, out, "nDiffuse", nd); set_num(env, out, "nCaustic", nc);
+  return out;
+}
+// listsExport(lists, which) -> {records: Float64Array(n*11), attempts: Float64Array(n*2) (phase, attempt)}; full-format lists
+static napi_value ListsExport(napi_env env, napi_callback_info info) {
+  Args a(env, info);
+  ListsBox *lb = a.ext<ListsBox>(0);
+  if (!lb) return nullptr;
+  const int which = (int)a.num(1, 0);
+  uint32_t n = 0, words = 0;
+  if (rt_lists_view(lb->lists, which, nullptr, &n, &words, nullptr) != RT_OK) { napi_throw_range_error(env, nullptr, "listsExport(lists, which): which is 0 (diffuse) or 1 (caustic)"); return nullptr; }
+  void *rd, *ad; napi_value rec = make_typed(env, napi_float64_array, (size_t)n * 11, 8, &rd), att = make_typed(env, napi_float64_array, (size_t)n * 2, 8, &ad), out;
+  if (!rec || !att) { napi_throw_error(env, nullptr, "N-API call failed: typed array"); return nullptr; }
+  std::vector<int64_t> tmp((size_t)n * 2);
+  int rc = rt_lists_export(lb->lists, which, (double *)rd, tmp.data());
+  if (rc != RT_OK) return fail(env, lb->cb->ctx, rc);
+  for (size_t i = 0; i < tmp.size(); i++) ((double *)ad)[i] = (double)tmp[i];
+  NAPI_OK(napi_create_object(env, &out));
+  napi_set_named_property(env, out, "records", rec); napi_set_named_property(env, out, "attempts", att);
+  return out;
+}
+// listsRecords(lists, which) -> {n, words, precision, records: Float32Array(n*words) | Float64Array(n*words/2)}: the list's records as
+// they lie in GPU memory (rt_lists_view), copied out
+static napi_value ListsRecords(napi_env env, napi_callback_info info) {
+  Args a(env, info);
+  ListsBox *lb = a.ext<ListsBox>(0);
+  if (!lb) return nullptr;
+  const void *dev = nullptr; uint32_t n = 0, words = 0; int prec = 0;
+  if (rt_lists_view(lb->lists, (int)a.num(1, 0), &dev, &n, &words, &prec) != RT_OK) { napi_throw_range_error(env, nullptr, "listsRecords(lists, which): which is 0 (diffuse) or 1 (caustic)"); return nullptr; }
+  const bool f64 = prec == RT_PRECISION_F64 && words == 22;
+  void *data; napi_value rec = f64 ? make_typed(env, napi_float64_array, (size_t)n * 11, 8, &data) : make_typed(env, napi_float32_array, (size_t)n * words, 4, &data), out;
+  if (!rec) { napi_throw_error(env, nullptr, "N-API call failed: typed array"); return nullptr; }
+  int rc = rt_device_copy(lb->cb->ctx, data, dev, (uint64_t)n * words * 4);
+  if (rc != RT_OK) return fail(env, lb->cb->ctx, rc);
+  NAPI_OK(napi_create_object(env, &out));
+  set_num(env, out, "n", n); set_num(env, out, "words", words); set_num(env, out, "precision", prec);
+  napi_set_named_property(env, out, "records", rec);
+  return out;
+}
+// emitShard(scene, params, phase, attemptBegin, attemptEnd, format, tagBase, out Uint32Array | device buffer) -> {n, words, stats}
+// One rank's share of a batch of emission attempts: the stored photons of [attemptBegin, attemptEnd), in attempt order, as
+// records of words + 1 uint32 in `out` (room for attemptEnd - attemptBegin records always suffices).
+static napi_value EmitShard(napi_env env, napi_callback_info info) {
+  Args a(env, info);
+  SceneBox *sb = a.ext<SceneBox>(0);
+  if (!sb) return nullptr;
+  rt_params p; read_params(env, a.argv[1], &p);
+  const int phase = (int)a.num(2, 1), format = (int)a.num(5, RT_SHARD_PACKED);
+  const double b0 = a.num(3, 0), b1 = a.num(4, 0), tb = a.num(6, 0);
+  if (!(b0 >= 0) || !(b1 >= b0) || !(tb >= 0) || b1 > 9.0e15) { napi_throw_range_error(env, nullptr, "emitShard: bad attempt range"); return nullptr; }
+  const uint32_t W = format == RT_SHARD_PACKED ? 9u : (p.precision == RT_PRECISION_F64 ? 22u : 11u);
+  size_t bytes = 0;
+  uint32_t *out = (uint32_t *)mem_arg(a, 7, napi_uint32_array, sb->cb, &bytes, "emitShard");
+  if (!out) return nullptr;
+  const size_t cap = bytes / ((size_t)(W + 1) * 4);
+  if (cap == 0 || cap > 0x7FFFFFFFu) { napi_throw_range_error(env, nullptr, "emitShard: the output holds no record (or more than 2^31)"); return nullptr; }
+  uint32_t n = 0; rt_emit_stats st; memset(&st, 0, sizeof st);
+  int rc = rt_emit_shard(sb->scene, &p, phase, (uint64_t)b0, (uint64_t)b1, format, (uint64_t)tb, (uint32_t)cap, out, &n, &st);
+  if (rc != RT_OK) return fail(env, sb->cb->ctx, rc);
+  napi_value res; NAPI_OK(napi_create_object(env, &res));
+  set_num(env, res, "n", n); set_num(env, res, "words", W);
+  napi_set_named_property(env, res, "stats", emit_stats_object(env, st));
+  return res;
+}
+// listsApply(lists, phase, tagBase, shards Uint32Array | device buffer, counts Uint32Array(nShards), stride) -> info
+// One merged batch: shard s starts at record s * stride of `shards` and holds counts[s] records, shards in attempt order.
+static napi_value ListsApply(napi_env env, napi_callback_info info) {
+  Args a(env, info);
+  ListsBox *lb = a.ext<ListsBox>(0);
+  if (!lb) return nullptr;
+  const double tb = a.num(2, 0), stride = a.num(5, 0);
+  size_t bytes = 0, nc = 0;
+  const uint32_t *shards = (const uint32_t *)mem_arg(a, 3, napi_uint32_array, lb->cb, &bytes, "listsApply");
+  if (!shards) return nullptr;
+  const uint32_t *counts = (const uint32_t *)a.typed(4, napi_uint32_array, &nc);
+  const uint32_t W = rt_lists_record_words(lb->lists);
+  if (!counts || nc == 0 || !(stride >= 1) || !(tb >= 0) || stride > 2147483647.0) { napi_throw_range_error(env, nullptr, "listsApply(lists, phase, tagBase, shards, counts, stride)"); return nullptr; }
+  if ((double)nc * stride * (W + 1) * 4 > (double)bytes) { napi_throw_range_error(env, nullptr, "listsApply: shards holds fewer than counts.length * stride records"); return nullptr; }
+  for (size_t i = 0; i < nc; i++) if (counts[i] > (uint32_t)stride) { napi_throw_range_error(env, nullptr, "listsApply: a count exceeds the stride"); return nullptr; }
+  rt_lists_info li; memset(&li, 0, sizeof li);
+  int rc = rt_lists_apply(lb->lists, (int)a.num(1, 1), (uint64_t)tb, shards, counts, (uint32_t)nc, (uint32_t)stride, &li);
+  if (rc != RT_OK) return fail(env, lb->cb->ctx, rc);
+  napi_value out; NAPI_OK(napi_create_object(env, &out));
+  set_num(env, out, "nDiffuse", li.n_diffuse); set_num(env, out, "nCaustic", li.n_caustic);
+  set_num(env, out, "batchDiffuse", li.batch_diffuse); set_num(env, out, "batchCaustic", li.batch_caustic);
+  set_num(env, out, "takenDiffuse", li.taken_diffuse); set_num(env, out, "takenCaustic", li.taken_caustic);
+  set_num(env, out, "phaseEnded", li.phase_ended); set_num(env, out, "lastAttempt", (double)li.last_attempt);
+  return out;
+}
+// emitPhotons(scene, params, phase, attemptBegin, attemptEnd) -> {records: Float64Array(n*11), attempts: Float64Array(n), kind: Uint8Array(n), stats}
+// every stored photon of the attempt range, no caps (kind 1 diffuse, 2 caustic)
+static napi_value EmitPhotons(napi_env env, napi_callback_info info) {
+  Args a(env, info);
+  SceneBox *sb = a.ext<SceneBox>(0);
+  if (!sb) return nullptr;
+  rt_params p; read_params(env, a.argv[1], &p);
+  const double b0 = a.num(3, 0), b1 = a.num(4, 0);
+  if (!(b0 >= 0) || !(b1 >= b0) || b1 - b0 > 16777216.0) { napi_throw_range_error(env, nullptr, "emitPhotons: the range must hold at most 2^24 attempts"); return nullptr; }
+  const uint32_t cap = (uint32_t)(b1 - b0);
+  std::vector<double> rec((size_t)cap * 11); std::vector<int64_t> att(cap); std::vector<uint8_t> kind(cap);
+  uint32_t n = 0; rt_emit_stats st; memset(&st, 0, sizeof st);
+  if (cap) { int rc = rt_emit_photons(sb->scene, &p, (int)a.num(2, 1), (uint64_t)b0, (uint64_t)b1, cap, rec.data(), att.data(), kind.data(), &n, &st); if (rc != RT_OK) return fail(env, sb->cb->ctx, rc); }
+  void *rd, *ad, *kd; napi_value r = make_typed(env, napi_float64_array, (size_t)n * 11, 8, &rd), at = make_typed(env, napi_float64_array, n, 8, &ad), k = make_typed(env, napi_uint8_array, n, 1, &kd), out;
+  if (!r || !at || !k) { napi_throw_error(env, nullptr, "N-API call failed: typed array"); return nullptr; }
+  if (n) { memcpy(rd, rec.data(), (size_t)n * 88); memcpy(kd, kind.data(), n); }
+  for (uint32_t i = 0; i < n; i++) ((double *)ad)[i] = (double)att[i];
+  NAPI_OK(napi_create_object(env, &out));
+  napi_set_named_property(env, out, "records", r); napi_set_named_property(env, out, "attempts", at); napi_set_named_property(env, out, "kind", k);
+  napi_set_named_property(env, out, "stats", emit_stats_object(env, st));
+  return out;
+}
+// photonMapBuildLists(lists, which) -> map: the kd-tree of a list without its photons leaving the GPU
+static napi_value PhotonMapBuildLists(napi_env env, napi_callback_info info) {
+  Args a(env, info);
+  ListsBox *lb = a.ext<ListsBox>(0);
+  if (!lb) return nullptr;
+  rt_photon_map *m = nullptr;
+  int rc = rt_photon_map_build_lists(lb->lists, (int)a.num(1, 0), &m);
+  if (rc != RT_OK) return fail(env, lb->cb->ctx, rc);
+  return map_handle(env, lb->cb, m);
+}
+// photonMapBuildPacked(ctx, photons Float32Array(n*9) | device buffer[, n]) -> map
+static napi_value PhotonMapBuildPacked(napi_env env, napi_callback_info info) {
+  Args a(env, info);
+  CtxBox *cb = a.ext<CtxBox>(0);
+  if (!cb) return nullptr;
+  size_t bytes = 0;
+  const float *ph = (const float *)mem_arg(a, 1, napi_float32_array, cb, &bytes, "photonMapBuildPacked");
+  if (!ph) return nullptr;
+  const double n = a.has(2) ? a.num(2, 0) : (double)(bytes / 36);
+  if (!(n >= 0) || n * 36 > (double)bytes || (!a.has(2) && bytes % 36)) { napi_throw_range_error(env, nullptr, "photonMapBuildPacked: 9 floats per photon"); return nullptr; }
+  rt_photon_map *m = nullptr;
+  int rc = rt_photon_map_build_packed(cb->ctx, ph, (uint32_t)n, &m);
+  if (rc != RT_OK) return fail(env, cb->ctx, rc);
+  return map_handle(env, cb, m);
+}
+static napi_value PhotonMapSize(napi_env env, napi_callback_info info) {
+  Args a(env, info);
+  MapBox *mb = a.ext<MapBox>(0);
+  if (!mb) return nullptr;
+  napi_value out; napi_create_uint32(env, rt_photon_map_size(mb->map), &out);
+  return out;
+}
+// kdBuild(ctx, positions Float32Array(n*3)) -> {perm: Int32Array(n), dim: Uint8Array(n)}: the tree alone
+static napi_value KdBuild(napi_env env, napi_callback_info info) {
+  Args a(env, info);
+  CtxBox *cb = a.ext<CtxBox>(0);
+  if (!cb) return nullptr;
+  size_t n3 = 0;
+  const float *pos = (const float *)a.typed(1, napi_float32_array, &n3);
+  if (!pos || n3 % 3) { if (!pending(env)) napi_throw_range_error(env, nullptr, "kdBuild(ctx, positions): 3 floats per point"); return nullptr; }
+  const uint32_t n = (uint32_t)(n3 / 3);
+  void *pd, *dd; napi_value perm = make_typed(env, napi_int32_array, n, 4, &pd), dim = make_typed(env, napi_uint8_array, n, 1, &dd), out;
+  if (!perm || !dim) { napi_throw_error(env, nullptr, "N-API call failed: typed array"); return nullptr; }
+  int rc = rt_kd_build(cb->ctx, pos, n, (int32_t *)pd, (uint8_t *)dd);
+  if (rc != RT_OK) return fail(env, cb->ctx, rc);
+  NAPI_OK(napi_create_object(env, &out));
+  napi_set_named_property(env, out, "perm", perm); napi_set_named_property(env, out, "dim", dim);
+  return out;
+}
+// gatherRadianceStatic(map, hits device buffer (nq*9 floats), nq, r, k, rgb device buffer (nq*3 floats)): the gather that
+// allocates nothing
+static napi_value GatherRadianceStatic(napi_env env, napi_callback_info info) {
+  Args a(env, info);
+  MapBox *mb = a.ext<MapBox>(0);
+  DevBox *hits = a.ext<DevBox>(1), *rgb = a.ext<DevBox>(5);
+  if (!mb || !hits || !rgb) { if (!pending(env)) napi_throw_type_error(env, nullptr, "gatherRadianceStatic(map, hitsBuffer, nq, r, k, rgbBuffer)"); return nullptr; }
+  if (hits->cb != mb->cb || rgb->cb != mb->cb) { napi_throw_error(env, nullptr, "gatherRadianceStatic: the buffers belong to another context"); return nullptr; }
+  const double nq = a.num(2, 0);
+  if (!(nq >= 0) || nq * 36 > (double)hits->bytes || nq * 12 > (double)rgb->bytes) { napi_throw_range_error(env, nullptr, "gatherRadianceStatic: nq exceeds the buffers (36 bytes per hit, 12 per result)"); return nullptr; }
+  int rc = rt_gather_radiance_static(mb->map, (const float *)hits->ptr, (uint32_t)nq, a.num(3, 0), (uint32_t)a.num(4, 0), (float *)rgb->ptr);
+  if (rc != RT_OK) return fail(env, mb->cb->ctx, rc);
+  return nullptr;
+}
+
 static napi_value FindMedian(napi_env env, napi_callback_info info) {
   Args a(env, info);
   napi_value out; napi_create_uint32(env, rt_find_median((uint32_t)a.num(0, 1)), &out);
@@ -570,6 +988,12 @@ static napi_value ModuleInit(napi_env env, napi_value exports) {
     { "kdRadius", KdRadius }, { "kdKnn", KdKnn }, { "kdNearestPath", KdNearestPath }, { "gatherRadiance", GatherRadiance }, { "gatherRadianceAdaptive", GatherRadianceAdaptive }, { "traceTile", TraceTile },
     { "traceRays", TraceRays }, { "directLight", DirectLight }, { "createPhotons", CreatePhotons }, { "walkPhotons", WalkPhotons },
     { "findMedian", FindMedian },
+    { "deviceAlloc", DeviceAlloc }, { "deviceFree", DeviceFree }, { "deviceBytes", DeviceBytes }, { "deviceRead", DeviceRead }, { "deviceWrite", DeviceWrite },
+    { "setOption", SetOption }, { "setFramesInFlight", SetFramesInFlight }, { "join", Join }, { "synchronize", Synchronize }, { "stream", Stream }, { "bandRows", BandRows },
+    { "emitManyLists", EmitManyLists }, { "listsCreate", ListsCreate }, { "listsFree", ListsFree }, { "listsRecordWords", ListsRecordWords }, { "listsCounts", ListsCounts },
+    { "listsExport", ListsExport }, { "listsRecords", ListsRecords }, { "emitShard", EmitShard }, { "listsApply", ListsApply }, { "emitPhotons", EmitPhotons },
+    { "photonMapBuildLists", PhotonMapBuildLists }, { "photonMapBuildPacked", PhotonMapBuildPacked }, { "photonMapSize", PhotonMapSize }, { "kdBuild", KdBuild },
+    { "gatherRadianceStatic", GatherRadianceStatic },
   };
   for (const auto &f : fns) {
     napi_value fn; napi_create_function(env, f.name, NAPI_AUTO_LENGTH, f.fn, nullptr, &fn);

@@ -249,4 +249,98 @@ check('Scene.traceTile / traceOnCanvas -> fillRect', tileBad <= 2, `${tileBad} p
   if (global.gc) global.gc();
 }
 
-process.exit(failures ? 1 : 0);
+// the throughput path: photon lists that stay on the GPU, trees built from them there, frames queued into device buffers,
+// shards and their merge, and the multi-GPU example with two workers on this one GPU
+(async () => {
+  const path = require('path');
+  const native = rt.addon(), ctxN = rt.context();
+  const bits = (a) => new Uint32Array(a.buffer, a.byteOffset, a.byteLength / 4);
+  const sameBits = (a, b) => { const x = bits(a), y = bits(b); if (x.length !== y.length) return false; for (let i = 0; i < x.length; i++) if (x[i] !== y[i]) return false; return true; };
+  {
+    // emitManyPhotons left the lists on the GPU; what the host path (emitMany: arrays across the boundary) returns is the same
+    const host = native.emitMany(scene._scene(), scene.params);
+    check('device-resident lists = host lists', native.listsCounts(scene.photonLists).nDiffuse === 10000 && sameBits(host.diffuse, scene._recD) && sameBits(host.caustic, scene._recC));
+    // the 36-byte format: position, direction, power * colour of the same photons
+    const packed = native.emitManyLists(scene._scene(), scene.params, rt.SHARD.PACKED);
+    const pr = native.listsRecords(packed.lists, 0);
+    let worstP = 0;
+    for (let i = 0; i < pr.n; i++) {
+      const r = scene._recD.subarray(i * 11, i * 11 + 11), q = pr.records.subarray(i * 9, i * 9 + 9);
+      const want = [r[0], r[1], r[2], r[3], r[4], r[5], r[6] * r[7], r[6] * r[8], r[6] * r[9]];
+      for (let c = 0; c < 9; c++) worstP = Math.max(worstP, Math.abs(q[c] - want[c]) / Math.max(1, Math.abs(want[c])));
+    }
+    check('packed lists hold the same photons', pr.n === 10000 && pr.words === 9 && worstP < 1e-6, `max rel diff ${worstP}`);
+    // trees: from the full list on the GPU (the scene's), from the packed list, from packed photons handed over as an array
+    const a = native.photonMapNodes(scene.photonKdTDiffuse.map), b = native.photonMapNodes(native.photonMapBuildLists(packed.lists, 0));
+    const c = native.photonMapNodes(native.photonMapBuildPacked(ctxN, pr.records)), d = native.kdBuild(ctxN, Float32Array.from({ length: pr.n * 3 }, (_, i) => pr.records[Math.floor(i / 3) * 9 + i % 3]));
+    check('trees from lists / packed photons / positions agree', sameBits(a.perm, b.perm) && sameBits(a.perm, c.perm) && sameBits(a.perm, d.perm) && a.dim.every((v, i) => v === b.dim[i] && v === c.dim[i] && v === d.dim[i]) &&
+      native.photonMapSize(scene.photonKdTDiffuse.map) === 10000);
+    native.listsFree(packed.lists);
+    // shards: two sub-ranges of one batch, merged, give the lists of the loop (first 4096 attempts of phase 1, no cap reached)
+    const W1 = 10, lo = new Uint32Array(2048 * W1), hi = new rt.DeviceBuffer(2048 * W1 * 4);
+    const s0 = native.emitShard(scene._scene(), scene.params, 1, 0, 2048, rt.SHARD.PACKED, 0, lo), s1 = native.emitShard(scene._scene(), scene.params, 1, 2048, 4096, rt.SHARD.PACKED, 0, hi.handle);
+    const m = Math.max(s0.n, s1.n, 1), merged = new Uint32Array(2 * m * W1);
+    merged.set(lo.subarray(0, s0.n * W1), 0); merged.set(hi.read(new Uint32Array(s1.n * W1)), m * W1);
+    const ls = native.listsCreate(ctxN, scene.params, rt.SHARD.PACKED);
+    const info = native.listsApply(ls, 1, 0, merged, Uint32Array.of(s0.n, s1.n), m);
+    const all = native.emitPhotons(scene._scene(), scene.params, 1, 0, 4096);
+    const nD = all.kind.reduce((k, v) => k + (v === 1), 0);
+    const got = native.listsRecords(ls, 0);
+    let worstS = 0, j = 0;
+    for (let i = 0; i < all.kind.length && j < got.n; i++) {
+      if (all.kind[i] !== 1) continue;
+      const r = all.records.subarray(i * 11, i * 11 + 11), q = got.records.subarray(j * 9, j * 9 + 9);
+      const want = [r[0], r[1], r[2], r[3], r[4], r[5], r[6] * r[7], r[6] * r[8], r[6] * r[9]];
+      for (let c = 0; c < 9; c++) worstS = Math.max(worstS, Math.abs(q[c] - want[c]) / Math.max(1, Math.abs(want[c])));
+      j++;
+    }
+    check('emitShard + listsApply = the stored photons of the same attempts', info.nDiffuse === nD && got.n === nD && j === nD && info.nDiffuse + info.nCaustic === s0.n + s1.n && info.phaseEnded === 0 && worstS < 1e-6,
+      `${s0.n} + ${s1.n} stored photons, ${nD} diffuse, max rel diff ${worstS}`);
+    hi.free(); native.listsFree(ls);
+  }
+  {
+    // frames queued into device buffers (three in flight) are the finished frame
+    const done = scene.render(0, 0, W, H);
+    const frames = scene.renderFrames(4, null, 3);
+    check('queued frames = finished frame', frames.length === 4 && frames.every((f) => sameBits(f, done.rgba8)));
+    const pre = new rt.DeviceBuffer(W * H * 32);
+    scene.renderQueued(0, 0, W, H, { pre });
+    const preHost = pre.read(new Float64Array(W * H * 4));
+    check('queued frame into a pre-clamp buffer', sameBits(preHost, done.pre));
+    const small = new rt.DeviceBuffer(64);
+    let refused = false;
+    try { scene.renderQueued(0, 0, W, H, { rgba8: small }); } catch (e) { refused = /smaller than the tile/.test(e.message); }
+    check('queued frame into a short buffer is refused', refused);
+    pre.free(); small.free();
+    native.join(ctxN); native.synchronize(ctxN);
+    let unknown = false;
+    try { native.setOption(ctxN, 'no_such_switch', 1); } catch (e) { unknown = /unknown option/.test(e.message); }
+    native.setOption(ctxN, 'knn_verbose', 0);
+    check('context calls', unknown && typeof native.stream(ctxN) === 'bigint' && native.bandRows(100, 16, 2, 1) === 48 && native.bandRows(100, 16, 2, 0) === 52);
+  }
+  {
+    // the gather that allocates nothing, on device buffers, against the ordinary one
+    const nq = 512, hits = new Float32Array(nq * 9);
+    for (let i = 0; i < nq; i++) {
+      const ph = scene._recD.subarray((i * 19) * 11, (i * 19) * 11 + 3);
+      hits.set([ph[0], ph[1], ph[2], 0, 0, 1, 200, 180, 160], i * 9);
+    }
+    const hd = new rt.DeviceBuffer(nq * 36).write(hits), od = new rt.DeviceBuffer(nq * 12);
+    const map = scene.photonKdTDiffuse.map;
+    let okG = true;
+    for (const [r, k] of [[0.4, 0], [0, 50]]) {
+      native.gatherRadianceStatic(map, hd.handle, nq, r, k, od.handle);
+      okG = okG && sameBits(od.read(new Float32Array(nq * 3)), native.gatherRadiance(map, hits, r, k));
+    }
+    check('gatherRadianceStatic on device buffers', okG);
+    hd.free(); od.free();
+  }
+  {
+    // two workers, each with its own context, on this GPU: lists, trees and frame of the one-GPU job
+    const multi = require(path.join(__dirname, '..', 'examples', 'multi_gpu.js'));
+    const out = await multi.run({ devices: [0, 0], preset: 10, width: 256, height: 160, batch: 1 << 17, check: true,
+      options: { numPhotonsDiffuse: 20000, numPhotonsCaustic: 30000, seed: 7 } });
+    check('multi_gpu.js: two workers = one GPU', out.check.ok, JSON.stringify(out.check) + ` rounds ${out.workers[0].rounds}`);
+  }
+  process.exit(failures ? 1 : 0);
+})().catch((e) => { console.log('FAIL uncaught: ' + (e && e.stack || e)); process.exit(1); });
