@@ -32,19 +32,60 @@ FLOP_PER_TEST = {0: 14, 1: 20, 2: 34, 3: 54, 4: 46, 5: 45, 6: 30, 7: 32}
 PEAK_FP32_VALU_TFLOPS = 157.3      # 256 CU x 4 SIMD x 64 flop/clk (32 lanes x FMA) x 2.4 GHz; packed fp32 issues at half rate, so it is the same peak
 PEAK_HBM_GBS = 8000.0
 BYTES_PER_GATHER = 64 * 36 + 36 + 12
-PROFILE_TAG = "r02"
+PROFILE_TAG = "r03"
+_COUNTERS = None
 
 
-def measured_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed PMC passes of this same command (rocprofv3 cannot run
-    inside the benchmark): profiles/<tag>_traffic.json, written by tools/profile_round.sh + tools/make_profiles.py."""
-    for tag in (PROFILE_TAG, "r01_c"):
+def leg_counters(leg, pattern, which="largest_grid_dispatches"):
+    """Counter record of the kernel whose name contains `pattern`, from the committed per-leg counter passes of this same
+    command (rocprofv3 cannot run inside the benchmark): profiles/<tag>_counters_by_leg.json, written by
+    tools/profile_legs.sh + tools/make_leg_profiles.py from runs with --legs <leg> ('frames' = --legs none).
+    which: the dispatches with the kernel's largest grid in that leg (the ones a roofline figure quotes) or all_dispatches."""
+    global _COUNTERS
+    if _COUNTERS is None:
         try:
-            with open(os.path.join(ROOT, "profiles", f"{tag}_traffic.json")) as f:
-                return json.load(f)[kernel]["traffic_bytes_per_launch"]
-        except (OSError, KeyError, ValueError):
-            continue
+            with open(os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_counters_by_leg.json")) as f:
+                _COUNTERS = json.load(f)
+        except (OSError, ValueError):
+            _COUNTERS = {}
+    for name, rec in _COUNTERS.get(leg, {}).items():
+        if not name.startswith("_") and pattern in name:
+            return rec.get(which)
     return None
+
+
+def measured_traffic(leg, pattern, which="largest_grid_dispatches", launches=1.0):
+    """HBM bytes (2 x FETCH_SIZE + WRITE_SIZE, KiB -> bytes) of `launches` launches of the kernel in that leg"""
+    rec = leg_counters(leg, pattern, which)
+    return int(rec["traffic_bytes_per_launch"] * launches) if rec and rec.get("traffic_bytes_per_launch") is not None else None
+
+
+def executed_block(leg, pattern, seconds_per_launch, which="largest_grid_dispatches", launches=1.0):
+    """What the SQ counters say the kernel executed, against this run's clock: wave-level fp instructions by class
+    (2 FMA + MUL + ADD + TRANS) x the mean active lanes of a VALU instruction = flop per launch (counter passes of this
+    command's leg), divided by the launch duration measured in this run.  fp64 flop count double in `frac` (the vector
+    unit issues them at half the fp32 rate)."""
+    rec = leg_counters(leg, pattern, which)
+    if not rec or rec.get("executed_flop_f32_per_launch") is None or seconds_per_launch <= 0:
+        return None
+    f32, f64 = rec["executed_flop_f32_per_launch"] * launches, rec["executed_flop_f64_per_launch"] * launches
+    return {"flop_f32_per_launch": f32, "flop_f64_per_launch": f64, "lanes_per_valu_instruction": rec.get("lanes_per_valu_instruction"),
+            "waiting_over_wave_cycles": rec.get("waiting_over_wave_cycles"), "fp_share_of_valu_instructions": rec.get("flop_instruction_share_of_valu"),
+            "achieved_f32": f32 / seconds_per_launch / 1e12, "achieved_f64": f64 / seconds_per_launch / 1e12, "unit": "TFLOP/s",
+            "frac": (f32 + 2 * f64) / seconds_per_launch / 1e12 / PEAK_FP32_VALU_TFLOPS,
+            "source": f"profiles/{PROFILE_TAG}_counters_by_leg.json['{leg}'][kernel containing '{pattern}']['{which}'] (tables: profiles/{PROFILE_TAG}_{leg}_pmc.md); "
+                      "64 x wave instructions (2 FMA + MUL + ADD + TRANS) x lanes / 64, over this run's launch duration"}
+
+
+def frame_executed(in_flight, seconds_per_frame):
+    """both kernels of a headline frame (the pair the library runs with that many frames in flight) against the frame time"""
+    pair = ("k_primary_tiles<", "k_tail_persistent") if in_flight >= 3 else ("k_primary<float", "k_tail<float")
+    parts = [executed_block("frames", k, seconds_per_frame) for k in pair]
+    if any(x is None for x in parts):
+        return None
+    f32 = sum(x["flop_f32_per_launch"] for x in parts)
+    return {"flop_f32_per_frame": f32, "achieved_f32": f32 / seconds_per_frame / 1e12, "unit": "TFLOP/s", "frac": f32 / seconds_per_frame / 1e12 / PEAK_FP32_VALU_TFLOPS,
+            "kernels": list(pair), "source": parts[0]["source"]}
 
 
 def flop_per_ray_pass(flat):
@@ -201,6 +242,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="skip the photon-map (k-NN gather) leg")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the short legs for the older tracer, the 10k-primitive scene, emission and the full render")
+    ap.add_argument("--legs", default="all", help="report-only legs to run, comma-separated: gather (1M-photon build + k-NN gather, tile order), raster, mode_a, config4, "
+                                                 "emit, full_b, config0, knn_real, radius_real; 'all' (default) or 'none'.  One leg per run is how the per-leg profiles are made")
     ap.add_argument("--independent-frames", action="store_true", help="N > 1: every rank renders whole frames of its own (weak scaling) instead of the one-job split")
     ap.add_argument("--photons-per-gpu", type=int, default=12_500_000, help="N > 1: stored photons per GPU of the sharded emission (half diffuse, half caustic)")
     ap.add_argument("--band", type=int, default=16, help="N > 1: rows per interleaved band")
@@ -255,12 +298,22 @@ def main():
     split = world > 1 and not args.independent_frames
     phases = None
 
+    ALL_LEGS = ("gather", "raster", "mode_a", "config4", "emit", "full_b", "config0", "knn_real", "radius_real")
+    legs = set(ALL_LEGS) if args.legs == "all" else {x for x in args.legs.split(",") if x and x != "none"}
+    if legs - set(ALL_LEGS):
+        ap.error(f"unknown leg(s) {sorted(legs - set(ALL_LEGS))}; known: {', '.join(ALL_LEGS)}")
+    if args.no_gather:
+        legs -= {"gather", "raster", "knn_real", "radius_real"}
+    if args.no_other_configs:
+        legs -= {"mode_a", "config4", "emit", "full_b", "config0", "knn_real", "radius_real"}
+    want = lambda name: name in legs
+
     def other_legs():
         """the report-only legs (photon maps, the older tracer, the large scene, emission, full renders); each times itself"""
         # ---- photon-map leg: 1M-photon kd-tree build + k-NN radiance gather per pixel ----
         extra = {}
         roof_gather = roof_build = roof_emit = None
-        if not args.no_gather:                        # (every rank runs the report-only legs: they hold barriers)
+        if want("gather") or want("raster"):          # (every rank runs the report-only legs: they hold barriers)
             rec_host, hits_host = synth.box_photons(args.photons, seed=7), synth.box_queries(W, H)
             rec = torch.from_numpy(rec_host).to(dev)
             hits = torch.from_numpy(hits_host).to(dev)
@@ -269,7 +322,7 @@ def main():
             del pm
             torch.cuda.synchronize()
             builds = []
-            for _ in range(3):
+            for _ in range(3 if want("gather") else 1):
                 tb = time.perf_counter()
                 pm = ctx.photon_map(rec)
                 builds.append(time.perf_counter() - tb)
@@ -281,42 +334,44 @@ def main():
                           "achieved": build_bytes / build_s / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": build_bytes / build_s / 1e9 / PEAK_HBM_GBS,
                           "traffic": None, "algorithmic_bytes": build_bytes, "seconds": build_s, "photons": n_ph,
                           "note": "algorithmic bytes = N x (12 B read + 12 B written) x ceil(log2 N) + 5 N; time = host clock around the whole call, best of 3"}
-            pm.gather(hits, k=args.knn, out=rgb)                               # warm-up
-            ctx.profile_enable(True)
-            ctx.profile_select("gather_knn,gather_knn_split,gather_knn_single,gather_knn_heap_fallback")
-            ctx.profile_reset()
-            gsteps = max(2, min(args.steps, 5))
-            barrier()
-            tg = time.perf_counter()
-            for _ in range(gsteps):
-                pm.gather(hits, k=args.knn, out=rgb)
-            ctx.synchronize()
-            barrier()
-            gdt = time.perf_counter() - tg
-            g_ms, g_launches = ctx.profile_get("gather_knn")
-            fb_ms, fb_launches = ctx.profile_get("gather_knn_heap_fallback")
-            sp_ms, sp_launches = ctx.profile_get("gather_knn_split")
-            sg_ms, sg_launches = ctx.profile_get("gather_knn_single")
-            ctx.profile_enable(False)
-            gathers = hits.shape[0] * gsteps
-            gps = torch.tensor([gathers / gdt], dtype=torch.float64, device=cdev)
-            if world > 1:
-                dist.all_reduce(gps, op=dist.ReduceOp.SUM)
-            g_achieved = hits.shape[0] * BYTES_PER_GATHER / (g_ms / g_launches * 1e-3) / 1e9
-            extra = {"knn_gathers_per_s": float(gps.item()), "knn_k": args.knn, "photons": args.photons,
-                     "kd_build_s": build_s, "gather_ms_per_step": gdt / gsteps * 1e3,
-                     "split_units_ms_per_step": sp_ms / gsteps, "split_unit_launches": sp_launches,
-                     "single_query_ms_per_step": sg_ms / gsteps, "single_query_launches": sg_launches,
-                     "heap_fallback_ms_per_step": fb_ms / gsteps, "heap_fallback_launches": fb_launches}
-            roof_gather = {"kernel": "k_gather_knn_wave", "bound": "hbm", "achieved": g_achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                           "frac": g_achieved / PEAK_HBM_GBS, "traffic": measured_traffic("k_gather_knn_wave"),
-                           "algorithmic_bytes_per_gather": BYTES_PER_GATHER, "avg_launch_ms": g_ms / g_launches,
-                           "whole_call": {"ms": gdt / gsteps * 1e3, "frac": hits.shape[0] * BYTES_PER_GATHER / (gdt / gsteps) / 1e9 / PEAK_HBM_GBS,
-                                          "note": "every launch of rt_gather_radiance (first pass, the units cut into eighths, single queries) and the host's counter read-backs between them"}}
+            if want("gather"):
+                pm.gather(hits, k=args.knn, out=rgb)                               # warm-up
+                ctx.profile_enable(True)
+                ctx.profile_select("gather_knn,gather_knn_split,gather_knn_single,gather_knn_heap_fallback")
+                ctx.profile_reset()
+                gsteps = max(2, min(args.steps, 5))
+                barrier()
+                tg = time.perf_counter()
+                for _ in range(gsteps):
+                    pm.gather(hits, k=args.knn, out=rgb)
+                ctx.synchronize()
+                barrier()
+                gdt = time.perf_counter() - tg
+                g_ms, g_launches = ctx.profile_get("gather_knn")
+                fb_ms, fb_launches = ctx.profile_get("gather_knn_heap_fallback")
+                sp_ms, sp_launches = ctx.profile_get("gather_knn_split")
+                sg_ms, sg_launches = ctx.profile_get("gather_knn_single")
+                ctx.profile_enable(False)
+                gathers = hits.shape[0] * gsteps
+                gps = torch.tensor([gathers / gdt], dtype=torch.float64, device=cdev)
+                if world > 1:
+                    dist.all_reduce(gps, op=dist.ReduceOp.SUM)
+                g_achieved = hits.shape[0] * BYTES_PER_GATHER / (g_ms / g_launches * 1e-3) / 1e9
+                extra = {"knn_gathers_per_s": float(gps.item()), "knn_k": args.knn, "photons": args.photons,
+                         "kd_build_s": build_s, "gather_ms_per_step": gdt / gsteps * 1e3,
+                         "split_units_ms_per_step": sp_ms / gsteps, "split_unit_launches": sp_launches,
+                         "single_query_ms_per_step": sg_ms / gsteps, "single_query_launches": sg_launches,
+                         "heap_fallback_ms_per_step": fb_ms / gsteps, "heap_fallback_launches": fb_launches}
+                roof_gather = {"kernel": "k_gather_knn_wave", "bound": "hbm", "achieved": g_achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                               "frac": g_achieved / PEAK_HBM_GBS, "traffic": measured_traffic("gather", "k_gather_knn_wave"),
+                               "executed": executed_block("gather", "k_gather_knn_wave", g_ms / g_launches * 1e-3),
+                               "algorithmic_bytes_per_gather": BYTES_PER_GATHER, "avg_launch_ms": g_ms / g_launches,
+                               "whole_call": {"ms": gdt / gsteps * 1e3, "frac": hits.shape[0] * BYTES_PER_GATHER / (gdt / gsteps) / 1e9 / PEAK_HBM_GBS,
+                                              "note": "every launch of rt_gather_radiance (first pass, the units cut into eighths, single queries) and the host's counter read-backs between them"}}
             # the same gather on less friendly inputs: the queries in raster order instead of 8x8 tiles, and a real emitted map
             # (the default scene's caustic + diffuse photons) queried at the frame's own first-hit points
             order = np.arange(W * H).reshape(H // 8, 8, W // 8, 8).transpose(0, 2, 1, 3).reshape(-1) if (H % 8 == 0 and W % 8 == 0) else None
-            if order is not None:
+            if order is not None and want("raster"):
                 raster = torch.from_numpy(np.ascontiguousarray(hits_host[np.argsort(order)])).to(dev)
                 pm.gather(raster, k=args.knn, out=rgb)
                 ctx.synchronize()
@@ -330,7 +385,7 @@ def main():
             del pm, rec
 
         # ---- short legs for the other BASELINE configs (reported under "extra", never part of `value`) ----
-        if not args.no_other_configs:
+        if legs - {"gather", "raster"}:
             frame = torch.empty((H, W, 4), dtype=torch.uint8, device=dev)
 
             def timed_frames(scene, params, out, n=5, maps=(None, None)):
@@ -342,122 +397,132 @@ def main():
                     stt = scene.trace_tile(params, maps[0], maps[1], out_rgba8=out, want=())["stats"]
                 ctx.synchronize()
                 return (time.perf_counter() - t_) / n, stt
-            # the older tracer (ray.js) on its preset 3 at the same resolution
-            flat_a = FlatScene.from_json(os.path.join(ROOT, "tests", "golden", "scene_rayjs3_flat.json")).with_size(W, H)
-            pa = capi.default_params(precision=capi.PRECISION_F32, mode=capi.MODE_WHITTED, seed=seed, max_trace_dist=100.0, max_depth=20, sub_sample=1)
-            dt_a, st_a = timed_frames(ctx.upload(flat_a), pa, frame)
-            extra["mode_a_rayjs_preset3"] = {"Mrays_per_s": st_a["rays"] / dt_a / 1e6, "ms_per_frame": dt_a * 1e3, "rays_per_frame": st_a["rays"],
-                                             "primitives": int(flat_a.n_shapes), "resolution": [W, H]}
-            # configs[3]: 10 000 primitives at 3840x2160, paths of up to 8 segments, through the hierarchy
-            flat4 = synth.many_primitive_scene(10000, seed=42, width=3840, height=2160)
-            frame4 = torch.empty((2160, 3840, 4), dtype=torch.uint8, device=dev)
-            p4 = capi.default_params(precision=capi.PRECISION_F32, use_direct_light=0, use_photon_maps=0, seed=seed, sub_sample=1, max_bounces=8)
-            dt4, st4 = timed_frames(ctx.upload(flat4), p4, frame4, n=3)
-            brute = st4["rays"] * st4["prims_per_ray_brute_force"]
-            extra["config4_10k_primitives_4k"] = {"Mrays_per_s": st4["rays"] / dt4 / 1e6, "ms_per_frame": dt4 * 1e3, "rays_per_frame": st4["rays"],
-                                                  "primitives": int(flat4.n_shapes), "prim_tests": st4["prim_tests"], "brute_force_tests": brute,
-                                                  "tests_avoided_frac": 1.0 - st4["prim_tests"] / brute}
-            del frame4
-            # photon emission on one GPU (the configs[4] kernel): 2 M diffuse + 2 M caustic photons of the default scene, the lists
-            # kept in device memory as packed 36-byte photons, then both kd-trees straight from the lists
-            pe1 = capi.default_params(precision=capi.PRECISION_F32, num_photons_diffuse=2_000_000, num_photons_caustic=2_000_000, seed=seed)
-            lists, _ = sc.emit_many_lists(pe1, capi.SHARD_PACKED, strict=False)
-            del lists
-            ctx.profile_enable(True)
-            ctx.profile_select("photon_emit_bounce")
-            ctx.profile_reset()
-            ctx.synchronize()
-            t_ = time.perf_counter()
-            lists, em = sc.emit_many_lists(pe1, capi.SHARD_PACKED, strict=False)
-            ctx.synchronize()
-            dte = time.perf_counter() - t_
-            e_ms, e_n = ctx.profile_get("photon_emit_bounce")
-            ctx.profile_enable(False)
-            t_ = time.perf_counter()
-            md, mc = lists.photon_map(0), lists.photon_map(1)
-            ctx.synchronize()
-            dtm = time.perf_counter() - t_
-            stored = em["n_diffuse"] + em["n_caustic"]
-            extra["photon_emission"] = {"stored_photons_per_s": stored / dte, "segments_per_s": em["segments"] / dte,
-                                        "attempts": em["attempts_phase1"] + em["attempts_phase2"], "segments": em["segments"], "seconds": dte,
-                                        "emit_kernel_ms": e_ms, "emit_kernel_launches": e_n, "maps_from_lists_s": dtm,
-                                        "note": "rt_emit_many_lists: photons stay in device memory (packed 36-byte records), list caps applied on the GPU, "
-                                                "8 words read back per batch; segments = emitPhoton calls of the attempts the sequential loop runs"}
-            if e_ms > 0:
-                # (the kernel also runs the attempts of a last batch beyond the one that ends a phase: its own segment count is the rate's numerator)
-                ach = em["segments"] * fl / (e_ms * 1e-3) / 1e12
-                roof_emit = {"kernel": "k_emit<float> (createPhoton + the emitPhoton random walk, one attempt per lane; every segment scans all primitives)",
-                             "bound": "valu", "achieved": ach, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_VALU_TFLOPS,
-                             "traffic": None, "algorithmic_flop_per_segment": fl, "segments": em["segments"], "kernel_ms": e_ms, "launches": e_n,
-                             "note": "segments counted are those of the sequential loop; the launches also trace the surplus attempts of each phase's last batch"}
-            # the reference's actual render (mode B): direct light + both radius gathers on those maps, one 1080p frame
-            pf = capi.default_params(precision=capi.PRECISION_F32, num_photons_diffuse=2_000_000, num_photons_caustic=2_000_000, seed=seed, shadow_bias=1e-4)
-            dtf, stf = timed_frames(sc, pf, frame, n=3, maps=(md, mc))
-            extra["full_mode_b_frame"] = {"ms_per_frame": dtf * 1e3, "Mrays_per_s": stf["rays"] / dtf / 1e6, "rays_per_frame": stf["rays"],
-                                          "shadow_rays_per_frame": stf["shadow_rays"], "gathers_per_frame": stf["gathers"], "gathers_per_s": stf["gathers"] / dtf,
-                                          "photons": stored, "note": "direct light, diffuse (r = 0.40) and caustic (r = 0.15) radius gathers: the reference's traceRay in full; the gathers are queued, sorted by position and served 64 at a time (k_gather_deferred, k_gather_items)"}
-            # ... and BASELINE config 0's frame (320x240, 10k + 10k photons, everything on): the frame the CPU oracle is timed on
-            flat0 = flat.with_size(320, 240)
-            sc0 = ctx.upload(flat0)
-            p0 = capi.default_params(precision=capi.PRECISION_F32, num_photons_diffuse=10000, num_photons_caustic=10000, seed=seed, shadow_bias=1e-4)
-            ctx.synchronize()
-            t_ = time.perf_counter()
-            lists0, _ = sc0.emit_many_lists(p0, capi.SHARD_PACKED, strict=False)
-            md0, mc0 = lists0.photon_map(0), lists0.photon_map(1)
-            ctx.synchronize()
-            dt_prep = time.perf_counter() - t_
-            frame0 = torch.empty((240, 320, 4), dtype=torch.uint8, device=dev)
-            dt0, st0 = timed_frames(sc0, p0, frame0, n=20, maps=(md0, mc0))
-            extra["full_mode_b_config0"] = {"gpu": {"frame_ms": dt0 * 1e3, "emission_and_kd_builds_ms": dt_prep * 1e3, "rays": st0["rays"], "Mrays_per_s": st0["rays"] / dt0 / 1e6},
-                                            "cpu": cpu_full_line,
-                                            "note": "BASELINE config 0 (default scene at 320x240, 10k + 10k photons, direct light and both radius gathers): the same frame on "
-                                                    "the GPU (fp32) and on the CPU oracle (fp64)"}
-            del md0, mc0, lists0, sc0
+            if want("mode_a"):
+                # the older tracer (ray.js) on its preset 3 at the same resolution
+                flat_a = FlatScene.from_json(os.path.join(ROOT, "tests", "golden", "scene_rayjs3_flat.json")).with_size(W, H)
+                pa = capi.default_params(precision=capi.PRECISION_F32, mode=capi.MODE_WHITTED, seed=seed, max_trace_dist=100.0, max_depth=20, sub_sample=1)
+                dt_a, st_a = timed_frames(ctx.upload(flat_a), pa, frame)
+                extra["mode_a_rayjs_preset3"] = {"Mrays_per_s": st_a["rays"] / dt_a / 1e6, "ms_per_frame": dt_a * 1e3, "rays_per_frame": st_a["rays"],
+                                                 "primitives": int(flat_a.n_shapes), "resolution": [W, H]}
+            if want("config4"):
+                # configs[3]: 10 000 primitives at 3840x2160, paths of up to 8 segments, through the hierarchy
+                flat4 = synth.many_primitive_scene(10000, seed=42, width=3840, height=2160)
+                frame4 = torch.empty((2160, 3840, 4), dtype=torch.uint8, device=dev)
+                p4 = capi.default_params(precision=capi.PRECISION_F32, use_direct_light=0, use_photon_maps=0, seed=seed, sub_sample=1, max_bounces=8)
+                dt4, st4 = timed_frames(ctx.upload(flat4), p4, frame4, n=3)
+                brute = st4["rays"] * st4["prims_per_ray_brute_force"]
+                extra["config4_10k_primitives_4k"] = {"Mrays_per_s": st4["rays"] / dt4 / 1e6, "ms_per_frame": dt4 * 1e3, "rays_per_frame": st4["rays"],
+                                                      "primitives": int(flat4.n_shapes), "prim_tests": st4["prim_tests"], "brute_force_tests": brute,
+                                                      "tests_avoided_frac": 1.0 - st4["prim_tests"] / brute}
+                del frame4
+            need_maps = want("emit") or want("full_b") or want("knn_real") or want("radius_real")
+            if need_maps:
+                # photon emission on one GPU (the configs[4] kernel): 2 M diffuse + 2 M caustic photons of the default scene, the lists
+                # kept in device memory as packed 36-byte photons, then both kd-trees straight from the lists
+                pe1 = capi.default_params(precision=capi.PRECISION_F32, num_photons_diffuse=2_000_000, num_photons_caustic=2_000_000, seed=seed)
+                lists, _ = sc.emit_many_lists(pe1, capi.SHARD_PACKED, strict=False)
+                del lists
+                ctx.profile_enable(True)
+                ctx.profile_select("photon_emit_bounce")
+                ctx.profile_reset()
+                ctx.synchronize()
+                t_ = time.perf_counter()
+                lists, em = sc.emit_many_lists(pe1, capi.SHARD_PACKED, strict=False)
+                ctx.synchronize()
+                dte = time.perf_counter() - t_
+                e_ms, e_n = ctx.profile_get("photon_emit_bounce")
+                ctx.profile_enable(False)
+                t_ = time.perf_counter()
+                md, mc = lists.photon_map(0), lists.photon_map(1)
+                ctx.synchronize()
+                dtm = time.perf_counter() - t_
+                stored = em["n_diffuse"] + em["n_caustic"]
+                extra["photon_emission"] = {"stored_photons_per_s": stored / dte, "segments_per_s": em["segments"] / dte,
+                                            "attempts": em["attempts_phase1"] + em["attempts_phase2"], "segments": em["segments"], "seconds": dte,
+                                            "emit_kernel_ms": e_ms, "emit_kernel_launches": e_n, "maps_from_lists_s": dtm,
+                                            "note": "rt_emit_many_lists: photons stay in device memory (packed 36-byte records), list caps applied on the GPU, "
+                                                    "8 words read back per batch; segments = emitPhoton calls of the attempts the sequential loop runs"}
+                if e_ms > 0:
+                    # (the kernel also runs the attempts of a last batch beyond the one that ends a phase: its own segment count is the rate's numerator)
+                    ach = em["segments"] * fl / (e_ms * 1e-3) / 1e12
+                    roof_emit = {"kernel": "k_emit<float> (createPhoton + the emitPhoton random walk, one attempt per lane; every segment scans all primitives)",
+                                 "bound": "valu", "achieved": ach, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_VALU_TFLOPS,
+                                 "traffic": measured_traffic("emit", "k_emit<float", which="all_dispatches", launches=e_n), "algorithmic_flop_per_segment": fl, "segments": em["segments"], "kernel_ms": e_ms, "launches": e_n,
+                                 "executed": executed_block("emit", "k_emit<float", e_ms * 1e-3, which="all_dispatches", launches=e_n),
+                                 "note": "segments counted are those of the sequential loop; the launches also trace the surplus attempts of each phase's last batch"}
+            if want("full_b"):
+                # the reference's actual render (mode B): direct light + both radius gathers on those maps, one 1080p frame
+                pf = capi.default_params(precision=capi.PRECISION_F32, num_photons_diffuse=2_000_000, num_photons_caustic=2_000_000, seed=seed, shadow_bias=1e-4)
+                dtf, stf = timed_frames(sc, pf, frame, n=3, maps=(md, mc))
+                extra["full_mode_b_frame"] = {"ms_per_frame": dtf * 1e3, "Mrays_per_s": stf["rays"] / dtf / 1e6, "rays_per_frame": stf["rays"],
+                                              "shadow_rays_per_frame": stf["shadow_rays"], "gathers_per_frame": stf["gathers"], "gathers_per_s": stf["gathers"] / dtf,
+                                              "photons": stored, "note": "direct light, diffuse (r = 0.40) and caustic (r = 0.15) radius gathers: the reference's traceRay in full; the gathers are queued, sorted by position and served 64 at a time (k_gather_deferred, k_gather_items)"}
+            if want("config0"):
+                # ... and BASELINE config 0's frame (320x240, 10k + 10k photons, everything on): the frame the CPU oracle is timed on
+                flat0 = flat.with_size(320, 240)
+                sc0 = ctx.upload(flat0)
+                p0 = capi.default_params(precision=capi.PRECISION_F32, num_photons_diffuse=10000, num_photons_caustic=10000, seed=seed, shadow_bias=1e-4)
+                ctx.synchronize()
+                t_ = time.perf_counter()
+                lists0, _ = sc0.emit_many_lists(p0, capi.SHARD_PACKED, strict=False)
+                md0, mc0 = lists0.photon_map(0), lists0.photon_map(1)
+                ctx.synchronize()
+                dt_prep = time.perf_counter() - t_
+                frame0 = torch.empty((240, 320, 4), dtype=torch.uint8, device=dev)
+                dt0, st0 = timed_frames(sc0, p0, frame0, n=20, maps=(md0, mc0))
+                extra["full_mode_b_config0"] = {"gpu": {"frame_ms": dt0 * 1e3, "emission_and_kd_builds_ms": dt_prep * 1e3, "rays": st0["rays"], "Mrays_per_s": st0["rays"] / dt0 / 1e6},
+                                                "cpu": cpu_full_line,
+                                                "note": "BASELINE config 0 (default scene at 320x240, 10k + 10k photons, direct light and both radius gathers): the same frame on "
+                                                        "the GPU (fp32) and on the CPU oracle (fp64)"}
+                del md0, mc0, lists0, sc0
             # the k-nearest gather on that real map at the frame's own first-hit points
-            if not args.no_gather:
+            if want("knn_real") or want("radius_real"):
                 hp = capi.default_params(precision=capi.PRECISION_F32, use_direct_light=0, use_photon_maps=0, seed=seed, max_bounces=1)
                 real_hits = synth.first_hit_queries(sc, hp, W, H)
                 if real_hits.shape[0]:
                     rh = torch.from_numpy(real_hits).to(dev)
                     out_r = torch.empty((rh.shape[0], 3), dtype=torch.float32, device=dev)
-                    mc.gather(rh, k=args.knn, out=out_r)
-                    ctx.synchronize()
-                    t_ = time.perf_counter()
-                    for _ in range(2):
+                    if want("knn_real"):
                         mc.gather(rh, k=args.knn, out=out_r)
-                    ctx.synchronize()
-                    extra["knn_real_map"] = {"gathers_per_s": 2 * rh.shape[0] / (time.perf_counter() - t_), "photons": em["n_caustic"], "queries": int(rh.shape[0]),
-                                             "note": "the default scene's emitted caustic map, queried at the frame's first-hit points in 8x8-tile order"}
-                    # the reference's own gather (rayphoton.js:1765-1815): fixed radius, at the same points, both maps
-                    rad = {}
-                    for name, pm_, r_ in (("diffuse_r0.40", md, 0.40), ("caustic_r0.15", mc, 0.15)):
-                        pm_.gather(rh, r=r_, out=out_r)
                         ctx.synchronize()
                         t_ = time.perf_counter()
                         for _ in range(2):
+                            mc.gather(rh, k=args.knn, out=out_r)
+                        ctx.synchronize()
+                        extra["knn_real_map"] = {"gathers_per_s": 2 * rh.shape[0] / (time.perf_counter() - t_), "photons": em["n_caustic"], "queries": int(rh.shape[0]),
+                                                 "note": "the default scene's emitted caustic map, queried at the frame's first-hit points in 8x8-tile order"}
+                    if want("radius_real"):
+                        # the reference's own gather (rayphoton.js:1765-1815): fixed radius, at the same points, both maps
+                        rad = {}
+                        for name, pm_, r_ in (("diffuse_r0.40", md, 0.40), ("caustic_r0.15", mc, 0.15)):
                             pm_.gather(rh, r=r_, out=out_r)
-                        ctx.synchronize()
-                        gps = 2 * rh.shape[0] / (time.perf_counter() - t_)
-                        # photons inside the balls, from a sample of the queries (rt_kd_radius counts them)
-                        samp = real_hits[:: max(1, real_hits.shape[0] // 4096), :3]
-                        cnt, _ = pm_.radius(samp, r_, cap=1)
-                        mean_in = float(cnt.mean())
-                        # per (query, photon inside the ball): 3 sub + 5 (d^2) + 5 (direction . normal) + 6 (three FMAs) = 19 flop
-                        tf = gps * mean_in * 19 / 1e12
-                        rad[name] = {"gathers_per_s": gps, "photons_in_ball_mean": mean_in, "photon_tests_per_s": gps * mean_in,
-                                     "algorithmic_TFLOP_per_s": tf, "frac_of_fp32_peak": tf / PEAK_FP32_VALU_TFLOPS}
-                    with ctx.option("defer_gathers", 0, -1):
-                        sub = rh[::16].contiguous()
-                        out_s = torch.empty((sub.shape[0], 3), dtype=torch.float32, device=dev)
-                        md.gather(sub, r=0.40, out=out_s)
-                        ctx.synchronize()
-                        t_ = time.perf_counter()
-                        md.gather(sub, r=0.40, out=out_s)
-                        ctx.synchronize()
-                        rad["diffuse_r0.40_lane_by_lane"] = {"gathers_per_s": sub.shape[0] / (time.perf_counter() - t_), "note": "every 16th query, one lane walking the tree per query (k_gather_radius)"}
-                    rad["note"] = "rt_gather_radiance with k = 0 on the emitted 2 M-photon maps: queries queued, sorted by position, served 64 at a time, subtrees of <= 4096 photons as work items"
-                    extra["radius_gather_real_map"] = rad
-            del md, mc, lists
+                            ctx.synchronize()
+                            t_ = time.perf_counter()
+                            for _ in range(2):
+                                pm_.gather(rh, r=r_, out=out_r)
+                            ctx.synchronize()
+                            gps = 2 * rh.shape[0] / (time.perf_counter() - t_)
+                            # photons inside the balls, from a sample of the queries (rt_kd_radius counts them)
+                            samp = real_hits[:: max(1, real_hits.shape[0] // 4096), :3]
+                            cnt, _ = pm_.radius(samp, r_, cap=1)
+                            mean_in = float(cnt.mean())
+                            # per (query, photon inside the ball): 3 sub + 5 (d^2) + 5 (direction . normal) + 6 (three FMAs) = 19 flop
+                            tf = gps * mean_in * 19 / 1e12
+                            rad[name] = {"gathers_per_s": gps, "photons_in_ball_mean": mean_in, "photon_tests_per_s": gps * mean_in,
+                                         "algorithmic_TFLOP_per_s": tf, "frac_of_fp32_peak": tf / PEAK_FP32_VALU_TFLOPS}
+                        with ctx.option("defer_gathers", 0, -1):
+                            sub = rh[::16].contiguous()
+                            out_s = torch.empty((sub.shape[0], 3), dtype=torch.float32, device=dev)
+                            md.gather(sub, r=0.40, out=out_s)
+                            ctx.synchronize()
+                            t_ = time.perf_counter()
+                            md.gather(sub, r=0.40, out=out_s)
+                            ctx.synchronize()
+                            rad["diffuse_r0.40_lane_by_lane"] = {"gathers_per_s": sub.shape[0] / (time.perf_counter() - t_), "note": "every 16th query, one lane walking the tree per query (k_gather_radius)"}
+                        rad["note"] = "rt_gather_radiance with k = 0 on the emitted 2 M-photon maps: queries queued, sorted by position, served 64 at a time, subtrees of <= 4096 photons as work items"
+                        extra["radius_gather_real_map"] = rad
+            if need_maps:
+                del md, mc, lists
         return extra, roof_gather, roof_build, roof_emit
 
     # N = 1: the other legs run first (seconds of GPU work), so that the headline frames are timed on a chip that is already
@@ -669,7 +734,8 @@ def main():
                            "k_tail<float> (every path that survives its first hit, to its end: closest-hit scan (every primitive, less the groups no ray of the wave reaches) + shade per segment, "
                            "256-lane groups with LDS-resident path state)") + " -- the longer of the frame's two kernels",
                 "bound": "valu", "achieved": ach, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_VALU_TFLOPS,
-                "traffic": measured_traffic("k_tail_persistent" if in_flight >= 3 else "k_tail"), "algorithmic_flop_per_ray_pass": fl, "avg_launch_ms": t_avg * 1e3,
+                "traffic": measured_traffic("frames", "k_tail_persistent" if in_flight >= 3 else "k_tail<float"), "algorithmic_flop_per_ray_pass": fl, "avg_launch_ms": t_avg * 1e3,
+                "executed": executed_block("frames", "k_tail_persistent" if in_flight >= 3 else "k_tail<float", t_avg),
                 "segments_per_launch": int(tail_rays), "launches_per_step": 1.0, "timed_launches": int(tail_launches),
                 "primitive_tests_per_segment_executed": st["prim_tests"] / max(1, st["rays"]),
                 "note": "the timed frames overlap (four frames in flight), so a launch shares the chip with the neighbouring frames' kernels and its duration is not its cost; "
@@ -678,10 +744,13 @@ def main():
                         "rate on this chip is 106 TFLOP/s, profiles/r02_valu_issue_rate.txt)",
                 "exclusive": {"note": "frames one at a time, where the library uses the compacting tail kernel k_tail<float> (it finishes a lone frame sooner)",
                               "tail": {"avg_launch_ms": tx_avg * 1e3, "achieved": tail_flop / max(tx_avg, 1e-12) / 1e12,
-                                       "frac": tail_flop / max(tx_avg, 1e-12) / 1e12 / PEAK_FP32_VALU_TFLOPS},
+                                       "frac": tail_flop / max(tx_avg, 1e-12) / 1e12 / PEAK_FP32_VALU_TFLOPS,
+                                       "traffic": measured_traffic("frames", "k_tail<float"), "executed": executed_block("frames", "k_tail<float", tx_avg)},
                               "primary": {"avg_launch_ms": px_avg * 1e3, "rays_per_launch": W * H, "achieved": W * H * fl / max(px_avg, 1e-12) / 1e12,
-                                          "frac": W * H * fl / max(px_avg, 1e-12) / 1e12 / PEAK_FP32_VALU_TFLOPS}},
-                "frame": {"achieved": frame_ach, "frac": frame_ach / PEAK_FP32_VALU_TFLOPS, "ms": t_total / args.steps * 1e3},
+                                          "frac": W * H * fl / max(px_avg, 1e-12) / 1e12 / PEAK_FP32_VALU_TFLOPS,
+                                          "traffic": measured_traffic("frames", "k_primary<float"), "executed": executed_block("frames", "k_primary<float", px_avg)}},
+                "frame": {"achieved": frame_ach, "frac": frame_ach / PEAK_FP32_VALU_TFLOPS, "ms": t_total / args.steps * 1e3,
+                          "executed": frame_executed(in_flight, t_total / args.steps)},
                 "host_submit_ms_per_frame": t_submit / args.steps * 1e3}
         else:
             frame_ach = (rays // args.steps) * fl / (t_total / args.steps) / 1e12
