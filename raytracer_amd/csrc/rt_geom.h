@@ -540,6 +540,9 @@ RT_D float isect_fast_any(int type, const float *f, V3<float> o, V3<float> d, fl
 // The same scans through the hierarchy.  Every primitive whose box the ray can reach before the best hit so far is
 // tested with the same distance function as in the all-primitives scan, and equal distances are settled on the
 // original index, so the result is the all-primitives scan's (boxes are padded; a NaN slab interval counts as hit).
+// (Tried for fp32: every lane first walks on to its next leaf, then the wave tests the leaves type by type with the
+// type-specialised tests -- 2.15 against 2.16 ms on the 10 000-primitive 4K frame: the walk waits for its dependent node
+// loads, not for divergent tests.)
 template <typename T, int MODE> RT_D int scan_bvh(const DevScene<T> &S, V3<T> o, V3<T> d, T eps, T limit, T &t_out, uint32_t *tests) {
   T best = Limits<T>::inf(); int best_idx = -1;
   const T lim = (MODE == 2) ? limit - eps : T(0);

@@ -215,6 +215,26 @@ static int trace_tile_mode(rt_scene *sc, int slot, const rt_params *p, DevMap md
       C.cull_lists = W.cull.as<uint32_t>(); C.cull_stride = stride;
     }
   }
+  // Hierarchy scenes: the first pass scans, from LDS, the primitives its workgroup's pyramid can reach (k_primary_gathered);
+  // the lists are made like the small scenes' (one launch per scene, camera and tile layout).  Option cull_lists = 0, or a
+  // scene so large that testing every primitive against every workgroup would cost more than it saves: the walk per ray.
+  const uint32_t *big_lists = nullptr; uint32_t big_stride = 0;
+  constexpr uint32_t big_cap = 256;
+  if constexpr (sizeof(T) == 4) {
+    const uint32_t n_wg = div_up(n_paths, 256);
+    if (S.bvh && S.sbound && S.sot_cam && !whole_frame && K.cull_lists && (uint64_t)S.n_shapes * n_wg <= (4ull << 30)) {
+      rt_scene::CullKey key = { x0, y0, wb, hb, blk, p->sub_sample, (uint32_t)n_paths, C.tiles_x, C.band_shift, C.band_period, C.band_first };
+      const uint32_t stride = 16u + big_cap;
+      const size_t need = (size_t)n_wg * stride * 4;
+      if (!W.cull_valid || W.cull.bytes < need || memcmp(&W.cull_key, &key, sizeof key) != 0) {
+        W.cull_valid = false;
+        RT_HIP(ctx, W.cull.reserve(need));
+        RT_LAUNCH(ctx, "cull_lists", k_cull_lists_big, div_up(n_wg, 4), 256, S, C, n_wg, 256u, W.cull.as<uint32_t>(), stride, big_cap);
+        W.cull_key = key; W.cull_valid = true;
+      }
+      big_lists = W.cull.as<uint32_t>(); big_stride = stride;
+    }
+  }
   if (whole_frame) {
     const uint32_t tblocks = div_up(n_paths, RT_TAIL_THREADS);
     if (lds_tail) RT_LAUNCH_SMEM(ctx, "trace", (k_tail<T, true, WHITTED, FULL, RT_TAIL_PRIMARY>), tblocks, RT_TAIL_THREADS, smem, S, P, C, md, mc, levels, (const uint32_t *)nullptr, (const uint32_t *)nullptr, 0u, 0u, ctr, 0, 0u, (uint32_t *)nullptr, (uint32_t *)nullptr, 0);
@@ -274,6 +294,13 @@ static int trace_tile_mode(rt_scene *sc, int slot, const rt_params *p, DevMap md
           const uint32_t resident = (uint32_t)ctx->n_cu * 8u;
           const uint32_t per_block = std::min<uint32_t>(div_up(blocks, resident), RT_PT_MAX_TILES);
           RT_LAUNCH_SMEM(ctx, "primary", (k_primary_tiles<WHITTED, FULL>), div_up(blocks, per_block), 256, smem, S, P, C, md, mc, levels, q_cur, cnt, ctr, blocks, per_block);
+          tiles_done = true;
+        }
+      }
+      if constexpr (sizeof(T) == 4) {
+        if (!tiles_done && big_lists) {
+          RT_LAUNCH_SMEM(ctx, "primary", (k_primary_gathered<WHITTED, FULL>), blocks, 256, gathered_lds_bytes(big_cap), S, P, C, md, mc, levels, q_cur, cnt, wave_mask, block_count, ctr,
+                         big_lists, big_stride, big_cap);
           tiles_done = true;
         }
       }

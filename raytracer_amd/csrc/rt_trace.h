@@ -692,35 +692,42 @@ RT_D bool shade_step(const DevScene<T> &S, const ScanSrc<T> &G, const PathSoA<T>
 // which the caller loads before it stages the scene so that the round trip is not paid here.
 // Conservative (padded spheres, the rectangle widened by a pixel), so the scan over the list finds the same hits.
 // wg: the workgroup of the first pass (wg_size consecutive paths) the list is for; called by one whole wave.
+struct TilePyramid { V3<float> o, nl, nr, nb, nt; };      // apex and the four inward unit normals
+RT_D TilePyramid tile_pyramid(const DevScene<float> &S, const TraceCfg &C, uint32_t wg, uint32_t wg_size) {
+  const uint32_t p0 = wg * wg_size, p1 = min(p0 + wg_size, C.n_paths) - 1;
+  uint32_t r_, c0, c1;
+  const uint32_t ss = (uint32_t)(C.sub_sample * C.sub_sample);
+  const uint32_t pix0 = div_by(p0, ss, C.magic_ss, r_), pix1 = div_by(p1, ss, C.magic_ss, r_);
+  uint32_t row0, row1;
+  pixel_colrow(C, pix0, c0, row0); pixel_colrow(C, pix1, c1, row1);
+  if (C.tiles_x) {
+    // pixels pix0 .. pix1 of one tile are whole rows of it unless they lie in one row; across tiles: no culling
+    if ((pix0 >> 8) != (pix1 >> 8)) { c0 = 0; c1 = (uint32_t)C.w - 1; row0 = 0; row1 = (uint32_t)C.h - 1; }
+    else if (row0 != row1) { c0 &= ~31u; c1 = c0 + 31u; }
+  } else if (row0 != row1) { c0 = 0; c1 = (uint32_t)C.w - 1; }
+  const float jit = (C.block > 1 ? (float)C.block : 0.0f) + 1.0f;        // block jitter + sub-sample jitter, in pixels
+  const float xa = (float)(C.x0 + (int)c0 * C.block) - 1.0f, xb = (float)(C.x0 + (int)c1 * C.block) + jit + 1.0f;
+  const float ya = (float)(C.y0 + (int)band_row(C, row0) * C.block) - 1.0f, yb = (float)(C.y0 + (int)band_row(C, row1) * C.block) + jit + 1.0f;
+  const float ua = (xa * 2.0f / (float)S.width - 1.0f) * S.camera[12], ub = (xb * 2.0f / (float)S.width - 1.0f) * S.camera[12];
+  const float vb = -(ya * 2.0f / (float)S.height - 1.0f) * S.camera[13], va = -(yb * 2.0f / (float)S.height - 1.0f) * S.camera[13];
+  const V3<float> cu = ld3(S.camera + 3), cv = ld3(S.camera + 6), cw = ld3(S.camera + 9);
+  auto dir = [&](float u, float v) { return (u * cu + v * cv) + (-1.0f) * cw; };
+  const V3<float> d00 = dir(ua, va), d10 = dir(ub, va), d01 = dir(ua, vb), d11 = dir(ub, vb), dc = dir(0.5f * (ua + ub), 0.5f * (va + vb));
+  auto plane = [&](V3<float> a, V3<float> b) {                 // unit normal of the plane through the apex, a and b, facing the pyramid's axis
+    V3<float> nn = cross(a, b);
+    const float l = rt_sqrt(sqlen(nn));
+    const float sgn = dot(nn, dc) < 0.0f ? -1.0f : 1.0f;
+    return (l > 0.0f ? sgn / l : 0.0f) * nn;                    // (degenerate: zero normal, never culls)
+  };
+  TilePyramid py;
+  py.o = ld3(S.camera); py.nl = plane(d00, d01); py.nr = plane(d10, d11); py.nb = plane(d00, d10); py.nt = plane(d01, d11);
+  return py;
+}
 RT_D void cull_primitives_wave(const DevScene<float> &S, const TraceCfg &C, uint32_t wg, uint32_t wg_size, uint16_t *vis, uint32_t *vseg, float4 first64) {
   {
     const int lane = threadIdx.x & 63;
-    const uint32_t p0 = wg * wg_size, p1 = min(p0 + wg_size, C.n_paths) - 1;
-    uint32_t r_, c0, c1;
-    const uint32_t ss = (uint32_t)(C.sub_sample * C.sub_sample);
-    const uint32_t pix0 = div_by(p0, ss, C.magic_ss, r_), pix1 = div_by(p1, ss, C.magic_ss, r_);
-    uint32_t row0, row1;
-    pixel_colrow(C, pix0, c0, row0); pixel_colrow(C, pix1, c1, row1);
-    if (C.tiles_x) {
-      // pixels pix0 .. pix1 of one tile are whole rows of it unless they lie in one row; across tiles: no culling
-      if ((pix0 >> 8) != (pix1 >> 8)) { c0 = 0; c1 = (uint32_t)C.w - 1; row0 = 0; row1 = (uint32_t)C.h - 1; }
-      else if (row0 != row1) { c0 &= ~31u; c1 = c0 + 31u; }
-    } else if (row0 != row1) { c0 = 0; c1 = (uint32_t)C.w - 1; }
-    const float jit = (C.block > 1 ? (float)C.block : 0.0f) + 1.0f;        // block jitter + sub-sample jitter, in pixels
-    const float xa = (float)(C.x0 + (int)c0 * C.block) - 1.0f, xb = (float)(C.x0 + (int)c1 * C.block) + jit + 1.0f;
-    const float ya = (float)(C.y0 + (int)band_row(C, row0) * C.block) - 1.0f, yb = (float)(C.y0 + (int)band_row(C, row1) * C.block) + jit + 1.0f;
-    const float ua = (xa * 2.0f / (float)S.width - 1.0f) * S.camera[12], ub = (xb * 2.0f / (float)S.width - 1.0f) * S.camera[12];
-    const float vb = -(ya * 2.0f / (float)S.height - 1.0f) * S.camera[13], va = -(yb * 2.0f / (float)S.height - 1.0f) * S.camera[13];
-    const V3<float> o = ld3(S.camera), cu = ld3(S.camera + 3), cv = ld3(S.camera + 6), cw = ld3(S.camera + 9);
-    auto dir = [&](float u, float v) { return (u * cu + v * cv) + (-1.0f) * cw; };
-    const V3<float> d00 = dir(ua, va), d10 = dir(ub, va), d01 = dir(ua, vb), d11 = dir(ub, vb), dc = dir(0.5f * (ua + ub), 0.5f * (va + vb));
-    auto plane = [&](V3<float> a, V3<float> b) {                 // unit normal of the plane through the apex, a and b, facing the pyramid's axis
-      V3<float> nn = cross(a, b);
-      const float l = rt_sqrt(sqlen(nn));
-      const float sgn = dot(nn, dc) < 0.0f ? -1.0f : 1.0f;
-      return (l > 0.0f ? sgn / l : 0.0f) * nn;                    // (degenerate: zero normal, never culls)
-    };
-    const V3<float> nl = plane(d00, d01), nr = plane(d10, d11), nb = plane(d00, d10), nt = plane(d01, d11);
+    const TilePyramid py = tile_pyramid(S, C, wg, wg_size);
+    const V3<float> o = py.o, nl = py.nl, nr = py.nr, nb = py.nb, nt = py.nt;
     uint32_t total = 0;
     uint32_t below[RT_NUM_TYPES] = {};                            // kept slots below the first slot of each type
     for (uint32_t base = 0; base < S.n_shapes; base += 64) {
@@ -889,6 +896,127 @@ __global__ void __launch_bounds__(256) k_primary_tiles(DevScene<float> S, PathSo
   }
   flush();
   if (tid == 0 && tests) atomicAdd(&ctr->prim_tests[(blockIdx.x % RT_CTR_SLOTS) * 16], tests);
+  flush_tally(tally, ctr);
+}
+
+// ---- the first pass of scenes that are scanned through the hierarchy (too many primitives for LDS) ----
+// All rays of a first-pass workgroup start at the camera and pass through one small rectangle of pixels, so the few
+// primitives they can reach are known per workgroup and per camera: k_cull_lists_big tests every primitive's bounding
+// sphere against every workgroup's pyramid once (the host keeps the lists from frame to frame, like the small scenes'),
+// and k_primary_gathered copies its workgroup's primitives -- records, the camera's origin terms, flags -- into LDS and
+// scans them there, every lane the same primitive at the same time: no walk, no divergence, no dependent global loads.
+// lists: per workgroup `stride` words: 9 type bounds (word 8 = the length), 7 unused, then up to cap sorted slots.  A list
+// longer than cap keeps its length (and no slots): that workgroup walks the hierarchy per ray as before.
+static __global__ void __launch_bounds__(256) k_cull_lists_big(DevScene<float> S, TraceCfg C, uint32_t n_wg, uint32_t wg_size, uint32_t *lists, uint32_t stride, uint32_t cap) {
+  const uint32_t wg = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (wg >= n_wg) return;
+  const int lane = threadIdx.x & 63;
+  uint32_t *rec = lists + (size_t)wg * stride;
+  const TilePyramid py = tile_pyramid(S, C, wg, wg_size);
+  uint32_t total = 0;
+  uint32_t below[RT_NUM_TYPES] = {};                          // kept slots below the first slot of each type
+  for (uint32_t base = 0; base < S.n_shapes; base += 64) {
+    const uint32_t i = base + lane;
+    bool keep = false;
+    if (i < S.n_shapes) {
+      const float4 bs = S.sbound[i];
+      const V3<float> c = mk<float>(bs.x, bs.y, bs.z) - py.o;
+      const float R = bs.w;                                    // +inf (or NaN): never culled
+      keep = !(dot(py.nl, c) < -R || dot(py.nr, c) < -R || dot(py.nb, c) < -R || dot(py.nt, c) < -R);
+    }
+    const unsigned long long m = __ballot(keep);
+    if (m == 0ull) continue;
+    const uint32_t pos = total + (uint32_t)__popcll(m & (((unsigned long long)1 << lane) - 1));
+    if (keep && pos < cap) rec[16 + pos] = i;
+    total += (uint32_t)__popcll(m);
+#pragma unroll
+    for (int t = 0; t < RT_NUM_TYPES; t++) {
+      const uint32_t e = S.seg[t];
+      const unsigned long long lt = e <= base ? 0ull : (e - base >= 64 ? ~0ull : (((unsigned long long)1 << (e - base)) - 1));
+      below[t] += (uint32_t)__popcll(m & lt);
+    }
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int t = 0; t < RT_NUM_TYPES; t++) rec[t] = below[t];
+    rec[RT_NUM_TYPES] = total;
+  }
+}
+
+// LDS of k_primary_gathered for lists of up to cap primitives: records, origin terms, original indices, flags, 16 bounds
+static inline __host__ __device__ size_t gathered_lds_bytes(uint32_t cap) { return (size_t)cap * (RT_GEOM_STRIDE * 4 + RT_OT_STRIDE * 4 + 8) + 64; }
+
+// closest hit among the gathered primitives k = vseg[t] .. vseg[t + 1] of type t; equal distances go to the lowest
+// original index (MODE 3: the highest), which is the hierarchy walk's rule, so either route gives the same hit
+template <int MODE> RT_D int scan_gathered(const float *lg, const float *lot, const uint32_t *lorig, const uint32_t *lflags, const uint32_t *vseg, V3<float> d,
+                                           float eps, float &t_out) {
+  float best = __builtin_huge_valf(); int best_o = -1;
+#define RT_GATHERED_LOOP(TYPE)                                                                          \
+  RT_SCAN_UNROLL_PRAGMA                                                                                 \
+  for (uint32_t k = vseg[TYPE]; k < vseg[TYPE + 1]; k++) {                                              \
+    float f[RT_GEOM_STRIDE], ot[RT_OT_STRIDE];                                                          \
+    load_record<TYPE>(lg + (size_t)k * RT_GEOM_STRIDE, f);                                              \
+    load_origin_terms<TYPE>(lot + (size_t)k * RT_OT_STRIDE, ot);                                        \
+    const int flags = (TYPE == RT_CYLINDER) ? (int)lflags[k] : 0;                                       \
+    const float t = isect_fast<TYPE>(f, ot, d, eps, flags);                                             \
+    if (t > eps && t <= best) {                                                                         \
+      const int o_ = (int)lorig[k];                                                                     \
+      if (t < best || (best_o >= 0 && (MODE == 3 ? o_ > best_o : o_ < best_o))) { best = t; best_o = o_; } \
+    }                                                                                                   \
+  }
+  RT_GATHERED_LOOP(RT_PLANE) RT_GATHERED_LOOP(RT_SPHERE) RT_GATHERED_LOOP(RT_HEMISPHERE) RT_GATHERED_LOOP(RT_CYLINDER)
+  RT_GATHERED_LOOP(RT_TRIANGLE) RT_GATHERED_LOOP(RT_SQUARE) RT_GATHERED_LOOP(RT_DISC) RT_GATHERED_LOOP(RT_ANNULUS)
+#undef RT_GATHERED_LOOP
+  t_out = best;
+  return best_o;
+}
+
+template <bool WHITTED, bool FULL>
+__global__ void __launch_bounds__(256) k_primary_gathered(DevScene<float> S, PathSoA<float> P, TraceCfg C, DevMap Md, DevMap Mc, float *levels,
+                                                          uint32_t *queue, uint32_t *count_ptr, unsigned long long *wave_mask, uint32_t *block_count,
+                                                          TraceCounters *ctr, const uint32_t *lists, uint32_t stride, uint32_t cap) {
+  extern __shared__ __align__(16) unsigned char rt_lds[];
+  float *lg = (float *)rt_lds, *lot = lg + (size_t)cap * RT_GEOM_STRIDE;
+  uint32_t *lorig = (uint32_t *)(lot + (size_t)cap * RT_OT_STRIDE), *lflags = lorig + cap, *vseg = lflags + cap;
+  const uint32_t count = C.n_paths, tid = threadIdx.x;
+  if (blockIdx.x == 0 && tid == 0) *count_ptr = count;        // the queue length the later passes read
+  const uint32_t *rec = lists + (size_t)blockIdx.x * stride;
+  const uint32_t n = rec[RT_NUM_TYPES];                       // (workgroup-uniform)
+  const bool gathered = n <= cap && S.sot_cam != nullptr;
+  if (gathered) {
+    if (tid <= RT_NUM_TYPES) vseg[tid] = rec[tid];
+    // every thread issues the loads of its primitive before it stores any of them: one global round trip for the slot, one for the rest
+    for (uint32_t k = tid; k < n; k += 256) {
+      const uint32_t s = min(rec[16 + k], S.n_shapes - 1u);
+      const uint4 *src = (const uint4 *)(S.sgeom + (size_t)s * RT_GEOM_STRIDE);
+      const uint4 a = src[0], b = src[1], c = src[2];
+      const float *so = S.sot_cam + (size_t)s * RT_OT_STRIDE;
+      const float o0 = so[0], o1 = so[1], o2 = so[2], o3 = so[3], o4 = so[4];
+      const uint32_t og = S.sorig[s], fl = S.sflags32[s];
+      uint4 *dst = (uint4 *)(lg + (size_t)k * RT_GEOM_STRIDE);
+      dst[0] = a; dst[1] = b; dst[2] = c;
+      float *dt = lot + (size_t)k * RT_OT_STRIDE;
+      dt[0] = o0; dt[1] = o1; dt[2] = o2; dt[3] = o3; dt[4] = o4;
+      lorig[k] = og; lflags[k] = fl;
+    }
+    __syncthreads();
+  }
+  const ScanSrc<float> G = global_scan_src<float>(S);         // shading reads hit records (and walks the hierarchy for shadow rays) in global memory
+  const uint32_t p = blockIdx.x * blockDim.x + tid;
+  bool alive = false;
+  ShadeTally tally;
+  if (p < count) {
+    if (!C.subq_cap) queue[p] = p;                            // identity queue for the ordered compaction
+    PathState<float> st = raygen_path<float>(S, C, p);
+    float t = 0.f; int idx;
+    if (gathered) idx = scan_gathered<WHITTED ? 3 : 0>(lg, lot, lorig, lflags, vseg, st.d, (float)C.epsilon, t);
+    else idx = scan_scene<float, WHITTED ? 3 : 0>(S, G, st.o, st.d, (float)C.epsilon, 0.0f, t, &tally.tests);
+    alive = shade_step<float, WHITTED, FULL>(S, G, P, C, Md, Mc, levels, p, st, t, idx, 0, tally);
+    if (alive) store_path<float>(P, p, st);
+  }
+  if (gathered && tid == 0) atomicAdd(&ctr->prim_tests[(blockIdx.x % RT_CTR_SLOTS) * 16], (unsigned long long)n * (min(blockIdx.x * blockDim.x + blockDim.x, count) - blockIdx.x * blockDim.x));
+  if (C.subq_cap) block_append_subqueue(alive, p, queue, C.subq_cap, ctr->subq_count[0], blockIdx.x / (C.subq_cap >> 8));
+  else block_publish_masks(alive, wave_mask, block_count);
   flush_tally(tally, ctr);
 }
 

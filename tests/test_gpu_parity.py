@@ -977,6 +977,36 @@ def test_hierarchy_frames_equal_all_primitive_frames(rt):
         assert x["stats"]["prim_tests"] < z["stats"]["prim_tests"]
 
 
+@pytest.mark.parametrize("size", [(192, 108), (960, 540)])
+def test_gathered_first_pass_equals_the_walk(rt, size):
+    """Hierarchy scenes, fp32: the first pass scans, from LDS, the primitives its workgroup's pyramid can reach (lists made
+    once per camera); with option cull_lists = 0 every camera ray walks the hierarchy instead.  Both find the closest
+    primitive with ties going to the lowest index, so the frames must agree bit for bit -- at a size where most workgroups'
+    lists fit their LDS budget and at one where many do not (those workgroups walk)."""
+    capi, ctx = rt
+    from raytracer_amd import synth
+    W, H = size
+    big = ctx.upload(synth.many_primitive_scene(10000, seed=42, width=W, height=H))
+    for kw in (dict(use_direct_light=0), dict(shadow_bias=1e-4)):
+        q = capi.default_params(precision=capi.PRECISION_F32, use_photon_maps=0, seed=3, max_bounces=8, **kw)
+        got = big.trace_tile(q, want=("pre", "rgba8"))
+        with ctx.option("cull_lists", 0, 1):
+            ref = big.trace_tile(q, want=("pre", "rgba8"))
+        assert same(got["pre"], ref["pre"]) and np.array_equal(got["rgba8"], ref["rgba8"]), kw
+        for k in ("rays", "shadow_rays", "tail_rays", "bounces"):
+            assert got["stats"][k] == ref["stats"][k], k
+        assert got["stats"]["prim_tests"] != ref["stats"]["prim_tests"]          # (the two routes really differ)
+        # a mode A frame of the same scene (ties go to the highest index there)
+    flat_a = synth.many_primitive_scene(10000, seed=42, width=W, height=H)
+    flat_a.shape_surface = np.tile(np.array([[0.3, 0.5]]), (flat_a.n_shapes, 1))          # ray.js's per-shape reflectance, specular
+    big_a = ctx.upload(flat_a)
+    qa = capi.default_params(precision=capi.PRECISION_F32, mode=capi.MODE_WHITTED, seed=3, max_trace_dist=100.0, max_depth=6)
+    got = big_a.trace_tile(qa, want=("pre",))
+    with ctx.option("cull_lists", 0, 1):
+        ref = big_a.trace_tile(qa, want=("pre",))
+    assert same(got["pre"], ref["pre"])
+
+
 # ------------------------------------------------------------------ every preset of the reference
 @pytest.mark.parametrize("name", ALL_PRESETS)
 def test_every_preset_emits_and_renders_like_the_oracle(rt, name):
