@@ -57,10 +57,10 @@ int pl_gather_radius_queued(rt_photon_map *m, DevMem &ws, DevMem &sort_tmp, cons
   RT_LAUNCH(ctx, "gather_requests", k_requests_from_hits, div_up(nq, 256), 256, hits_dev, nq, C.gq);
   unsigned long long *kin = (unsigned long long *)(base + o_kin), *kout = (unsigned long long *)(base + o_kout);
   uint32_t *vin = (uint32_t *)(base + o_vin), *vout = (uint32_t *)(base + o_vout);
-  RT_LAUNCH(ctx, "gather_keys", k_gather_keys, div_up(nq, 256), 256, C, (float)(4.0 / r), kin, vin);
+  RT_LAUNCH(ctx, "gather_keys", k_gather_keys, div_up(nq, 256), 256, C, (float)(RT_GATHER_CELLS_PER_RADIUS / r), kin, vin);
   { KernelTimer timer_(ctx, "gather_sort"); RT_TRY(rt_sort_pairs_u64(ctx, sort_tmp, kin, kout, vin, vout, nq)); }
   C.gq_order = vout;
-  GatherItems items; items.items = (uint2 *)(base + o_items); items.count = C.gq_count + 1; items.cap = K.gather_split > 0 ? items_cap : 0; items.tag = 0;
+  GatherItems items; items.items = (uint2 *)(base + o_items); items.count = C.gq_count + 1; items.cap = K.gather_split > 0 ? items_cap : 0; items.tag = 0; items.stage = nullptr; items.stage_n = 0; items.full = false;
   int split = 0;
   if (K.gather_split > 0) while (((uint64_t)m->n >> split) > (uint64_t)K.gather_split && split < 24) split++;
   DevMap none = {};

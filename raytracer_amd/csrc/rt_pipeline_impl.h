@@ -7,6 +7,7 @@
 #include "rt_trace.h"
 #include <stdlib.h>
 
+
 // working epsilon of a precision: the reference's EPSILON for fp64, the coarser epsilon_f32 for fp32
 template <typename T> static double working_eps(const rt_params *p) {
   if (sizeof(T) == 8) return p->epsilon;
@@ -335,13 +336,13 @@ static int trace_tile_mode(rt_scene *sc, int slot, const rt_params *p, DevMap md
       unsigned long long *kin = W.gsort.as<unsigned long long>(), *kout = kin + C.gq_cap;
       uint32_t *vin = (uint32_t *)(kout + C.gq_cap), *vout = vin + C.gq_cap;
       const double rmax = std::max(md.n ? p->diffuse_radius : 0.0, mc.n ? p->caustic_radius : 0.0);
-      const float inv_cell = rmax > 0 ? (float)(4.0 / rmax) : 1.0f;
+      const float inv_cell = rmax > 0 ? (float)(RT_GATHER_CELLS_PER_RADIUS / rmax) : 1.0f;
       RT_LAUNCH(ctx, "gather_keys", k_gather_keys, div_up(C.gq_cap, 256), 256, C, inv_cell, kin, vin);
       { KernelTimer timer_(ctx, "gather_sort"); RT_TRY(rt_sort_pairs_u64(ctx, W.gtemp, kin, kout, vin, vout, C.gq_cap)); }
       C.gq_order = vout;
     }
     // subtrees of at most ~4096 photons become work items of their own (option gather_split = that size; 0: no splitting)
-    GatherItems items; items.items = nullptr; items.count = C.gq_count + 1; items.cap = 0; items.tag = 0;
+    GatherItems items; items.items = nullptr; items.count = C.gq_count + 1; items.cap = 0; items.tag = 0; items.stage = nullptr; items.stage_n = 0; items.full = false;
     int split_d = 0, split_c = 0;
     if (K.gather_sort && K.gather_split > 0) {
       auto depth_for = [&](uint32_t n) { int d = 0; while (((uint64_t)n >> d) > (uint64_t)K.gather_split && d < 24) d++; return d; };
@@ -364,6 +365,17 @@ static int trace_tile_mode(rt_scene *sc, int slot, const rt_params *p, DevMap md
 #endif
   // without `stats` nothing has to come back: the frame stays queued on the stream and the caller synchronises when
   // it wants the pixels (frames of a sequence then run back to back, with no host round trip between them)
+#ifdef RT_GATHER_PROBE
+  if (K.probe && defer) {
+    unsigned long long h[8];
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    RT_HIP(ctx, hipMemcpyFromSymbol(h, HIP_SYMBOL(g_gather_probe), sizeof h));
+    fprintf(stderr, "gather probe: walks %llu steps %llu candidates %llu in-ball lane tests %llu needing lanes %llu consumes %llu overflows %llu longest request wave %llu cycles\n", h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]);
+    { unsigned long long hh[40]; RT_HIP(ctx, hipMemcpyFromSymbol(hh, HIP_SYMBOL(g_gather_hist), sizeof hh)); for (int b = 0; b < 32; b++) if (hh[b]) fprintf(stderr, "   request waves of 2^%d cycles: %llu\n", b, hh[b]); memset(hh, 0, sizeof hh); RT_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(g_gather_hist), hh, sizeof hh)); }
+    memset(h, 0, sizeof h);
+    RT_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(g_gather_probe), h, sizeof h));
+  }
+#endif
   if (!readback) { RT_HIP(ctx, hipGetLastError()); return RT_OK; }
   TraceCounters hc;
   const uint32_t *hcounts = hc.counts;

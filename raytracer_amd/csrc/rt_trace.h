@@ -313,7 +313,12 @@ RT_D V3<T> gather_map(const DevMap &M, V3<T> x, V3<T> normal, double r) {
 // LDS written by some lanes of a wave is read by others: order the accesses (the waves of a workgroup run this code
 // independently, so no workgroup barrier)
 #define RT_WAVE_SYNC() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
-struct WaveGatherLds { float4 cand[RT_WG_CAP]; float pay[RT_WG_CAP * 6]; uint32_t front[RT_WG_FRONT]; };
+#ifdef RT_GATHER_PROBE
+static __device__ unsigned long long g_gather_probe[8];
+static __device__ unsigned long long g_gather_hist[40];   // request waves of k_gather_deferred by log2 of their duration; [32..]: sums of durations by the same buckets / 1024   // walks, steps, candidates, in-ball lane tests, needing lanes, consumes
+#endif
+#define RT_WG_STAGE 64                     // work items a wave collects before it appends them to the frame's list with one atomic
+struct WaveGatherLds { float4 cand[RT_WG_CAP]; float pay[RT_WG_CAP * 6]; uint32_t front[RT_WG_FRONT]; uint2 stage[RT_WG_STAGE]; };
 // workgroups of k_gather_items per CU: as many as the staging buffers of their four waves leave room for in 160 KB of LDS
 #define RT_GATHER_ITEM_WGS ((int)((160 * 1024) / (4 * sizeof(WaveGatherLds))) > 8 ? 8 : (int)((160 * 1024) / (4 * sizeof(WaveGatherLds))))
 
@@ -322,7 +327,26 @@ RT_D float wg_max(float v) { for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shf
 
 // Work items of the split gather: the subtree at heap position `y` of map (x >> 31) for the 64 requests of wave
 // (x & 0x7FFFFFFF) of the sorted request queue.
-struct GatherItems { uint2 *items; uint32_t *count; uint32_t cap; uint32_t tag; };
+// A wave collects the items of its walks in LDS (stage, stage_n of them) and appends them together: the list's length is
+// ONE word, and an atomic per walk step from every wave of the frame made that word the kernel's bottleneck.
+struct GatherItems { uint2 *items; uint32_t *count; uint32_t cap; uint32_t tag; uint2 *stage; uint32_t stage_n; bool full; };
+// Appends the wave's staged items to the frame's list (all lanes call).  Items the list has no room for stay staged, at the
+// front, and `full` is set: nothing more is appended, the caller serves what is left itself.
+RT_D void gather_items_flush(GatherItems &g) {
+  if (g.stage_n == 0 || g.full) return;
+  const uint32_t lane = threadIdx.x & 63u, n = g.stage_n;
+  RT_WAVE_SYNC()
+  uint32_t base = 0;
+  if (lane == 0) base = atomicAdd(g.count, n);
+  base = __shfl(base, 0, 64);
+  const uint32_t room = base < g.cap ? min(g.cap - base, n) : 0u;
+  const uint2 mine = lane < n ? g.stage[lane] : make_uint2(0u, 0u);          // (RT_WG_STAGE <= 64: one item a lane)
+  if (lane < room) g.items[base + lane] = mine;
+  RT_WAVE_SYNC()
+  if (lane >= room && lane < n) g.stage[lane - room] = mine;
+  g.stage_n = n - room; g.full = room < n;
+  RT_WAVE_SYNC()
+}
 
 // Every lane of the wave must call (need = false: the lane has no point).  false: the points are too far apart for one
 // walk to pay (max_area_ratio > 0 only) -- nothing was computed and the caller gathers lane by lane.
@@ -330,7 +354,7 @@ struct GatherItems { uint2 *items; uint32_t *count; uint32_t cap; uint32_t tag; 
 // appended to the item queue (tagged split->tag) for other waves to serve -- a gather next to a lamp has a million
 // photons in its ball, and one wave takes 64 nodes per global round trip.
 RT_D bool gather_map_wave(const DevMap &M, bool need, V3<float> x, V3<float> nrm, double r, float max_area_ratio, WaveGatherLds &L, V3<float> &sum,
-                          uint32_t start = 1u, int split_depth = -1, const GatherItems *split = nullptr) {
+                          uint32_t start = 1u, int split_depth = -1, GatherItems *split = nullptr) {
   const int lane = threadIdx.x & 63;
   sum = mk<float>(0.f, 0.f, 0.f);
   if (!__any(need)) return true;
@@ -350,6 +374,13 @@ RT_D bool gather_map_wave(const DevMap &M, bool need, V3<float> x, V3<float> nrm
   }
   const double r2 = r * r;
   const float r2lo = (float)(r2 * (1.0 - 1e-6)), r2hi = (float)(r2 * (1.0 + 1e-6));      // fp32 d2 is within 3e-7 (relative) of the fp64 one
+  // a second, rounder bound on where the wave's photons lie: within r of a point that is within `reach` of the box's
+  // centre (the corners of the box hold no photon any lane wants); padded well beyond fp32 rounding
+  const float cx = 0.5f * (lo0 + hi0), cy = 0.5f * (lo1 + hi1), cz = 0.5f * (lo2 + hi2);
+  float reach = 0.f;
+  if (need) { const float ex = x.x - cx, ey = x.y - cy, ez = x.z - cz; reach = sqrtf(ex * ex + ey * ey + ez * ez); }
+  reach = wg_max(reach);
+  const float far2 = ((float)r + reach) * ((float)r + reach) * 1.0001f + 1e-12f;
   float sr = 0.f, sg = 0.f, sb = 0.f;
   uint32_t m = 0;
   // (a lane without a point: bounds no distance is below)
@@ -357,8 +388,15 @@ RT_D bool gather_map_wave(const DevMap &M, bool need, V3<float> x, V3<float> nrm
   auto consume = [&]() {
     RT_WAVE_SYNC()
     // the batch in fp32; should any (lane, candidate) distance fall inside the band, the batch again with the fp64 test
+    // (tried: candidates outside every lane's ball skip their payload reads and sums -- 6.04 against 5.91 ms per frame)
     float br = 0.f, bg = 0.f, bb = 0.f;
     bool band = false;
+#ifdef RT_GATHER_PROBE
+    uint32_t inb = 0;
+    for (uint32_t j = 0; j < m; j++) { const float4 cd = L.cand[j]; const float dx = x.x - cd.x, dy = x.y - cd.y, dz = x.z - cd.z; inb += (dx * dx + dy * dy + dz * dz < lo_lane) ? 1u : 0u; }
+    atomicAdd(&g_gather_probe[3], (unsigned long long)inb);
+    if (lane == 0) { atomicAdd(&g_gather_probe[2], (unsigned long long)m); atomicAdd(&g_gather_probe[5], 1ull); }
+#endif
     for (uint32_t j = 0; j < m; j++) {
       const float4 cd = L.cand[j];
       const float dx = x.x - cd.x, dy = x.y - cd.y, dz = x.z - cd.z;
@@ -389,16 +427,26 @@ RT_D bool gather_map_wave(const DevMap &M, bool need, V3<float> x, V3<float> nrm
   RT_WAVE_SYNC()
   uint32_t head = 0, tail = 1;
   bool overflow = false;
+#ifdef RT_GATHER_PROBE
+  { const unsigned long long nb_ = __ballot(need); if (lane == 0) { atomicAdd(&g_gather_probe[0], 1ull); atomicAdd(&g_gather_probe[4], (unsigned long long)__popcll(nb_)); } }
+#endif
   while (head != tail) {
+#ifdef RT_GATHER_PROBE
+    if (lane == 0) atomicAdd(&g_gather_probe[1], 1ull);
+#endif
     if (m + 64 > RT_WG_CAP) consume();
     const uint32_t size = tail - head;
-    const bool lifo = size > RT_WG_FRONT / 2;          // a wide level: take the deepest nodes, and only as many as leave room for their children
-    const uint32_t take = lifo ? min(64u, max(1u, (RT_WG_FRONT - size) / 2u)) : min(64u, size);
+    // a wide level: take the deepest nodes, and only as many as leave room for their children; within 64 entries of a full
+    // queue one node at a time (depth first: the queue then grows by at most one entry per level of the tree below it),
+    // so the queue cannot overflow
+    const bool lifo = size > RT_WG_FRONT / 2;
+    const uint32_t take = lifo ? (size + 64u >= RT_WG_FRONT ? 1u : min(64u, max(1u, (RT_WG_FRONT - 64u - size) / 2u))) : min(64u, size);
     const bool active = (uint32_t)lane < take;
     const uint32_t pos = active ? L.front[((lifo ? tail - take : head) + lane) % RT_WG_FRONT] : 1u;      // 1 <= pos <= n by construction
     if (lifo) tail -= take; else head += take;
     const float4 nd = M.node[pos - 1];
-    const bool inside = active && nd.x >= lo0 && nd.x <= hi0 && nd.y >= lo1 && nd.y <= hi1 && nd.z >= lo2 && nd.z <= hi2;
+    const float fx = nd.x - cx, fy = nd.y - cy, fz = nd.z - cz;
+    const bool inside = active && nd.x >= lo0 && nd.x <= hi0 && nd.y >= lo1 && nd.y <= hi1 && nd.z >= lo2 && nd.z <= hi2 && fx * fx + fy * fy + fz * fz <= far2;
     const unsigned long long mi = __ballot(inside);
     if (inside) {
       const uint32_t at = m + (uint32_t)__popcll(mi & (((unsigned long long)1 << lane) - 1));
@@ -417,16 +465,19 @@ RT_D bool gather_map_wave(const DevMap &M, bool need, V3<float> x, V3<float> nrm
     bool gr = active && 2ull * pos + 1 <= n && !(hid < pd);
     const bool at_split = split && active && (31 - __clz((int)pos)) + 1 == split_depth;     // (the nodes of a step may lie on different levels)
     if (__any(at_split && (gl || gr))) {                                               // (wave-uniform)
-      // these children are other waves' work: one item each, while the queue has room
-      const uint32_t mine = at_split ? (gl ? 1u : 0u) + (gr ? 1u : 0u) : 0u;
-      uint32_t before = mine;                                                          // inclusive prefix sum over the lanes
-      for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(before, o, 64); if (lane >= o) before += v; }
-      const uint32_t all = __shfl(before, 63, 64);
-      uint32_t base = 0;
-      if (lane == 0) base = atomicAdd(split->count, all);
-      base = __shfl(base, 0, 64) + before - mine;
-      if (at_split && gl) { if (base < split->cap) { split->items[base] = make_uint2(split->tag, 2 * pos); gl = false; } base++; }
-      if (at_split && gr) { if (base < split->cap) { split->items[base] = make_uint2(split->tag, 2 * pos + 1); gr = false; } }
+      // these children are other waves' work: one item each, staged in LDS and appended to the frame's list a stageful at
+      // a time.  Lower children, then upper children: at most 64 of either, so a (flushed) stage always has room -- only a
+      // frame whose list is full keeps children for this wave to walk
+      for (int side = 0; side < 2; side++) {
+        const bool child = at_split && (side ? gr : gl);
+        const unsigned long long mc_ = __ballot(child);
+        if (mc_ == 0ull) continue;
+        const uint32_t cnt = (uint32_t)__popcll(mc_);
+        if (split->stage_n + cnt > RT_WG_STAGE) gather_items_flush(*split);
+        const uint32_t at = split->stage_n + (uint32_t)__popcll(mc_ & (((unsigned long long)1 << lane) - 1));
+        if (child && at < RT_WG_STAGE) { split->stage[at] = make_uint2(split->tag, 2 * pos + (uint32_t)side); if (side) gr = false; else gl = false; }
+        split->stage_n = min(split->stage_n + cnt, (uint32_t)RT_WG_STAGE);
+      }
     }
     const unsigned long long ml = __ballot(gl), mr = __ballot(gr);
     const uint32_t cl = (uint32_t)__popcll(ml), cr = (uint32_t)__popcll(mr);
@@ -437,6 +488,9 @@ RT_D bool gather_map_wave(const DevMap &M, bool need, V3<float> x, V3<float> nrm
     tail += cl + cr;
     RT_WAVE_SYNC()
   }
+#ifdef RT_GATHER_PROBE
+  if (overflow && lane == 0) atomicAdd(&g_gather_probe[6], 1ull);
+#endif
   if (overflow) return false;
   consume();
   sum = mk<float>(sr, sg, sb);
@@ -1304,7 +1358,8 @@ __global__ void __launch_bounds__(256) k_tail_persistent(DevScene<T> S, PathSoA<
 // brightest displayable value).  A partial sum beyond +-2^30 is clamped to that and counted in the frame's gather_saturations,
 // a NaN is left out and counted (C.gsat) -- the gather-in-place path would return inf / NaN there, which the resolve clamps or
 // zeroes as well; the count tells a caller that the two routes may differ.
-RT_D void gather_accumulate(const TraceCfg &C, uint32_t p, float4 albedo, V3<float> sd, V3<float> sc) {
+// a partial sum in the accumulators' fixed-point units (clamped and counted as described above)
+RT_D void gather_quantise(const TraceCfg &C, float4 albedo, V3<float> sd, V3<float> sc, long long k[3]) {
   const float PI_ = 3.141592653589793f;
   const float dArea = PI_ * (float)(C.diffuse_radius * C.diffuse_radius), cArea = PI_ * (float)(C.caustic_radius * C.caustic_radius);
   const float lc[3] = { albedo.x, albedo.y, albedo.z }, d3[3] = { sd.x, sd.y, sd.z }, c3[3] = { sc.x, sc.y, sc.z };
@@ -1312,10 +1367,17 @@ RT_D void gather_accumulate(const TraceCfg &C, uint32_t p, float4 albedo, V3<flo
     const double f = ((double)(d3[c] * lc[c] / dArea) + (double)(c3[c] * lc[c] / cArea)) * RT_GACC_SCALE;
     const double lim = 1073741824.0 * RT_GACC_SCALE;            // 2^30 units: two such partial sums still fit
     const bool ok = f == f && f > -lim && f < lim;
-    const long long k = ok ? __double2ll_rn(f) : (f == f ? __double2ll_rn(f < 0 ? -lim : lim) : 0ll);
+    k[c] = ok ? __double2ll_rn(f) : (f == f ? __double2ll_rn(f < 0 ? -lim : lim) : 0ll);
     if (!ok && C.gsat) atomicAdd(C.gsat, 1ull);
-    if (k) atomicAdd((unsigned long long *)&C.gacc[(size_t)p * 3 + c], (unsigned long long)k);
   }
+}
+RT_D void gather_add(const TraceCfg &C, uint32_t p, const long long k[3]) {
+  for (int c = 0; c < 3; c++) if (k[c]) atomicAdd((unsigned long long *)&C.gacc[(size_t)p * 3 + c], (unsigned long long)k[c]);
+}
+RT_D void gather_accumulate(const TraceCfg &C, uint32_t p, float4 albedo, V3<float> sd, V3<float> sc) {
+  long long k[3];
+  gather_quantise(C, albedo, sd, sc, k);
+  gather_add(C, p, k);
 }
 
 // Serves the gather requests of a frame (TraceCfg::gq): one lane per request, a wave's 64 requests together where
@@ -1326,6 +1388,9 @@ static __global__ void __launch_bounds__(256) k_gather_deferred(TraceCfg C, DevM
   const uint32_t total = min(*C.gq_count, C.gq_cap);
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if ((i & ~63u) >= total) return;                           // (wave-uniform)
+#ifdef RT_GATHER_PROBE
+  const long long probe_t0 = clock64();
+#endif
   bool need = i < total;
   uint32_t r = need ? (C.gq_order ? C.gq_order[i] : i) : 0u;
   if (r >= C.gq_cap) { r = 0; need = false; }                // (never true)
@@ -1342,18 +1407,36 @@ static __global__ void __launch_bounds__(256) k_gather_deferred(TraceCfg C, DevM
   const float ratio = sorted ? 0.f : C.wave_gather_ratio;
   const bool coop = sorted || C.wave_gather_ratio > 0.f;
   GatherItems it = items;
+  it.stage = L.stage; it.stage_n = 0; it.full = false;
+  // (Tried: halves, quarters or eighths of the wave walk on their own when their boxes are much smaller than the whole
+  // wave's -- 11 % fewer candidates, the same frame time; the first 511 nodes of both trees in LDS -- the same time.)
   it.tag = i >> 6;
   if (__any(nd) && !(coop && gather_map_wave(Md, nd, hit, nrm, C.diffuse_radius, ratio, L, sd, 1u, split_d, (sorted && split_d > 0) ? &it : nullptr)) && nd)
     sd = gather_map<float>(Md, hit, nrm, C.diffuse_radius);
   it.tag = (i >> 6) | 0x80000000u;
   if (__any(nc) && !(coop && gather_map_wave(Mc, nc, hit, nrm, C.caustic_radius, ratio, L, sc, 1u, split_c, (sorted && split_c > 0) ? &it : nullptr)) && nc)
     sc = gather_map<float>(Mc, hit, nrm, C.caustic_radius);
+  // the wave's items go to the frame's list together; any the list has no room for are served here
+  gather_items_flush(it);
+  for (uint32_t k = 0; k < it.stage_n; k++) {               // (wave-uniform; normally no iteration)
+    const uint2 item = it.stage[k];
+    const bool caustic = item.x >> 31;
+    V3<float> part;
+    (void)gather_map_wave(caustic ? Mc : Md, caustic ? nc : nd, hit, nrm, caustic ? C.caustic_radius : C.diffuse_radius, 0.f, L, part, item.y);
+    if (caustic ? nc : nd) { if (caustic) sc = sc + part; else sd = sd + part; }
+  }
+#ifdef RT_GATHER_PROBE
+  if ((threadIdx.x & 63) == 0) { const unsigned long long dt_ = (unsigned long long)(clock64() - probe_t0); atomicMax(&g_gather_probe[7], dt_); atomicAdd(&g_gather_hist[63 - __clzll((long long)(dt_ | 1ull))], 1ull); }
+#endif
   if (!need || p >= C.n_paths) return;
   gather_accumulate(C, p, q2, sd, sc);
 }
 
 // The items k_gather_deferred has split off: persistent waves, each taking the next item while there are any (the
 // cursor and the item count live in device memory; the count is final when this kernel starts).
+// (Tried: a wave takes 4, 8 or 16 consecutive items at a time and keeps the requests and their sums in registers while
+// the items name the same requests -- 6.95, 8.5, 11.4 against 5.99 ms per frame: consecutive items cost alike, so runs of
+// them undo the balance that taking items one by one gives.)
 static __global__ void __launch_bounds__(256) k_gather_items(TraceCfg C, DevMap Md, DevMap Mc, GatherItems items, uint32_t *cursor) {
   __shared__ WaveGatherLds wg_lds[4];
   const int lane = threadIdx.x & 63;
@@ -1382,13 +1465,34 @@ static __global__ void __launch_bounds__(256) k_gather_items(TraceCfg C, DevMap 
   }
 }
 
-// Sort keys of the requests: 27-bit Morton code of the point in cells of `cell` (9 bits an axis around the origin, clamped;
-// the sort only has to bring neighbours together), then the path and the bounce, which make the order -- and with it
-// the groups of 64 and the order of every sum -- the same whatever order the requests were queued in; all ones for the
-// unused slots of the queue.
-RT_D uint32_t spread9(uint32_t v) {
-  v &= 511u; v = (v | (v << 16)) & 0x030000FFu; v = (v | (v << 8)) & 0x0300F00Fu; v = (v | (v << 4)) & 0x030C30C3u; v = (v | (v << 2)) & 0x09249249u;
+// Sort keys of the requests: 30-bit Hilbert index of the point in cells of `cell` (10 bits an axis around the origin,
+// clamped; the sort only has to bring neighbours together), then the path and the bounce, which make the order -- and
+// with it the groups of 64 and the order of every sum -- the same whatever order the requests were queued in; all ones
+// for the unused slots of the queue.  Hilbert rather than Morton order: consecutive cells of the curve are always
+// neighbours in space, so the 64 requests of a wave do not straddle one of the Z curve's jumps and the box around their
+// balls (what the wave's walk collects candidates from) stays close to one ball's.
+// cells of the keys per (largest) gather radius
+#define RT_GATHER_CELLS_PER_RADIUS 8.0
+RT_D uint32_t spread10(uint32_t v) {
+  v &= 1023u; v = (v | (v << 16)) & 0x030000FFu; v = (v | (v << 8)) & 0x0300F00Fu; v = (v | (v << 4)) & 0x030C30C3u; v = (v | (v << 2)) & 0x09249249u;
   return v;
+}
+// (J. Skilling, "Programming the Hilbert curve", 2004: axes to transposed index, then the bits interleaved)
+RT_D uint32_t hilbert30(uint32_t x, uint32_t y, uint32_t z) {
+  uint32_t X[3] = { x & 1023u, y & 1023u, z & 1023u };
+  for (uint32_t Q = 512u; Q > 1u; Q >>= 1) {
+    const uint32_t P = Q - 1u;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      if (X[i] & Q) X[0] ^= P;
+      else { const uint32_t t = (X[0] ^ X[i]) & P; X[0] ^= t; X[i] ^= t; }
+    }
+  }
+  X[1] ^= X[0]; X[2] ^= X[1];
+  uint32_t t = 0;
+  for (uint32_t Q = 512u; Q > 1u; Q >>= 1) if (X[2] & Q) t ^= Q - 1u;
+  X[0] ^= t; X[1] ^= t; X[2] ^= t;
+  return (spread10(X[0]) << 2) | (spread10(X[1]) << 1) | spread10(X[2]);
 }
 static __global__ void __launch_bounds__(256) k_gather_keys(TraceCfg C, float inv_cell, unsigned long long *keys, uint32_t *vals) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1397,9 +1501,9 @@ static __global__ void __launch_bounds__(256) k_gather_keys(TraceCfg C, float in
   unsigned long long key = ~0ull;
   if (i < total) {
     const float4 q0 = C.gq[(size_t)i * 3], q1 = C.gq[(size_t)i * 3 + 1];
-    auto cellof = [&](float v) { const float c = v * inv_cell + 256.0f; return (uint32_t)(c < 0.f ? 0.f : (c > 511.f ? 511.f : c)); };   // (NaN -> 0)
-    const uint32_t morton = spread9(cellof(q0.x)) | (spread9(cellof(q0.y)) << 1) | (spread9(cellof(q0.z)) << 2);
-    key = ((unsigned long long)morton << 37) | ((unsigned long long)(__float_as_uint(q0.w) & 0x7FFFFFFFu) << 6) | ((__float_as_uint(q1.w) >> 2) & 63u);
+    auto cellof = [&](float v) { const float c = v * inv_cell + 512.0f; return (uint32_t)(c < 0.f ? 0.f : (c > 1023.f ? 1023.f : c)); };   // (NaN -> 0)
+    const uint32_t h = hilbert30(cellof(q0.x), cellof(q0.y), cellof(q0.z));
+    key = ((unsigned long long)h << 34) | ((unsigned long long)(__float_as_uint(q0.w) & 0x0FFFFFFFu) << 6) | ((__float_as_uint(q1.w) >> 2) & 63u);
   }
   keys[i] = key; vals[i] = i;
 }
