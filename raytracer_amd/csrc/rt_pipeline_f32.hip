@@ -26,9 +26,10 @@ int pl_intersect_pairs_fast(rt_ctx *ctx, const rt_params *p, uint32_t n, const d
 
 // ---- stand-alone radius gathers through the request queue
 // hits: nq x 9 floats (point, normal, albedo 0..255); request i serves query i ("path" i)
-__global__ void __launch_bounds__(256) k_requests_from_hits(const float *hits, uint32_t nq, float4 *gq) {
+__global__ void __launch_bounds__(256) k_requests_from_hits(const float *hits, uint32_t nq, float4 *gq, uint32_t *valid) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nq) return;
+  valid[i] = 1u;
   const float *h = hits + (size_t)i * 9;
   gq[(size_t)i * 3] = make_float4(h[0], h[1], h[2], __uint_as_float(i));
   gq[(size_t)i * 3 + 1] = make_float4(h[3], h[4], h[5], __uint_as_float(1u));          // the "diffuse" slot of the request; bounce 0
@@ -44,28 +45,29 @@ int pl_gather_radius_queued(rt_photon_map *m, DevMem &ws, DevMem &sort_tmp, cons
   size_t off = 0;
   auto carve = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
   const uint32_t items_cap = (uint32_t)std::min<size_t>(std::max<size_t>(nq, 1u << 16), 1u << 22);
-  const size_t o_hdr = carve(256), o_gq = carve((size_t)nq * 48), o_gacc = carve((size_t)nq * 24), o_kin = carve((size_t)nq * 8), o_kout = carve((size_t)nq * 8),
-               o_vin = carve((size_t)nq * 4), o_vout = carve((size_t)nq * 4), o_items = carve((size_t)items_cap * 8);
+  const uint32_t items_shard = (items_cap / RT_ITEM_SHARDS) * 2u;
+  const size_t o_hdr = carve(RT_GQ_HEADER_BYTES), o_gq = carve((size_t)nq * 48), o_valid = carve((size_t)nq * 4), o_gacc = carve((size_t)nq * 24), o_kin = carve((size_t)nq * 8), o_kout = carve((size_t)nq * 8),
+               o_vin = carve((size_t)nq * 4), o_vout = carve((size_t)nq * 4), o_items = carve((size_t)items_shard * RT_ITEM_SHARDS * 8);
   RT_HIP(ctx, ws.reserve(off));
   char *base = (char *)ws.p;
   TraceCfg C = {};
   C.diffuse_radius = r; C.caustic_radius = r; C.n_paths = nq; C.wave_gather_ratio = (float)K.wave_gather;
   C.gq_count = (uint32_t *)(base + o_hdr); C.gq = (float4 *)(base + o_gq); C.gq_cap = nq; C.gacc = (long long *)(base + o_gacc);
-  const uint32_t hdr[4] = { nq, 0u, 0u, 0u };                 // requests, work items, item cursor
-  RT_HIP(ctx, hipMemcpyAsync(C.gq_count, hdr, 16, hipMemcpyHostToDevice, ctx->stream));
+  C.gq_valid = (uint32_t *)(base + o_valid); C.gq_first = nq;         // request i sits in slot i
+  RT_HIP(ctx, hipMemsetAsync(C.gq_count, 0, RT_GQ_HEADER_BYTES, ctx->stream));
   RT_HIP(ctx, hipMemsetAsync(C.gacc, 0, (size_t)nq * 24, ctx->stream));
-  RT_LAUNCH(ctx, "gather_requests", k_requests_from_hits, div_up(nq, 256), 256, hits_dev, nq, C.gq);
+  RT_LAUNCH(ctx, "gather_requests", k_requests_from_hits, div_up(nq, 256), 256, hits_dev, nq, C.gq, C.gq_valid);
   unsigned long long *kin = (unsigned long long *)(base + o_kin), *kout = (unsigned long long *)(base + o_kout);
   uint32_t *vin = (uint32_t *)(base + o_vin), *vout = (uint32_t *)(base + o_vout);
   RT_LAUNCH(ctx, "gather_keys", k_gather_keys, div_up(nq, 256), 256, C, (float)(RT_GATHER_CELLS_PER_RADIUS / r), kin, vin);
   { KernelTimer timer_(ctx, "gather_sort"); RT_TRY(rt_sort_pairs_u64(ctx, sort_tmp, kin, kout, vin, vout, nq)); }
   C.gq_order = vout;
-  GatherItems items; items.items = (uint2 *)(base + o_items); items.count = C.gq_count + 1; items.cap = K.gather_split > 0 ? items_cap : 0; items.tag = 0; items.stage = nullptr; items.stage_n = 0; items.full = false;
+  GatherItems items; items.items = (uint2 *)(base + o_items); items.count = C.gq_count + RT_ITEM_WORDS; items.cap = K.gather_split > 0 ? items_shard : 0; items.tag = 0; items.stage = nullptr; items.stage_n = 0; items.full = false;
   int split = 0;
   if (K.gather_split > 0) while (((uint64_t)m->n >> split) > (uint64_t)K.gather_split && split < 24) split++;
   DevMap none = {};
   RT_LAUNCH(ctx, "gather_deferred", k_gather_deferred, div_up(nq, 256), 256, C, m->view(), none, items, split, 0);
-  if (items.cap) RT_LAUNCH(ctx, "gather_items", k_gather_items, 256 * RT_GATHER_ITEM_WGS, 256, C, m->view(), none, items, C.gq_count + 2);
+  if (items.cap) RT_LAUNCH(ctx, "gather_items", k_gather_items, 256 * RT_GATHER_ITEM_WGS, 256, C, m->view(), none, items, C.gq_count + RT_ITEM_WORDS * (1u + RT_ITEM_SHARDS));
   RT_LAUNCH(ctx, "gather_to_rgb", k_accumulators_to_rgb, div_up((uint64_t)nq * 3, 256), 256, (const long long *)C.gacc, nq * 3, rgb_dev);
   RT_HIP(ctx, hipGetLastError());
   return RT_OK;

@@ -139,16 +139,18 @@ static int trace_tile_mode(rt_scene *sc, int slot, const rt_params *p, DevMap md
   C.band_first = band_shift ? (uint32_t)(p->band_rows * p->band_index) : 0u;
   C.fuse_resolve = (!WHITTED && p->sub_sample == 1) ? 1 : 0; C.pre = pre; C.post = post; C.rgba8 = rgba8;
   if (!p->use_photon_maps) { md.n = 0; mc.n = 0; }
-  C.gq = nullptr; C.gq_count = nullptr; C.gq_cap = 0; C.gacc = nullptr; C.gq_order = nullptr; C.gsat = &ctr->gather_saturations;
+  C.gq = nullptr; C.gq_count = nullptr; C.gq_cap = 0; C.gacc = nullptr; C.gq_order = nullptr; C.gq_valid = nullptr; C.gq_first = 0; C.gsat = &ctr->gather_saturations;
   bool defer = false;
   if constexpr (sizeof(T) == 4 && FULL && !WHITTED) {
     defer = p->use_photon_maps && (md.n || mc.n) && (K.defer_gathers < 0 ? (uint64_t)md.n + mc.n >= 200000u : K.defer_gathers != 0);
     if (defer) {                                              // request queue (a counter in its first 256 bytes) and per-path accumulators
       const uint32_t gq_cap = (uint32_t)std::min<size_t>(std::max<size_t>(2 * n_paths, 4096), (size_t)1 << 26);      // (requests beyond it are gathered where they are shaded)
-      RT_HIP(ctx, W.gq.reserve(256 + (size_t)gq_cap * 48));
+      RT_HIP(ctx, W.gq.reserve(RT_GQ_HEADER_BYTES + (size_t)gq_cap * 52));
       RT_HIP(ctx, W.gacc.reserve(n_paths * 3 * 8));
-      C.gq_count = W.gq.as<uint32_t>(); C.gq = (float4 *)((char *)W.gq.p + 256); C.gq_cap = gq_cap; C.gacc = W.gacc.as<long long>();
-      RT_HIP(ctx, hipMemsetAsync(C.gq_count, 0, 16, ctx->stream));      // requests, work items, item cursor
+      C.gq_count = W.gq.as<uint32_t>(); C.gq = (float4 *)((char *)W.gq.p + RT_GQ_HEADER_BYTES); C.gq_cap = gq_cap; C.gacc = W.gacc.as<long long>();
+      C.gq_valid = (uint32_t *)((char *)W.gq.p + RT_GQ_HEADER_BYTES + (size_t)gq_cap * 48); C.gq_first = (uint32_t)std::min<size_t>(n_paths, gq_cap);
+      RT_HIP(ctx, hipMemsetAsync(C.gq_count, 0, RT_GQ_HEADER_BYTES, ctx->stream));      // later requests; the item shards' lengths and cursors
+      RT_HIP(ctx, hipMemsetAsync(C.gq_valid, 0, (size_t)gq_cap * 4, ctx->stream));
       RT_HIP(ctx, hipMemsetAsync(C.gacc, 0, n_paths * 3 * 8, ctx->stream));
       C.fuse_resolve = 0;                                     // the resolve pass adds the accumulators
     }
@@ -342,17 +344,17 @@ static int trace_tile_mode(rt_scene *sc, int slot, const rt_params *p, DevMap md
       C.gq_order = vout;
     }
     // subtrees of at most ~4096 photons become work items of their own (option gather_split = that size; 0: no splitting)
-    GatherItems items; items.items = nullptr; items.count = C.gq_count + 1; items.cap = 0; items.tag = 0; items.stage = nullptr; items.stage_n = 0; items.full = false;
+    GatherItems items; items.items = nullptr; items.count = C.gq_count + RT_ITEM_WORDS; items.cap = 0; items.tag = 0; items.stage = nullptr; items.stage_n = 0; items.full = false;
     int split_d = 0, split_c = 0;
     if (K.gather_sort && K.gather_split > 0) {
       auto depth_for = [&](uint32_t n) { int d = 0; while (((uint64_t)n >> d) > (uint64_t)K.gather_split && d < 24) d++; return d; };
       split_d = md.n ? depth_for(md.n) : 0; split_c = mc.n ? depth_for(mc.n) : 0;
-      items.cap = (uint32_t)std::min<size_t>(std::max<size_t>(n_paths, 1u << 16), 1u << 22);
-      RT_HIP(ctx, W.gitems.reserve((size_t)items.cap * 8));
+      items.cap = (uint32_t)(std::min<size_t>(std::max<size_t>(n_paths, 1u << 16), 1u << 22) / RT_ITEM_SHARDS) * 2u;      // per shard (the shards fill unevenly)
+      RT_HIP(ctx, W.gitems.reserve((size_t)items.cap * RT_ITEM_SHARDS * 8));
       items.items = W.gitems.as<uint2>();
     }
     RT_LAUNCH(ctx, "gather_deferred", k_gather_deferred, div_up(C.gq_cap, 256), 256, C, md, mc, items, split_d, split_c);
-    if (items.cap) RT_LAUNCH(ctx, "gather_items", k_gather_items, 256 * RT_GATHER_ITEM_WGS, 256, C, md, mc, items, C.gq_count + 2);
+    if (items.cap) RT_LAUNCH(ctx, "gather_items", k_gather_items, 256 * RT_GATHER_ITEM_WGS, 256, C, md, mc, items, C.gq_count + RT_ITEM_WORDS * (1u + RT_ITEM_SHARDS));
   }
   if (WHITTED)
     RT_LAUNCH(ctx, "resolve", k_resolve_a<T>, div_up(n_pixels, 256), 256, P, C, levels, (uint32_t)n_paths, (int)p->max_depth, (int)n_pixels,
@@ -397,6 +399,7 @@ static int trace_tile_mode(rt_scene *sc, int slot, const rt_params *p, DevMap md
     for (uint32_t b = 0; b < (direct ? 1u : wave_bounces); b++) rays += hcounts[b];
     for (int k = 0; k < RT_CTR_SLOTS; k++) { tail += hc.tail_rays[k]; iters = hc.max_iter[k] > iters ? hc.max_iter[k] : iters; }
     stats->rays = rays + tail; stats->bounces = (direct ? 1u : wave_bounces) + iters;
+    for (int k = 0; k < RT_CTR_SLOTS; k++) { hc.shadow_rays += hc.prim_tests[k * 16 + 1]; hc.gathers += hc.prim_tests[k * 16 + 2]; hc.stack_overflows += hc.prim_tests[k * 16 + 3]; }
     stats->shadow_rays = hc.shadow_rays; stats->gathers = hc.gathers;
     stats->stack_overflows = hc.stack_overflows; stats->gather_saturations = hc.gather_saturations;
     stats->tail_rays = whole_frame ? tail - n_paths : tail;       // segments after the first pass that k_tail traced
@@ -500,6 +503,7 @@ int pl_trace_rays(rt_scene *sc, const rt_params *p, DevMap md, DevMap mc, uint32
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     *stats = rt_trace_stats{};
     for (int k = 0; k < RT_CTR_SLOTS; k++) stats->rays += hc.tail_rays[k];
+    for (int k = 0; k < RT_CTR_SLOTS; k++) { hc.shadow_rays += hc.prim_tests[k * 16 + 1]; hc.gathers += hc.prim_tests[k * 16 + 2]; hc.stack_overflows += hc.prim_tests[k * 16 + 3]; }
     stats->shadow_rays = hc.shadow_rays; stats->gathers = hc.gathers; stats->stack_overflows = hc.stack_overflows;
   }
   return RT_OK;

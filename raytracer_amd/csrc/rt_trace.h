@@ -97,7 +97,10 @@ struct TraceCfg {
   // leave a request (3 x float4: point + path, normal, albedo / 255) in gq; k_gather_deferred serves the requests with
   // every lane busy and adds the results to the path's entry of gacc (fixed point, steps of 2^-32: the order of the additions
   // does not matter), which the resolve pass adds to the path's colour.  gq == nullptr: gathers where they are shaded.
-  float4 *gq; uint32_t *gq_count; uint32_t gq_cap; long long *gacc;
+  // Slots 0 .. gq_first - 1 belong to the first pass: path p's first hit leaves its request in slot p (no counter: a word
+  // that every wave of a frame adds to costs ~10 ns per wave); later hits take slots gq_first + (*gq_count)++.  gq_valid[slot]
+  // != 0 marks a slot that holds a request of this frame (cleared per frame).
+  float4 *gq; uint32_t *gq_count; uint32_t gq_cap; long long *gacc; uint32_t *gq_valid; uint32_t gq_first;
   unsigned long long *gsat;      // counts the partial sums that left the accumulators' range (gather_accumulate), or nullptr
   const uint32_t *gq_order;      // requests in the order k_gather_deferred serves them (sorted by position), or nullptr
   // fp32 first pass: per workgroup the list of primitives its rays can reach (cull_stride words each: 16 segment words,
@@ -121,7 +124,9 @@ RT_D uint32_t band_row(const TraceCfg &C, uint32_t row) {
 #define RT_MAX_TAIL_ROUNDS 3
 struct TraceCounters {
   unsigned long long shadow_rays, gathers, stack_overflows, gather_saturations, tail_rays[RT_CTR_SLOTS];
-  unsigned long long prim_tests[RT_CTR_SLOTS * 16];   // ray-primitive tests counted by the scans that skip primitives; slot s at [16 s]
+  // per slot s a cache line: [16 s] ray-primitive tests counted by the scans that skip primitives, [16 s + 1] shadow rays,
+  // [16 s + 2] gathers, [16 s + 3] material-stack overflows (flush_tally); the single words above are host-side sums
+  unsigned long long prim_tests[RT_CTR_SLOTS * 16];
   uint32_t max_iter[RT_CTR_SLOTS];          // iterations the longest-lived workgroup of k_tail ran
   // lengths of the sub-queues the first pass ([0]) and the bounce passes after it ([1], [2]) leave (s at [16 s])
   // ([RT_MAX_BOUNCE_PASSES + 1 + r]: paths that launch r of k_tail handed on to launch r + 1)
@@ -141,10 +146,13 @@ RT_D void flush_tally(const ShadeTally &t, TraceCounters *ctr) {
   if (__ballot((a | b | c | e) != 0) == 0) return;
   for (int off = 32; off > 0; off >>= 1) { a += __shfl_down(a, off, 64); b += __shfl_down(b, off, 64); c += __shfl_down(c, off, 64); e += __shfl_down(e, off, 64); }
   if ((threadIdx.x & 63) == 0) {
-    if (e) atomicAdd(&ctr->prim_tests[((blockIdx.x * 8 + (threadIdx.x >> 6)) % RT_CTR_SLOTS) * 16], e);   // one cache line per slot
-    if (a) atomicAdd(&ctr->shadow_rays, a);
-    if (b) atomicAdd(&ctr->gathers, b);
-    if (c) atomicAdd(&ctr->stack_overflows, c);
+    // one cache line per slot, the four tallies side by side in it: every wave of a frame ends here, and adds to ONE word
+    // from tens of thousands of waves take ~10 ns each, one after the other (0.3 ms per tally on a 1080p frame)
+    unsigned long long *line = &ctr->prim_tests[((blockIdx.x * 8 + (threadIdx.x >> 6)) % RT_CTR_SLOTS) * 16];
+    if (e) atomicAdd(line, e);
+    if (a) atomicAdd(line + 1, a);
+    if (b) atomicAdd(line + 2, b);
+    if (c) atomicAdd(line + 3, c);
   }
 }
 
@@ -327,8 +335,14 @@ RT_D float wg_max(float v) { for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shf
 
 // Work items of the split gather: the subtree at heap position `y` of map (x >> 31) for the 64 requests of wave
 // (x & 0x7FFFFFFF) of the sorted request queue.
-// A wave collects the items of its walks in LDS (stage, stage_n of them) and appends them together: the list's length is
-// ONE word, and an atomic per walk step from every wave of the frame made that word the kernel's bottleneck.
+// A wave collects the items of its walks in LDS (stage, stage_n of them) and appends them together, and the frame's list is
+// cut into RT_ITEM_SHARDS lists with a length word (and, for the consumer, a cursor word) each, a cache line apart: a word
+// that every wave of the frame adds to -- ~10 ns per add, one after the other -- was the bottleneck of both kernels.
+// items: shard s at items + s * cap (cap items each); count: shard s's length at count[s * RT_ITEM_WORDS].
+#define RT_ITEM_SHARDS 64u
+#define RT_ITEM_WORDS 32u                  // words between two shards' counters: 128 bytes
+// the header of a frame's request queue: word 0 counts the later requests, then a length word and a cursor word per shard
+#define RT_GQ_HEADER_BYTES ((size_t)RT_ITEM_WORDS * (1u + 2u * RT_ITEM_SHARDS) * 4u)
 struct GatherItems { uint2 *items; uint32_t *count; uint32_t cap; uint32_t tag; uint2 *stage; uint32_t stage_n; bool full; };
 // Appends the wave's staged items to the frame's list (all lanes call).  Items the list has no room for stay staged, at the
 // front, and `full` is set: nothing more is appended, the caller serves what is left itself.
@@ -336,12 +350,13 @@ RT_D void gather_items_flush(GatherItems &g) {
   if (g.stage_n == 0 || g.full) return;
   const uint32_t lane = threadIdx.x & 63u, n = g.stage_n;
   RT_WAVE_SYNC()
+  const uint32_t shard = (blockIdx.x * 4u + (threadIdx.x >> 6)) % RT_ITEM_SHARDS;
   uint32_t base = 0;
-  if (lane == 0) base = atomicAdd(g.count, n);
+  if (lane == 0) base = atomicAdd(g.count + shard * RT_ITEM_WORDS, n);
   base = __shfl(base, 0, 64);
   const uint32_t room = base < g.cap ? min(g.cap - base, n) : 0u;
   const uint2 mine = lane < n ? g.stage[lane] : make_uint2(0u, 0u);          // (RT_WG_STAGE <= 64: one item a lane)
-  if (lane < room) g.items[base + lane] = mine;
+  if (lane < room) g.items[(size_t)shard * g.cap + base + lane] = mine;
   RT_WAVE_SYNC()
   if (lane >= room && lane < n) g.stage[lane - room] = mine;
   g.stage_n = n - room; g.full = room < n;
@@ -560,13 +575,18 @@ RT_D bool shade_body(const DevScene<T> &S, const ScanSrc<T> &G, const TraceCfg &
             if constexpr (sizeof(T) == 4) {
               if (todo && C.gq) {
                 // one slot per lane that is here, reserved by the first of them
-                const unsigned long long here = __ballot(true);
-                const int lane = threadIdx.x & 63, leader = __ffsll((long long)here) - 1;
-                uint32_t base = 0;
-                if (lane == leader) base = atomicAdd(C.gq_count, (uint32_t)__popcll(here));
-                base = __shfl(base, leader, 64);
-                const uint32_t slot = base + (uint32_t)__popcll(here & (((unsigned long long)1 << lane) - 1));
+                const int lane = threadIdx.x & 63;
+                uint32_t slot = p;                                                         // a path's first hit: its own slot
+                if (bounce != 0 || p >= C.gq_first) {                                      // (wave-uniform in practice: a pass traces one bounce)
+                  const unsigned long long later = __ballot(true);
+                  const int leader2 = __ffsll((long long)later) - 1;
+                  uint32_t base = 0;
+                  if (lane == leader2) base = atomicAdd(C.gq_count, (uint32_t)__popcll(later));
+                  base = __shfl(base, leader2, 64);
+                  slot = C.gq_first + base + (uint32_t)__popcll(later & (((unsigned long long)1 << lane) - 1));
+                }
                 if (slot < C.gq_cap) {                                                     // (else: gathered here, below)
+                  C.gq_valid[slot] = 1u;
                   float4 *q = C.gq + (size_t)slot * 3;
                   q[0] = make_float4(hit.x, hit.y, hit.z, __uint_as_float(p));
                   q[1] = make_float4(n.x, n.y, n.z, __uint_as_float((uint32_t)todo | ((uint32_t)bounce << 2)));
@@ -1385,7 +1405,7 @@ RT_D void gather_accumulate(const TraceCfg &C, uint32_t p, float4 albedo, V3<flo
 // area) x albedo goes to the path's fixed-point accumulators.  The grid is an upper bound (gq_cap requests).
 static __global__ void __launch_bounds__(256) k_gather_deferred(TraceCfg C, DevMap Md, DevMap Mc, GatherItems items, int split_d, int split_c) {
   __shared__ WaveGatherLds wg_lds[4];
-  const uint32_t total = min(*C.gq_count, C.gq_cap);
+  const uint32_t total = min(C.gq_first + *C.gq_count, C.gq_cap);
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if ((i & ~63u) >= total) return;                           // (wave-uniform)
 #ifdef RT_GATHER_PROBE
@@ -1394,6 +1414,8 @@ static __global__ void __launch_bounds__(256) k_gather_deferred(TraceCfg C, DevM
   bool need = i < total;
   uint32_t r = need ? (C.gq_order ? C.gq_order[i] : i) : 0u;
   if (r >= C.gq_cap) { r = 0; need = false; }                // (never true)
+  if (need && !C.gq_valid[r]) need = false;                  // a first-pass slot whose path left no request (sorted: these come last)
+  if (!__any(need)) return;
   const float4 *q = C.gq + (size_t)r * 3;
   const float4 q0 = q[0], q1 = q[1], q2 = q[2];
   const V3<float> hit = mk<float>(q0.x, q0.y, q0.z), nrm = mk<float>(q1.x, q1.y, q1.z);
@@ -1441,27 +1463,35 @@ static __global__ void __launch_bounds__(256) k_gather_items(TraceCfg C, DevMap 
   __shared__ WaveGatherLds wg_lds[4];
   const int lane = threadIdx.x & 63;
   WaveGatherLds &L = wg_lds[threadIdx.x >> 6];
-  const uint32_t total = min(*C.gq_count, C.gq_cap), n_items = min(*items.count, items.cap);
-  for (;;) {
-    uint32_t k = 0;
-    if (lane == 0) k = atomicAdd(cursor, 1u);
-    k = __shfl(k, 0, 64);
-    if (k >= n_items) break;
-    const uint2 item = items.items[k];
-    const bool caustic = item.x >> 31;
-    const uint32_t i = (item.x & 0x7FFFFFFFu) * 64u + (uint32_t)lane;
-    bool need = i < total;
-    uint32_t r = need ? (C.gq_order ? C.gq_order[i] : i) : 0u;
-    if (r >= C.gq_cap) { r = 0; need = false; }              // (never true)
-    const float4 *q = C.gq + (size_t)r * 3;
-    const float4 q0 = q[0], q1 = q[1], q2 = q[2];
-    const V3<float> hit = mk<float>(q0.x, q0.y, q0.z), nrm = mk<float>(q1.x, q1.y, q1.z);
-    const uint32_t p = __float_as_uint(q0.w), todo = need ? (__float_as_uint(q1.w) & 3u) : 0u;
-    const DevMap &M = caustic ? Mc : Md;
-    const bool want = (todo & (caustic ? 2u : 1u)) && M.n && item.y >= 1u && item.y <= M.n;
-    V3<float> sum = mk<float>(0.f, 0.f, 0.f), zero = mk<float>(0.f, 0.f, 0.f);
-    (void)gather_map_wave(M, want, hit, nrm, caustic ? C.caustic_radius : C.diffuse_radius, 0.f, L, sum, item.y >= 1u && item.y <= M.n ? item.y : 1u);
-    if (want && p < C.n_paths) gather_accumulate(C, p, q2, caustic ? zero : sum, caustic ? sum : zero);
+  const uint32_t total = min(C.gq_first + *C.gq_count, C.gq_cap);
+  // every wave starts at a shard of its own and goes round all of them (cursor[s * RT_ITEM_WORDS]: shard s's next item)
+  const uint32_t first_shard = (blockIdx.x * 4u + (threadIdx.x >> 6)) % RT_ITEM_SHARDS;
+  for (uint32_t step = 0; step < RT_ITEM_SHARDS; step++) {
+    const uint32_t shard = (first_shard + step) % RT_ITEM_SHARDS;
+    const uint32_t n_items = min(items.count[shard * RT_ITEM_WORDS], items.cap);
+    const uint2 *list = items.items + (size_t)shard * items.cap;
+    for (;;) {
+      uint32_t k = 0;
+      if (lane == 0) k = atomicAdd(cursor + shard * RT_ITEM_WORDS, 1u);
+      k = __shfl(k, 0, 64);
+      if (k >= n_items) break;
+      const uint2 item = list[k];
+      const bool caustic = item.x >> 31;
+      const uint32_t i = (item.x & 0x7FFFFFFFu) * 64u + (uint32_t)lane;
+      bool need = i < total;
+      uint32_t r = need ? (C.gq_order ? C.gq_order[i] : i) : 0u;
+      if (r >= C.gq_cap) { r = 0; need = false; }            // (never true)
+      if (need && !C.gq_valid[r]) need = false;
+      const float4 *q = C.gq + (size_t)r * 3;
+      const float4 q0 = q[0], q1 = q[1], q2 = q[2];
+      const V3<float> hit = mk<float>(q0.x, q0.y, q0.z), nrm = mk<float>(q1.x, q1.y, q1.z);
+      const uint32_t p = __float_as_uint(q0.w), todo = need ? (__float_as_uint(q1.w) & 3u) : 0u;
+      const DevMap &M = caustic ? Mc : Md;
+      const bool want = (todo & (caustic ? 2u : 1u)) && M.n && item.y >= 1u && item.y <= M.n;
+      V3<float> sum = mk<float>(0.f, 0.f, 0.f), zero = mk<float>(0.f, 0.f, 0.f);
+      (void)gather_map_wave(M, want, hit, nrm, caustic ? C.caustic_radius : C.diffuse_radius, 0.f, L, sum, item.y >= 1u && item.y <= M.n ? item.y : 1u);
+      if (want && p < C.n_paths) gather_accumulate(C, p, q2, caustic ? zero : sum, caustic ? sum : zero);
+    }
   }
 }
 
@@ -1497,9 +1527,9 @@ RT_D uint32_t hilbert30(uint32_t x, uint32_t y, uint32_t z) {
 static __global__ void __launch_bounds__(256) k_gather_keys(TraceCfg C, float inv_cell, unsigned long long *keys, uint32_t *vals) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= C.gq_cap) return;
-  const uint32_t total = min(*C.gq_count, C.gq_cap);
+  const uint32_t total = min(C.gq_first + *C.gq_count, C.gq_cap);
   unsigned long long key = ~0ull;
-  if (i < total) {
+  if (i < total && C.gq_valid[i]) {
     const float4 q0 = C.gq[(size_t)i * 3], q1 = C.gq[(size_t)i * 3 + 1];
     auto cellof = [&](float v) { const float c = v * inv_cell + 512.0f; return (uint32_t)(c < 0.f ? 0.f : (c > 1023.f ? 1023.f : c)); };   // (NaN -> 0)
     const uint32_t h = hilbert30(cellof(q0.x), cellof(q0.y), cellof(q0.z));
