@@ -943,9 +943,10 @@ int pl_emit_counters(rt_scene *sc, bool reset, uint64_t *segments, uint64_t *err
   EmitCounters hc; memset(&hc, 0, sizeof hc);
   if (sc->ws_misc.p) {
     RT_HIP(ctx, hipMemcpyAsync(&hc, sc->ws_misc.p, sizeof hc, hipMemcpyDeviceToHost, ctx->stream));
-    if (reset) RT_HIP(ctx, hipMemsetAsync(sc->ws_misc.p, 0, sizeof hc, ctx->stream));
+    if (reset) { RT_HIP(ctx, hipMemsetAsync(sc->ws_misc.p, 0, 64, ctx->stream)); RT_HIP(ctx, hipMemsetAsync((char *)sc->ws_misc.p + 256, 0, sizeof hc - 256, ctx->stream)); }   // (not the words at byte 64)
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
   }
+  for (int k = 0; k < RT_EMIT_CTR_SLOTS; k++) { hc.segments += hc.slots[k * 16]; hc.errors += hc.slots[k * 16 + 1]; hc.overflows += hc.slots[k * 16 + 2]; }
   if (segments) *segments = hc.segments;
   if (errors) *errors = hc.errors;
   return RT_OK;
@@ -1159,9 +1160,9 @@ static int emit_many_lists(rt_scene *sc, const rt_params *p, int format, rt_phot
   RT_TRY(rt_lists_create(ctx, p, format, &L));
   struct Guard { rt_photon_lists *&l; bool keep = false; ~Guard() { if (!keep) { rt_lists_free(l); l = nullptr; } } } guard{ L };
   RT_TRY(pl_emit_counters(sc, true, nullptr, nullptr));
-  if (!sc->ws_misc.p) { RT_HIP(ctx, sc->ws_misc.alloc(256)); }
+  if (!sc->ws_misc.p) { RT_HIP(ctx, sc->ws_misc.alloc(sizeof(EmitCounters))); }
   unsigned long long *seg_exact = (unsigned long long *)((char *)sc->ws_misc.p + 64);
-  RT_HIP(ctx, hipMemsetAsync(sc->ws_misc.p, 0, 256, ctx->stream));
+  RT_HIP(ctx, hipMemsetAsync(sc->ws_misc.p, 0, sizeof(EmitCounters), ctx->stream));
   uint32_t nd = 0, nc = 0;
   const uint32_t W = L->W;
   for (int phase = 1; phase <= 2 && !st.capped; phase++) {

@@ -14,7 +14,18 @@ struct EmitCfg {
   uint32_t num_diffuse, num_caustic;
   uint64_t seed;
 };
-struct EmitCounters { unsigned long long segments, errors, overflows; };
+// The emission's statistics.  Device code adds to `slots` (wave w: line w % 64, words 0..2 = segments, errors, overflows) --
+// a single word that every wave of a launch adds to when it ends costs ~10 ns per wave, one after the other; the host sums the
+// lines into the three words in front.  (Byte 64: the exact segment count of rt_emit_many*, see there.)
+#define RT_EMIT_CTR_SLOTS 64
+struct EmitCounters { unsigned long long segments, errors, overflows, pad_[29]; unsigned long long slots[RT_EMIT_CTR_SLOTS * 16]; };
+static_assert(sizeof(EmitCounters) == 256 + RT_EMIT_CTR_SLOTS * 128, "the slots start behind the 256 bytes of single words");
+RT_D void emit_tally(EmitCounters *ctr, unsigned long long segments, unsigned long long errors, unsigned long long overflows) {
+  unsigned long long *line = &ctr->slots[((blockIdx.x * 4u + (threadIdx.x >> 6)) % RT_EMIT_CTR_SLOTS) * 16];
+  if (segments) atomicAdd(line, segments);
+  if (errors) atomicAdd(line + 1, errors);
+  if (overflows) atomicAdd(line + 2, overflows);
+}
 
 #define RT_REC_STRIDE 11
 
@@ -149,11 +160,7 @@ __global__ void __launch_bounds__(256, RT_EMIT_MIN_BLOCKS) k_emit(DevScene<T> S,
   for (int off = 32; off > 0; off >>= 1) {
     segments += __shfl_down(segments, off, 64); errors += __shfl_down(errors, off, 64); overflows += __shfl_down(overflows, off, 64);
   }
-  if ((threadIdx.x & 63) == 0) {
-    if (segments) atomicAdd(&ctr->segments, segments);
-    if (errors) atomicAdd(&ctr->errors, errors);
-    if (overflows) atomicAdd(&ctr->overflows, overflows);
-  }
+  if ((threadIdx.x & 63) == 0) emit_tally(ctr, segments, errors, overflows);
 }
 
 // createPhoton(source) / emitPhoton(photon, depth, trackOnlyCaustic, materialStack) for explicit photons, one lane each
@@ -190,9 +197,7 @@ __global__ void __launch_bounds__(64) k_photons_explicit(DevScene<T> S, EmitCfg 
     const int stored = photon_walk<T>(S, G, C, rng, ph, st, depth ? depth[i] : 0, track_only_caustic != 0, rec, segments, errors, overflows);
     kind[i] = (uint8_t)stored;
     if (stored) for (int c = 0; c < RT_REC_STRIDE; c++) r[c] = (double)rec[c];
-    if (segments) atomicAdd(&ctr->segments, segments);
-    if (errors) atomicAdd(&ctr->errors, errors);
-    if (overflows) atomicAdd(&ctr->overflows, overflows);
+    emit_tally(ctr, segments, errors, overflows);
   }
   if (draws) draws[i] = rng.draw;
 }

@@ -548,7 +548,7 @@ int pl_photons_explicit(rt_scene *sc, const rt_params *p, uint32_t n, int domain
                         double *io, uint8_t *kind, uint32_t *draws) {
   rt_ctx *ctx = sc->ctx;
   DevScene<T> &S = SceneOf<T>::get(sc);
-  if (!sc->ws_misc.p) { RT_HIP(ctx, sc->ws_misc.alloc(256)); RT_HIP(ctx, hipMemsetAsync(sc->ws_misc.p, 0, 256, ctx->stream)); }
+  if (!sc->ws_misc.p) { RT_HIP(ctx, sc->ws_misc.alloc(sizeof(EmitCounters))); RT_HIP(ctx, hipMemsetAsync(sc->ws_misc.p, 0, sizeof(EmitCounters), ctx->stream)); }
   EmitCfg C; C.epsilon = working_eps<T>(p); C.max_depth = p->max_depth; C.num_diffuse = p->num_photons_diffuse;
   C.num_caustic = p->num_photons_caustic; C.seed = p->seed;
   RT_LAUNCH(ctx, "photons_explicit", k_photons_explicit<T>, div_up(n, 64), 64, S, C, n, domain, (unsigned long long)first_stream, first_draw, create,
@@ -565,7 +565,7 @@ int pl_emit_batch(rt_scene *sc, const rt_params *p, int phase, uint64_t a0, uint
   RT_HIP(ctx, sc->ws_emit_kind.reserve(count));
   RT_HIP(ctx, sc->ws_emit_seg.reserve(count));
   RT_HIP(ctx, sc->ws_emit_rec.reserve((size_t)count * RT_REC_STRIDE * sizeof(T)));
-  if (!sc->ws_misc.p) { RT_HIP(ctx, sc->ws_misc.alloc(256)); RT_HIP(ctx, hipMemsetAsync(sc->ws_misc.p, 0, 256, ctx->stream)); }
+  if (!sc->ws_misc.p) { RT_HIP(ctx, sc->ws_misc.alloc(sizeof(EmitCounters))); RT_HIP(ctx, hipMemsetAsync(sc->ws_misc.p, 0, sizeof(EmitCounters), ctx->stream)); }
   EmitCfg C; C.epsilon = working_eps<T>(p); C.max_depth = p->max_depth; C.num_diffuse = p->num_photons_diffuse;
   C.num_caustic = p->num_photons_caustic; C.seed = p->seed;
   // persistent waves: as many workgroups as stay resident (RT_EMIT_MIN_BLOCKS per CU), fewer for a small batch; every

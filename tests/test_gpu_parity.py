@@ -109,20 +109,30 @@ def test_scene_scans_f64_exact(rt, preset):
     assert np.array_equal(occ, b["occluded"])
 
 
+# fp32 against the reference's fp64 scans on the golden rays (4096 a preset, half of them starting exactly on a surface),
+# counted, not averaged.  Measured on the MI355X: not one hit / miss / occluder decision differs on any of the four presets,
+# in any of the three scan modes; the slack of 2 is for a grazing ray of another compiler.  Distances: the rays whose fp32
+# distance is off by more than 1e-4 relative are on-surface origins that take the other root of their own sphere or
+# cylinder (same shape, other t): 1 on preset 10, none elsewhere.
+F32_SCAN_EXPECTED = {10: dict(flips=0, far=1), 4: dict(flips=0, far=0), 7: dict(flips=0, far=0), 9: dict(flips=0, far=0)}
+
+
 @pytest.mark.parametrize("preset", [10, 4, 7, 9])
 def test_scene_scans_f32(rt, preset):
     capi, ctx = rt
     b = load_bundle(f"closest_preset{preset}")
     sc = ctx.upload(load_scene(preset))
     p = capi.default_params(precision=capi.PRECISION_F32)
+    exp = F32_SCAN_EXPECTED[preset]
     t, idx = sc.intersect(p, capi.SCAN_CLOSEST, b["ray_o"], b["ray_d"])
-    agree = idx == b["idx_all"]
-    # half of the fixture's rays start exactly on a surface, where t ~ eps decisions differ in fp32
-    assert agree.mean() > 0.97, agree.mean()
-    hit = agree & (idx >= 0)
+    _, idx_nl = sc.intersect(p, capi.SCAN_CLOSEST_NOLIGHT, b["ray_o"], b["ray_d"])
+    _, occ = sc.intersect(p, capi.SCAN_ANY, b["ray_o"], b["ray_d"], b["source_dist"])
+    flips = [int((idx != b["idx_all"]).sum()), int((idx_nl != b["idx_nolight"]).sum()), int((occ != b["occluded"]).sum())]
+    assert max(flips) <= exp["flips"] + 2, flips
+    hit = (idx == b["idx_all"]) & (idx >= 0)
     rel = np.abs(t[hit] - b["t_all"][hit]) / np.maximum(1.0, b["t_all"][hit])
-    # (an on-surface origin may pick the other root of its own sphere/cylinder: same shape, other t)
-    assert np.quantile(rel, 0.99) < 1e-4 and np.median(rel) < 1e-6
+    assert int((rel > 1e-4).sum()) <= exp["far"] + 2, int((rel > 1e-4).sum())
+    assert np.quantile(rel, 0.99) < 5e-6 and np.median(rel) < 1e-6
 
 
 def _slot_boundary_scene(n_prims, width=96, height=64):
@@ -280,21 +290,30 @@ def test_emission_sharded_ranges_concatenate(rt):
 
 
 def test_emission_f32_statistics(rt):
+    """fp32 emission against the reference's lists (10 000 + 10 000 photons), counted.  The streams are keyed by attempt, so
+    an attempt is comparable one to one.  Measured on the MI355X: the phases end 4 and 6 attempts away from the reference's
+    34 109 / 42 136; 9 998 of the 10 000 diffuse and 9 999 of the 10 000 caustic photons are stored by the same attempts
+    (the others: a hit within fp32 rounding of a rim, or a draw within rounding of its threshold, decided the other way --
+    and one such attempt shifts every later list position, hence sets, not positions); of the common attempts 191 / 204
+    store their photon more than 1e-3 away (a walk through glass amplifies the fp32 rounding of its first hit with every
+    bounce), the rest within 2.5e-4 at the 95th percentile."""
     capi, ctx = rt
     sc = ctx.upload(load_scene(10))
     p = capi.default_params(precision=capi.PRECISION_F32, num_photons_diffuse=10000, num_photons_caustic=10000, seed=SEED)
     e = sc.emit_many(p)
     g = load_bundle("photons_c1")
     st = e["stats"]
-    # same keyed streams: almost every attempt takes the same branches as in fp64
-    assert abs(st["attempts_phase1"] - g.meta["stats"]["attempts1"]) < 200
-    assert abs(st["attempts_phase2"] - g.meta["stats"]["attempts2"]) < 400
-    # (one attempt that stores in one build and not in the other shifts every later list position, so compare sets)
-    common = np.intersect1d(e["diffuse_attempt"][:, 1], g["diffuse_tag"][:, 2]).size
-    assert common / g["diffuse_tag"].shape[0] > 0.97, common
-    _, ia, ib = np.intersect1d(e["diffuse_attempt"][:, 1], g["diffuse_tag"][:, 2], return_indices=True)
-    d = np.abs(e["diffuse"][ia][:, :3] - g["diffuse"][ib][:, :3]).max(axis=1)
-    assert np.quantile(d, 0.95) < 1e-3
+    assert abs(st["attempts_phase1"] - g.meta["stats"]["attempts1"]) <= 4 + 16
+    assert abs(st["attempts_phase2"] - g.meta["stats"]["attempts2"]) <= 6 + 16
+    for name, lost, displaced in (("diffuse", 2, 191), ("caustic", 1, 204)):
+        a, gt = e[name + "_attempt"], g[name + "_tag"]
+        ka = a[:, 0].astype(np.int64) * (1 << 40) + a[:, 1].astype(np.int64)           # (phase, attempt)
+        kg = gt[:, 1].astype(np.int64) * (1 << 40) + gt[:, 2].astype(np.int64)
+        common, ia, ib = np.intersect1d(ka, kg, return_indices=True)
+        assert gt.shape[0] - common.size <= lost + 8, (name, common.size)
+        d = np.abs(e[name][ia][:, :3] - g[name][ib][:, :3]).max(axis=1)
+        assert int((d > 1e-3).sum()) <= displaced + 60, (name, int((d > 1e-3).sum()))
+        assert np.quantile(d, 0.95) < 5e-4
 
 
 def test_emission_attempt_cap(rt):
