@@ -542,7 +542,9 @@ RT_D float isect_fast_any(int type, const float *f, V3<float> o, V3<float> d, fl
 // original index, so the result is the all-primitives scan's (boxes are padded; a NaN slab interval counts as hit).
 // (Tried for fp32: every lane first walks on to its next leaf, then the wave tests the leaves type by type with the
 // type-specialised tests -- 2.15 against 2.16 ms on the 10 000-primitive 4K frame: the walk waits for its dependent node
-// loads, not for divergent tests.)
+// loads, not for divergent tests.  Also tried: the wavefront passes' closest-hit scan as persistent waves whose lanes take the
+// next queued ray as soon as their walk ends (the walk as a resumable state, eight nodes at a time) -- 2.73 against 2.17 ms: the
+// one-ray-per-lane kernel needs 20 registers and keeps every SIMD full of waves, which a walk that waits needs more than busy lanes.)
 template <typename T, int MODE> RT_D int scan_bvh(const DevScene<T> &S, V3<T> o, V3<T> d, T eps, T limit, T &t_out, uint32_t *tests) {
   T best = Limits<T>::inf(); int best_idx = -1;
   const T lim = (MODE == 2) ? limit - eps : T(0);
