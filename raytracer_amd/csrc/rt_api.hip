@@ -153,6 +153,8 @@ void rt_shutdown(rt_ctx *ctx) {
   for (int i = 0; i < RT_MAX_IN_FLIGHT; i++) if (ctx->streams[i]) (void)hipStreamSynchronize(ctx->streams[i]);
   for (auto &kv : ctx->events) for (auto &ev : kv.second) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
   for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
+  for (auto &b : ctx->map_pool) (void)hipFree(b.second);
+  ctx->map_pool.clear(); ctx->map_pool_bytes = 0;
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
   for (int i = 0; i < RT_MAX_IN_FLIGHT; i++) if (ctx->frame_done[i]) (void)hipEventDestroy(ctx->frame_done[i]);
   for (int i = 0; i < RT_MAX_IN_FLIGHT; i++) if (ctx->streams[i]) (void)hipStreamDestroy(ctx->streams[i]);

@@ -81,6 +81,26 @@ struct rt_ctx {
   uint32_t *pinned = nullptr;    // small pinned scratch for counters read back each bounce
   RtKnobs knobs;
   DevMem ws_kd;                  // kd-tree build workspace (grow-only)
+  // Device blocks of freed photon maps, kept for the next map of the same size (a map is six allocations of up to 88 bytes a
+  // photon; building a map per frame of an animation, or per benchmark repetition, otherwise spends a fifth of its time in
+  // hipMalloc / hipFree).  At most RT_MAP_POOL_BLOCKS blocks and RT_MAP_POOL_BYTES bytes; rt_shutdown frees them.
+  std::vector<std::pair<size_t, void *>> map_pool;
+  size_t map_pool_bytes = 0;
+  hipError_t pool_take(DevMem &m, size_t bytes) {
+    if (bytes == 0) bytes = 16;
+    for (size_t i = 0; i < map_pool.size(); i++)
+      if (map_pool[i].first == bytes) {
+        m.release(); m.p = map_pool[i].second; m.bytes = bytes;
+        map_pool_bytes -= bytes; map_pool[i] = map_pool.back(); map_pool.pop_back();
+        return hipSuccess;
+      }
+    return m.alloc(bytes);
+  }
+  void pool_give(DevMem &m) {
+    if (!m.p) return;
+    if (map_pool.size() < 24 && map_pool_bytes + m.bytes <= ((size_t)2 << 30)) { map_pool.emplace_back(m.bytes, m.p); map_pool_bytes += m.bytes; m.p = nullptr; m.bytes = 0; }
+    else m.release();
+  }
   hipEvent_t frame_done[RT_MAX_IN_FLIGHT] = {};   // recorded behind the last frame queued on streams[i], i >= 1
   bool frame_pending[RT_MAX_IN_FLIGHT] = {};      // ... and not yet joined into streams[0] (rt_join) or synchronised
 };
@@ -161,6 +181,7 @@ struct rt_photon_map {
   DevMem ws_queue, ws_sort;        // request queue, accumulators and sort buffers of the queued radius gather (grow-only)
   DevMem ws_knn_sort;              // keys, order, reordered queries and results of a k-nearest gather that sorts its queries (grow-only)
   float bbox[6] = { 0, 0, 0, 0, 0, 0 };   // min xyz, max xyz of the photon positions
+  bool core_valid = false;
   float core[6] = { 0, 0, 0, 0, 0, 0 };   // the same without the outermost 2 % on either side of every axis (from the nodes of the tree's top levels)
   DevMap view() const {
     DevMap m; m.n = n; m.node = node.as<float4>(); m.pay = pay.as<float>(); m.rec64 = rec64.as<double>(); m.perm = perm.as<int32_t>();

@@ -54,6 +54,13 @@ int rt_sort_pairs_u64(rt_ctx *ctx, DevMem &temp, const unsigned long long *keys_
   return RT_OK;
 }
 
+// The library sorts up to 2^20 items with a merge sort (block sort + ten merge passes at a million photons) unless told
+// otherwise; the radix sort needs one pass per digit of the 33 .. 42 key bits of a kd level.
+#ifndef RT_KD_MERGE_LIMIT
+#define RT_KD_MERGE_LIMIT 65536
+#endif
+using RtKdSortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, RT_KD_MERGE_LIMIT>;
+// (Tried: 6-, 7- and 8-bit digits for that radix sort -- 3.3, 3.6, 4.7 against 2.7 ms per build with the library's own digits.)
 // ------------------------------------------------------------------ build kernels
 __device__ __forceinline__ uint32_t sortable(float x) {
   if (x == 0.0f) x = 0.0f;                         // -0 and +0 compare equal in the reference's comparator
@@ -335,7 +342,7 @@ int rt_kd_build_device(rt_ctx *ctx, const float *d_pos, uint32_t n, int32_t *d_p
   size_t tmp_bytes = 0;
   int seg_bits = global_levels + 1;
   if (global_levels)
-    RT_HIP(ctx, rocprim::radix_sort_pairs(nullptr, tmp_bytes, (uint64_t *)nullptr, (uint64_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, n, 0,
+    RT_HIP(ctx, rocprim::radix_sort_pairs<RtKdSortConfig>(nullptr, tmp_bytes, (uint64_t *)nullptr, (uint64_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, n, 0,
                                           32 + seg_bits, ctx->stream));
   size_t off = 0;
   auto carve = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
@@ -365,7 +372,7 @@ int rt_kd_build_device(rt_ctx *ctx, const float *d_pos, uint32_t n, int32_t *d_p
     RT_LAUNCH(ctx, "kd_keys", k_kd_keys, grid, 256, n, d_pos, (const uint32_t *)idx_cur, sg, first, level, (const uint32_t *)bbmin, (const uint32_t *)bbmax, segdim, keyA);
     {
       KernelTimer timer_(ctx, "kd_sort");
-      RT_HIP(ctx, rocprim::radix_sort_pairs(base + o_tmp, tmp_bytes, keyA, keyB, idx_cur, idx_nxt, n, 0, level == 0 ? 32 : 32 + level + 1, ctx->stream));
+      RT_HIP(ctx, rocprim::radix_sort_pairs<RtKdSortConfig>(base + o_tmp, tmp_bytes, keyA, keyB, idx_cur, idx_nxt, n, 0, level == 0 ? 32 : 32 + level + 1, ctx->stream));
     }
     std::swap(idx_cur, idx_nxt);
     RT_LAUNCH(ctx, "kd_split", k_kd_split, grid, 256, n, (const uint32_t *)idx_cur, sg, (const uint8_t *)segdim, d_perm, d_dim);
@@ -440,16 +447,17 @@ int rt_map_build_device(rt_ctx *ctx, const void *src, int src_kind, uint32_t n, 
   *out = nullptr;
   if (n == 0) return rt_fail(ctx, RT_ERR_EMPTY_TREE, "tried to build a k-d tree with no data!");
   DevMem tpos;
-  RT_HIP(ctx, tpos.alloc((size_t)n * 12));
+  struct Back { rt_ctx *c; DevMem &d; ~Back() { c->pool_give(d); } } tpos_back{ ctx, tpos };      // (the build below synchronises before it returns)
+  RT_HIP(ctx, ctx->pool_take(tpos, (size_t)n * 12));
   rt_photon_map *m = new rt_photon_map();
   m->ctx = ctx; m->n = n;
-  hipError_t e = m->node.alloc((size_t)n * 16);
-  if (e == hipSuccess) e = m->pay.alloc((size_t)n * 24);
-  if (e == hipSuccess) e = m->perm.alloc((size_t)n * 4);
-  if (e == hipSuccess) e = m->dim.alloc((size_t)n);
+  hipError_t e = ctx->pool_take(m->node, (size_t)n * 16);
+  if (e == hipSuccess) e = ctx->pool_take(m->pay, (size_t)n * 24);
+  if (e == hipSuccess) e = ctx->pool_take(m->perm, (size_t)n * 4);
+  if (e == hipSuccess) e = ctx->pool_take(m->dim, (size_t)n);
   // fp64 copy of the records for the parity (fp64) renderer; only from fp64 records, and skipped for very large maps
   const bool keep64 = src_kind == MAP_SRC_REC64 && n <= (1u << 24);
-  if (e == hipSuccess && keep64) e = m->rec64.alloc((size_t)n * 88);
+  if (e == hipSuccess && keep64) e = ctx->pool_take(m->rec64, (size_t)n * 88);
   if (e != hipSuccess) { delete m; return rt_fail(ctx, RT_ERR_HIP, "photon map allocation failed: %s", hipGetErrorString(e)); }
   const uint32_t grid = div_up(n, 256);
   if (src_kind == MAP_SRC_REC64) RT_LAUNCH(ctx, "map_extract_pos", k_map_extract_pos<MAP_SRC_REC64>, grid, 256, n, src, tpos.as<float>());
@@ -462,22 +470,6 @@ int rt_map_build_device(rt_ctx *ctx, const void *src, int src_kind, uint32_t n, 
   else if (src_kind == MAP_SRC_FULL32) RT_LAUNCH(ctx, "map_permute", k_map_permute<MAP_SRC_FULL32>, grid, 256, n, src, m->perm.as<int32_t>(), m->dim.as<uint8_t>(), m->node.as<float4>(), m->pay.as<float>(), r64);
   else RT_LAUNCH(ctx, "map_permute", k_map_permute<MAP_SRC_PACKED>, grid, 256, n, src, m->perm.as<int32_t>(), m->dim.as<uint8_t>(), m->node.as<float4>(), m->pay.as<float>(), r64);
   if (hipStreamSynchronize(ctx->stream) != hipSuccess) { delete m; return rt_fail(ctx, RT_ERR_HIP, "photon map build failed"); }
-  {
-    // The box of the map's core: the nodes of the tree's top levels are the medians of ever smaller regions -- a
-    // sample of the photons spread like the photons themselves -- and the box drops the outermost 2 % of them on
-    // either side of every axis.  (The full bounding box of an emitted map is set by a handful of photons that
-    // left the scene through a gap and landed far out on a plane.)
-    const uint32_t ns = std::min<uint32_t>(n, 4095u);
-    std::vector<float4> top(ns);
-    if (hipMemcpy(top.data(), m->node.p, (size_t)ns * 16, hipMemcpyDeviceToHost) != hipSuccess) { delete m; return rt_fail(ctx, RT_ERR_HIP, "photon map build failed"); }
-    std::vector<float> v(ns);
-    for (int d = 0; d < 3; d++) {
-      for (uint32_t i = 0; i < ns; i++) v[i] = d == 0 ? top[i].x : (d == 1 ? top[i].y : top[i].z);
-      std::sort(v.begin(), v.end());
-      const uint32_t cut = ns / 50;
-      m->core[d] = v[cut]; m->core[3 + d] = v[ns - 1 - cut];
-    }
-  }
   *out = m;
   return RT_OK;
 }
@@ -513,7 +505,15 @@ extern "C" int rt_photon_map_build_lists(rt_photon_lists *lists, int which, rt_p
   const int kind = words == 9 ? MAP_SRC_PACKED : (words == 22 ? MAP_SRC_REC64 : MAP_SRC_FULL32);
   return rt_map_build_device(ctx, rec, kind, n, out);
 }
-extern "C" void rt_photon_map_free(rt_photon_map *m) { delete m; }
+// A map's blocks go back to its context's pool; everything queued that may still read them is waited for first (hipFree
+// would have waited for the whole device).
+extern "C" void rt_photon_map_free(rt_photon_map *m) {
+  if (!m) return;
+  rt_ctx *ctx = m->ctx;
+  (void)hipSetDevice(ctx->device);
+  if (rt_synchronize(ctx) == RT_OK) { ctx->pool_give(m->node); ctx->pool_give(m->pay); ctx->pool_give(m->perm); ctx->pool_give(m->dim); ctx->pool_give(m->rec64); }
+  delete m;
+}
 extern "C" uint32_t rt_photon_map_size(const rt_photon_map *m) { return m ? m->n : 0; }
 extern "C" int rt_photon_map_nodes(rt_photon_map *m, int32_t *perm, uint8_t *dim) {
   if (!m) return RT_ERR_INVALID;
@@ -1699,6 +1699,28 @@ static int rt_sort_pairs_u32(rt_ctx *ctx, DevMem &temp, const uint32_t *keys_in,
   return RT_OK;
 }
 
+// The box of the map's core: the nodes of the tree's top levels are the medians of ever smaller regions -- a sample of the
+// photons spread like the photons themselves -- and the box drops the outermost 2 % of them on either side of every axis.
+// (The full bounding box of an emitted map is set by a handful of photons that left the scene through a gap and landed far
+// out on a plane.)  Worked out when a k-nearest gather first asks for it, not at every build.
+static int map_core_box(rt_photon_map *m) {
+  if (m->core_valid) return RT_OK;
+  rt_ctx *ctx = m->ctx;
+  const uint32_t ns = std::min<uint32_t>(m->n, 4095u);
+  std::vector<float4> top(ns);
+  RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  RT_HIP(ctx, hipMemcpy(top.data(), m->node.p, (size_t)ns * 16, hipMemcpyDeviceToHost));
+  std::vector<float> v(ns);
+  for (int d = 0; d < 3; d++) {
+    for (uint32_t i = 0; i < ns; i++) v[i] = d == 0 ? top[i].x : (d == 1 ? top[i].y : top[i].z);
+    std::sort(v.begin(), v.end());
+    const uint32_t cut = ns / 50;
+    m->core[d] = v[cut]; m->core[3 + d] = v[ns - 1 - cut];
+  }
+  m->core_valid = true;
+  return RT_OK;
+}
+
 // the k-nearest gather of rt_gather_radiance: in the caller's order, or sorted first (see above)
 static int gather_knn_ordered(rt_photon_map *m, const float *dh, uint32_t nq, uint32_t k, float *dout) {
   rt_ctx *ctx = m->ctx;
@@ -1716,6 +1738,7 @@ static int gather_knn_ordered(rt_photon_map *m, const float *dh, uint32_t nq, ui
     const double mean_diag = total[1] > 0 ? (double)total[0] / (double)total[1] : 0.0;
     // (the map's extent without its stragglers -- a photon that left through a gap in the scene lands far out on a plane:
     // the box of its core, see rt_photon_map::core)
+    RT_TRY(map_core_box(m));
     const double e0 = m->core[3] - m->core[0], e1 = m->core[4] - m->core[1], e2 = m->core[5] - m->core[2];
     const double emax = std::max(e0, std::max(e1, e2));
     const double area = std::max(2.0 * (e0 * e1 + e1 * e2 + e2 * e0), 1e-6 * emax * emax);
@@ -1735,6 +1758,7 @@ static int gather_knn_ordered(rt_photon_map *m, const float *dh, uint32_t nq, ui
   char *base = (char *)m->ws_knn_sort.p;
   uint32_t *kin = (uint32_t *)(base + o_kin), *kout = (uint32_t *)(base + o_kout), *vin = (uint32_t *)(base + o_vin), *vout = (uint32_t *)(base + o_vout);
   float *hs = (float *)(base + o_hits), *rs = (float *)(base + o_rgb);
+  RT_TRY(map_core_box(m));
   const double emax = std::max((double)m->core[3] - m->core[0], std::max((double)m->core[4] - m->core[1], (double)m->core[5] - m->core[2]));
   const float inv_cell = emax > 0 ? (float)(1024.0 / emax) : 1.0f;      // (queries outside the core box share its outermost cells)
   RT_LAUNCH(ctx, "gather_knn_keys", k_knn_keys, div_up(nq, 256), 256, dh, nq, m->core[0], m->core[1], m->core[2], inv_cell, kin, vin);
