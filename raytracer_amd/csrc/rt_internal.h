@@ -192,4 +192,4 @@ struct rt_photon_map {
 // looks up this device's copy of the static scratch array (rt_kd.hip); called by rt_init with the device current
 int rt_static_scratch_setup(rt_ctx *ctx);
 rt_ctx *rt_lists_ctx(rt_photon_lists *lists);
-int rt_kd_build_device(rt_ctx *ctx, const float *d_pos, uint32_t n, int32_t *d_perm, uint8_t *d_dim, float *bbox6);
+int rt_kd_build_device(rt_ctx *ctx, const float4 *d_pos, uint32_t n, int32_t *d_perm, uint8_t *d_dim, float *bbox6);

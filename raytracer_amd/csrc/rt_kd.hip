@@ -54,13 +54,23 @@ int rt_sort_pairs_u64(rt_ctx *ctx, DevMem &temp, const unsigned long long *keys_
   return RT_OK;
 }
 
-// The library sorts up to 2^20 items with a merge sort (block sort + ten merge passes at a million photons) unless told
-// otherwise; the radix sort needs one pass per digit of the 33 .. 42 key bits of a kd level.
+// The level sorts of the kd build.  The library sorts up to 2^20 items with a merge sort (block sort + ten merge passes at
+// a million photons) unless told otherwise; its radix sort needs one pass per 8-bit digit of the 32 .. 48 key bits of a
+// level, and every pass is a chain of workgroups that each wait for the one before (decoupled look-back): the passes of
+// a million items are bound by that chain, not by bandwidth.  Measured, whole build of 10^6 photons, 512 threads x items
+// per thread: 6: 2.50 ms, 8: 2.09, 9: 2.16, 10: 2.20, 12: 2.20, 16: 2.31, 24: 2.75; 256 x 12: 2.29, 256 x 24: 2.68,
+// 1024 x 5: 2.39, 1024 x 12: 2.41; the library's own choice 2.26.  (8 items make about one workgroup per compute unit
+// at a million photons; 12 and 16 items where those do -- 1.4 and 2 million photons -- gain 1 - 3 % there: left out.)
+// (Tried: 6- and 7-bit digits: 3.3, 3.6 ms.)
 #ifndef RT_KD_MERGE_LIMIT
 #define RT_KD_MERGE_LIMIT 65536
 #endif
-using RtKdSortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, RT_KD_MERGE_LIMIT>;
-// (Tried: 6-, 7- and 8-bit digits for that radix sort -- 3.3, 3.6, 4.7 against 2.7 ms per build with the library's own digits.)
+using RtKdSortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
+    rocprim::radix_sort_onesweep_config<rocprim::kernel_config<512, 32>, rocprim::kernel_config<512, 8>, 8, rocprim::block_radix_rank_algorithm::match>, RT_KD_MERGE_LIMIT>;
+// temp == nullptr: only the size of the temporary storage is returned in `bytes`
+static hipError_t kd_level_sort(void *temp, size_t &bytes, const uint64_t *keys_in, uint64_t *keys_out, const uint32_t *vals_in, uint32_t *vals_out, uint32_t n, int bits, hipStream_t stream) {
+  return rocprim::radix_sort_pairs<RtKdSortConfig>(temp, bytes, keys_in, keys_out, vals_in, vals_out, n, 0, bits, stream);
+}
 // ------------------------------------------------------------------ build kernels
 __device__ __forceinline__ uint32_t sortable(float x) {
   if (x == 0.0f) x = 0.0f;                         // -0 and +0 compare equal in the reference's comparator
@@ -79,39 +89,36 @@ __global__ void __launch_bounds__(256) k_kd_iota(uint32_t n, uint32_t *idx) {
   if (i < n) idx[i] = i;
 }
 
-__global__ void __launch_bounds__(256) k_kd_init(uint32_t n, uint32_t *idx, SegState sg) {
+// idx = identity, one segment (the root's) over the whole array, and every box of the global levels empty
+__global__ void __launch_bounds__(256) k_kd_init(uint32_t n, uint32_t *idx, SegState sg, uint32_t n_box_words, uint32_t *bbmin, uint32_t *bbmax) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_box_words) { bbmin[i] = 0xFFFFFFFFu; bbmax[i] = 0u; }
   if (i >= n) return;
   idx[i] = i; sg.pos[i] = 1; sg.start[i] = 0; sg.len[i] = n;
 }
-
-__global__ void __launch_bounds__(256) k_kd_bbox_clear(uint32_t first, uint32_t count, uint32_t *bbmin, uint32_t *bbmax) {
+__global__ void __launch_bounds__(256) k_kd_pos4(uint32_t n, const float *pos3, float4 *pos4) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= count * 3) return;
-  bbmin[(size_t)first * 3 + i] = 0xFFFFFFFFu; bbmax[(size_t)first * 3 + i] = 0u;
+  if (i < n) pos4[i] = make_float4(pos3[(size_t)i * 3], pos3[(size_t)i * 3 + 1], pos3[(size_t)i * 3 + 2], 0.f);
 }
 
-// min/max of every active segment (kdtree.js:85-92).  A workgroup takes KD_BBOX_ITEMS * 256 consecutive array
-// positions.  Near the root they all lie in one segment: the workgroup reduces in registers, across lanes and through
+// min/max of every active segment (kdtree.js:85-92) over the array positions a workgroup holds in registers:
+// KD_BBOX_ITEMS rows of 256 consecutive positions, row r's segment (heap position; 0 = none) in sp[r] and photon in
+// p[r].  Near the root the positions all lie in one segment: the workgroup reduces in registers, across lanes and through
 // LDS and issues one atomic per axis and bound (thousands of same-address atomics would serialise).  Further down,
 // waves that lie inside one segment reduce across lanes first; mixed waves fall back to per-lane atomics, which by
-// then go to many different addresses.
-#define KD_BBOX_ITEMS 16
-__global__ void __launch_bounds__(256) k_kd_bbox(uint32_t n, const float *pos3, const uint32_t *idx, SegState sg,
-                                                 uint32_t *bbmin, uint32_t *bbmax) {
-  __shared__ uint32_t red[4][6];
-  const uint32_t c0 = blockIdx.x * (256u * KD_BBOX_ITEMS);
-  if (c0 >= n) return;
-  const uint32_t c1 = min(n, c0 + 256u * KD_BBOX_ITEMS);
-  // segments are contiguous runs of active positions, so the chunk lies in one segment iff the segment of its first
-  // position reaches its end
-  const uint32_t sp_first = sg.pos[c0];
-  const bool one_segment = sp_first != 0 && !(sp_first & KD_DONE) && sg.start[c0] + sg.len[c0] >= c1;
+// then go to many different addresses.  All threads of the workgroup call this.
+#ifndef KD_BBOX_ITEMS
+#define KD_BBOX_ITEMS 4
+#endif
+__device__ __forceinline__ void kd_boxes_of_chunk(bool one_segment, uint32_t sp_first, const uint32_t (&sp)[KD_BBOX_ITEMS], const float4 (&p)[KD_BBOX_ITEMS],
+                                                  uint32_t (*red)[6], uint32_t *bbmin, uint32_t *bbmax) {
   if (one_segment) {
     uint32_t lo[3] = { 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu }, hi[3] = { 0, 0, 0 };
-    for (uint32_t i = c0 + threadIdx.x; i < c1; i += 256) {
-      const float *p = pos3 + (size_t)idx[i] * 3;
-      for (int d = 0; d < 3; d++) { uint32_t u = sortable(p[d]); lo[d] = min(lo[d], u); hi[d] = max(hi[d], u); }
+#pragma unroll
+    for (int r = 0; r < KD_BBOX_ITEMS; r++) {
+      if (!sp[r]) continue;
+      const float c[3] = { p[r].x, p[r].y, p[r].z };
+      for (int d = 0; d < 3; d++) { const uint32_t u = sortable(c[d]); lo[d] = min(lo[d], u); hi[d] = max(hi[d], u); }
     }
     for (int off = 32; off > 0; off >>= 1)
       for (int d = 0; d < 3; d++) {
@@ -128,17 +135,16 @@ __global__ void __launch_bounds__(256) k_kd_bbox(uint32_t n, const float *pos3, 
     }
     return;
   }
-  for (uint32_t row = 0; row < KD_BBOX_ITEMS; row++) {            // (workgroup-uniform trip count: the shuffles below need whole waves)
-    const uint32_t i = c0 + row * 256u + threadIdx.x;
-    uint32_t sp = (i < n) ? sg.pos[i] : 0;
-    if (sp & KD_DONE) sp = 0;
+#pragma unroll
+  for (int r = 0; r < KD_BBOX_ITEMS; r++) {                    // (workgroup-uniform trip count: the shuffles below need whole waves)
+    const uint32_t s = sp[r];
     uint32_t lo[3] = { 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu }, hi[3] = { 0, 0, 0 };
-    if (sp) {
-      const float *p = pos3 + (size_t)idx[i] * 3;
-      for (int d = 0; d < 3; d++) { uint32_t u = sortable(p[d]); lo[d] = u; hi[d] = u; }
+    if (s) {
+      const float c[3] = { p[r].x, p[r].y, p[r].z };
+      for (int d = 0; d < 3; d++) { const uint32_t u = sortable(c[d]); lo[d] = u; hi[d] = u; }
     }
-    uint32_t sp0 = __shfl(sp, 0, 64);
-    bool uniform = __all(sp == sp0 || sp == 0) && sp0 != 0;
+    const uint32_t s0 = __shfl(s, 0, 64);
+    const bool uniform = __all(s == s0 || s == 0) && s0 != 0;
     if (uniform) {
       for (int off = 32; off > 0; off >>= 1)
         for (int d = 0; d < 3; d++) {
@@ -146,11 +152,26 @@ __global__ void __launch_bounds__(256) k_kd_bbox(uint32_t n, const float *pos3, 
           lo[d] = min(lo[d], a); hi[d] = max(hi[d], b);
         }
       if ((threadIdx.x & 63) == 0)
-        for (int d = 0; d < 3; d++) { atomicMin(&bbmin[(size_t)sp0 * 3 + d], lo[d]); atomicMax(&bbmax[(size_t)sp0 * 3 + d], hi[d]); }
-    } else if (sp) {
-      for (int d = 0; d < 3; d++) { atomicMin(&bbmin[(size_t)sp * 3 + d], lo[d]); atomicMax(&bbmax[(size_t)sp * 3 + d], hi[d]); }
+        for (int d = 0; d < 3; d++) { atomicMin(&bbmin[(size_t)s0 * 3 + d], lo[d]); atomicMax(&bbmax[(size_t)s0 * 3 + d], hi[d]); }
+    } else if (s) {
+      for (int d = 0; d < 3; d++) { atomicMin(&bbmin[(size_t)s * 3 + d], lo[d]); atomicMax(&bbmax[(size_t)s * 3 + d], hi[d]); }
     }
   }
+}
+
+// the root's box: every position is in segment 1 and the photons are in their input order
+__global__ void __launch_bounds__(256) k_kd_bbox_root(uint32_t n, const float4 *pos4, uint32_t *bbmin, uint32_t *bbmax) {
+  __shared__ uint32_t red[4][6];
+  const uint32_t c0 = blockIdx.x * (256u * KD_BBOX_ITEMS);
+  if (c0 >= n) return;
+  uint32_t sp[KD_BBOX_ITEMS]; float4 p[KD_BBOX_ITEMS];
+#pragma unroll
+  for (int r = 0; r < KD_BBOX_ITEMS; r++) {
+    const uint32_t i = c0 + r * 256u + threadIdx.x;
+    sp[r] = i < n ? 1u : 0u;
+    p[r] = i < n ? pos4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  kd_boxes_of_chunk(true, 1u, sp, p, red, bbmin, bbmax);
 }
 
 // widest axis in fp64, `>` strict so ties go to the lowest axis (kdtree.js:93-100)
@@ -163,11 +184,11 @@ __device__ __forceinline__ int widest_dim3(const uint32_t *lo, const uint32_t *h
 }
 
 // Sort keys of one level (heap positions [first, 2 first), first = 2^level).  The array holds the level's segments in
-// heap order with exactly one finished node between neighbours, so the high part of a key only has to number them:
-// segment j of the level gets 2 j, the finished node in front of segment j gets 2 j - 1 -- level + 1 bits instead of a
-// full array position, which saves the radix sort two of its seven passes.  Low part: the coordinate along the
-// segment's widest axis (finished nodes: 0; they are alone in their group).
-__global__ void __launch_bounds__(256) k_kd_keys(uint32_t n, const float *pos3, const uint32_t *idx, SegState sg, uint32_t first, int level,
+// heap order with exactly one finished node between neighbours, so the high part of a key only has to number the
+// segments: `level` bits instead of a full array position, which saves the radix sort two of its seven passes.  Low part:
+// the coordinate along the segment's widest axis.  A finished node takes the number of the segment in front of it and the
+// largest low part: the sort is stable and the node already stands behind that segment, so there it stays.
+__global__ void __launch_bounds__(256) k_kd_keys(uint32_t n, const float4 *pos_cur, SegState sg, uint32_t first, int level,
                                                  const uint32_t *bbmin, const uint32_t *bbmax, uint8_t *segdim, uint64_t *keys) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -176,24 +197,53 @@ __global__ void __launch_bounds__(256) k_kd_keys(uint32_t n, const float *pos3, 
     const uint32_t q = sp & ~KD_DONE;
     const int dq = 31 - __clz((int)q);                      // depth of node q; its right subtree starts at segment k of this level
     const uint32_t k = ((2u * q + 1u) << (level - dq - 1)) - first;
-    keys[i] = (uint64_t)(2u * k - 1u) << 32;
+    keys[i] = ((uint64_t)(k - 1u) << 32) | 0xFFFFFFFFull;
     return;
   }
   const int d = widest_dim3(bbmin + (size_t)sp * 3, bbmax + (size_t)sp * 3);
   if (i == sg.start[i]) segdim[sp] = (uint8_t)d;
-  keys[i] = ((uint64_t)(2u * (sp - first)) << 32) | sortable(pos3[(size_t)idx[i] * 3 + d]);
+  const float4 p = pos_cur[i];
+  keys[i] = ((uint64_t)(sp - first) << 32) | sortable(d == 0 ? p.x : (d == 1 ? p.y : p.z));
 }
 
-__global__ void __launch_bounds__(256) k_kd_split(uint32_t n, const uint32_t *idx, SegState sg, const uint8_t *segdim,
-                                                  int32_t *perm, uint8_t *dim) {
-  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  uint32_t sp = sg.pos[i];
-  if (sp & KD_DONE) return;
-  uint32_t s = sg.start[i], len = sg.len[i], m = find_median(len);
-  if (i == s + m) { perm[sp - 1] = (int32_t)idx[i]; dim[sp - 1] = segdim[sp]; sg.pos[i] = sp | KD_DONE; }
-  else if (i < s + m) { sg.pos[i] = 2 * sp; sg.len[i] = m; }
-  else { sg.pos[i] = 2 * sp + 1; sg.start[i] = s + m + 1; sg.len[i] = len - m - 1; }
+// After a level's sort: the medians become nodes, the sides become the next level's segments (kdtree.js:104-118), the
+// photons' positions are brought into the new order (pos_cur[i] = pos4[idx[i]]: the one scattered read of a level; the key
+// kernel and the workgroups of the lower levels then read consecutive addresses), and -- boxes != 0 -- the new segments'
+// boxes are taken from the positions while they are in registers.
+__global__ void __launch_bounds__(256) k_kd_split(uint32_t n, const float4 *pos4, const uint32_t *idx, SegState sg, const uint8_t *segdim,
+                                                  int32_t *perm, uint8_t *dim, float4 *pos_cur, int boxes, uint32_t *bbmin, uint32_t *bbmax) {
+  __shared__ uint32_t red[4][6];
+  __shared__ uint32_t head[3];
+  const uint32_t c0 = blockIdx.x * (256u * KD_BBOX_ITEMS);
+  if (c0 >= n) return;
+  const uint32_t c1 = min(n, c0 + 256u * KD_BBOX_ITEMS);
+  uint32_t sp_new[KD_BBOX_ITEMS]; float4 p[KD_BBOX_ITEMS];
+#pragma unroll
+  for (int r = 0; r < KD_BBOX_ITEMS; r++) {
+    const uint32_t i = c0 + r * 256u + threadIdx.x;
+    sp_new[r] = 0; p[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i >= n) continue;
+    const uint32_t id = idx[i];
+    p[r] = pos4[id];
+    pos_cur[i] = p[r];
+    const uint32_t sp = sg.pos[i];
+    uint32_t s = 0, len = 0;
+    if (!(sp & KD_DONE)) {
+      s = sg.start[i]; len = sg.len[i];
+      const uint32_t m = find_median(len);
+      if (i == s + m) { perm[sp - 1] = (int32_t)id; dim[sp - 1] = segdim[sp]; sg.pos[i] = sp | KD_DONE; }
+      else if (i < s + m) { sp_new[r] = 2 * sp; len = m; sg.pos[i] = sp_new[r]; sg.len[i] = len; }
+      else { sp_new[r] = 2 * sp + 1; s = s + m + 1; len = len - m - 1; sg.pos[i] = sp_new[r]; sg.start[i] = s; sg.len[i] = len; }
+    }
+    if (r == 0 && threadIdx.x == 0) { head[0] = sp_new[0]; head[1] = s; head[2] = len; }
+  }
+  if (!boxes) return;                                        // (kernel argument)
+  __syncthreads();
+  // segments are contiguous runs of active positions, so the chunk lies in one segment iff the segment of its first
+  // position reaches its end
+  const uint32_t sp_first = head[0];
+  const bool one_segment = sp_first != 0 && head[1] + head[2] >= c1;
+  kd_boxes_of_chunk(one_segment, sp_first, sp_new, p, red, bbmin, bbmax);
 }
 
 // ---- the lower levels: one workgroup finishes a whole subtree of up to KD_LDS_S photons in LDS
@@ -205,8 +255,70 @@ __global__ void __launch_bounds__(256) k_kd_split(uint32_t n, const uint32_t *id
 // subtree's size alone, and so does the longest one: findMedian of the previous level's longest.
 #define KD_LDS_S 2048
 #define KD_LDS_T 1024
+#define KD_LDS_BITS 11                                       // log2(KD_LDS_S): a sort key keeps its position in that many bits
 struct KdSeg { uint32_t pos, start, len; };
-__global__ void __launch_bounds__(KD_LDS_T) k_kd_lds(const KdSeg *segs, const float *pos3, const uint32_t *idx, uint32_t *bbmin_g, uint32_t *bbmax_g,
+
+// Bitonic sort of S unique 64-bit keys in LDS by T threads, ascending.  A compare-exchange step pairs the elements i and
+// i | j.  For the steps with j < 64 E (E = S / T) a thread holds E consecutive elements in registers: pairs inside a
+// thread need nothing, pairs inside a wave are exchanged by lane shuffles -- no LDS traffic and no barrier; only the steps
+// across waves (10 of the 66 at S = 2048) go through LDS, one pair per thread and barrier.  Called by all T threads with
+// the keys written and a barrier passed; returns with the sorted keys in LDS behind a barrier.
+template <uint32_t S, uint32_t T> __device__ __forceinline__ void kd_lds_sort(unsigned long long *key, uint32_t tid) {
+  constexpr uint32_t E = S / T, W = 64u * E;                 // W: elements of one wave
+  unsigned long long e[E];
+  auto load = [&]() {
+#pragma unroll
+    for (uint32_t q = 0; q < E; q++) e[q] = key[tid * E + q];
+  };
+  auto store = [&]() {
+#pragma unroll
+    for (uint32_t q = 0; q < E; q++) key[tid * E + q] = e[q];
+    __syncthreads();
+  };
+  auto in_wave = [&](uint32_t k, uint32_t j_top) {           // the steps j_top, j_top / 2 .. 1 of merge size k on the registers
+    for (uint32_t j = j_top; j >= E; j >>= 1) {
+#pragma unroll
+      for (uint32_t q = 0; q < E; q++) {
+        const uint32_t i = tid * E + q;
+        const unsigned long long mine = e[q];
+        const uint32_t olo = (uint32_t)__shfl_xor((int)(uint32_t)mine, (int)(j / E), 64), ohi = (uint32_t)__shfl_xor((int)(uint32_t)(mine >> 32), (int)(j / E), 64);
+        const unsigned long long other = ((unsigned long long)ohi << 32) | olo;
+        const bool want_min = ((i & j) == 0) == ((i & k) == 0);
+        e[q] = ((other < mine) == want_min) ? other : mine;
+      }
+    }
+#pragma unroll
+    for (uint32_t j = E >> 1; j > 0; j >>= 1) {
+      if (j > j_top) continue;
+#pragma unroll
+      for (uint32_t q = 0; q < E; q++) {
+        if (q & j) continue;
+        const uint32_t i = tid * E + q;
+        const unsigned long long a = e[q], b = e[q | j];
+        if ((a > b) == ((i & k) == 0)) { e[q] = b; e[q | j] = a; }
+      }
+    }
+  };
+  load();
+  for (uint32_t k = 2; k <= W && k <= S; k <<= 1) in_wave(k, k >> 1);
+  store();
+  for (uint32_t k = 2 * W; k <= S; k <<= 1) {
+    for (uint32_t j = k >> 1; j >= W; j >>= 1) {
+#pragma unroll
+      for (uint32_t r = 0; r < S / 2 / T; r++) {
+        const uint32_t t = tid + r * T;
+        const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), p = i | j;
+        const unsigned long long a = key[i], b = key[p];
+        if ((a > b) == ((i & k) == 0)) { key[i] = b; key[p] = a; }
+      }
+      __syncthreads();
+    }
+    load();
+    in_wave(k, W >> 1);
+    store();
+  }
+}
+__global__ void __launch_bounds__(KD_LDS_T) k_kd_lds(const KdSeg *segs, const float4 *pos_cur, const uint32_t *idx, uint32_t *bbmin_g, uint32_t *bbmax_g,
                                                      int32_t *perm, uint8_t *dim_out) {
   constexpr uint32_t S = KD_LDS_S, T = KD_LDS_T;
   __shared__ float crd[3][S];                              // coordinates by local id (the photon's place in the segment on entry)
@@ -220,8 +332,8 @@ __global__ void __launch_bounds__(KD_LDS_T) k_kd_lds(const KdSeg *segs, const fl
   if (L == 0 || L > S) return;                             // (never: the host sizes the segments)
   for (uint32_t i = tid; i < S; i += T) {
     if (i < L) {
-      const float *p = pos3 + (size_t)idx[sg.start + i] * 3;
-      crd[0][i] = p[0]; crd[1][i] = p[1]; crd[2][i] = p[2];
+      const float4 p = pos_cur[sg.start + i];
+      crd[0][i] = p.x; crd[1][i] = p.y; crd[2][i] = p.z;
       spos[i] = sg.pos; sstart[i] = 0; slen[i] = (uint16_t)L;
     } else { spos[i] = 0; sstart[i] = (uint16_t)i; slen[i] = 0; crd[0][i] = crd[1][i] = crd[2][i] = 0.f; }
     lid[0][i] = (uint16_t)i; sdim[i] = 0;
@@ -232,25 +344,27 @@ __global__ void __launch_bounds__(KD_LDS_T) k_kd_lds(const KdSeg *segs, const fl
     __syncthreads();
     for (uint32_t k = tid; k < (S / 2) * 6; k += T) u.bb[k] = (k % 6 < 3) ? 0xFFFFFFFFu : 0u;
     __syncthreads();
-    // boxes of the segments with at least two photons
+    // boxes of the segments with at least two photons: runs of lanes with one segment reduce by shuffles (after the step
+    // `off` a lane holds the bounds of the next 2 off positions of its run), then the first lane of a run adds them to
+    // the segment's box -- one atomic per run, axis and bound instead of one per photon on a few addresses
 #pragma unroll
     for (uint32_t r = 0; r < S / T; r++) {
-      const uint32_t i = tid + r * T;
+      const uint32_t i = tid + r * T, lane = tid & 63u;
       const bool active = spos[i] != 0 && slen[i] >= 2;
-      const uint32_t s = sstart[i];
+      const uint32_t s = active ? (uint32_t)sstart[i] : 0xFFFFFFFFu;
       uint32_t lo[3] = { 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu }, hi[3] = { 0, 0, 0 };
       if (active) { const uint32_t l = lid[cur][i]; for (int d = 0; d < 3; d++) { lo[d] = hi[d] = sortable(crd[d][l]); } }
-      const uint32_t s0 = __shfl(s, 0, 64);
-      if (__all(active && s == s0)) {
-        for (int off = 32; off > 0; off >>= 1)
-          for (int d = 0; d < 3; d++) {
-            const uint32_t a = __shfl_xor(lo[d], off, 64), b = __shfl_xor(hi[d], off, 64);
-            lo[d] = min(lo[d], a); hi[d] = max(hi[d], b);
-          }
-        if ((tid & 63) == 0) for (int d = 0; d < 3; d++) { atomicMin(&u.bb[(s0 >> 1) * 6 + d], lo[d]); atomicMax(&u.bb[(s0 >> 1) * 6 + 3 + d], hi[d]); }
-      } else if (active) {
-        for (int d = 0; d < 3; d++) { atomicMin(&u.bb[(s >> 1) * 6 + d], lo[d]); atomicMax(&u.bb[(s >> 1) * 6 + 3 + d], hi[d]); }
+      for (uint32_t off = 1; off < 64u && off < maxlen; off <<= 1) {
+        const uint32_t s_there = __shfl_down(s, off, 64);
+        const bool take = lane + off < 64u && s_there == s;
+        for (int d = 0; d < 3; d++) {
+          const uint32_t a = __shfl_down(lo[d], off, 64), b = __shfl_down(hi[d], off, 64);
+          if (take) { lo[d] = min(lo[d], a); hi[d] = max(hi[d], b); }
+        }
       }
+      const uint32_t s_before = __shfl_up(s, 1, 64);
+      if (active && (lane == 0 || s_before != s))
+        for (int d = 0; d < 3; d++) { atomicMin(&u.bb[(s >> 1) * 6 + d], lo[d]); atomicMax(&u.bb[(s >> 1) * 6 + 3 + d], hi[d]); }
     }
     __syncthreads();
     if (top && tid < 3) {                                   // the subtree's own box, for the caller (the root's is the map's)
@@ -266,26 +380,16 @@ __global__ void __launch_bounds__(KD_LDS_T) k_kd_lds(const KdSeg *segs, const fl
       const uint32_t d = (sp != 0 && slen[i] >= 2) ? (uint32_t)widest_dim3(&u.bb[(sstart[i] >> 1) * 6], &u.bb[(sstart[i] >> 1) * 6 + 3]) : 0u;
       const uint32_t c = sp ? sortable(crd[d][lid[cur][i]]) : 0u, grp = sp ? sstart[i] : i;
       myd[r] = d;
-      mykey[r] = ((unsigned long long)grp << 43) | ((unsigned long long)c << 11) | i;
+      mykey[r] = ((unsigned long long)grp << (32 + KD_LDS_BITS)) | ((unsigned long long)c << KD_LDS_BITS) | i;
     }
     __syncthreads();                                       // (the keys overwrite the boxes)
 #pragma unroll
     for (uint32_t r = 0; r < S / T; r++) { const uint32_t i = tid + r * T; u.key[i] = mykey[r]; sdim[i] = (uint8_t)myd[r]; }
     __syncthreads();
     if (maxlen > 64) {
-      for (uint32_t k = 2; k <= S; k <<= 1)
-        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+      kd_lds_sort<S, T>(u.key, tid);
 #pragma unroll
-          for (uint32_t r = 0; r < S / 2 / T; r++) {
-            const uint32_t t = tid + r * T;
-            const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), p = i | j;
-            const unsigned long long a = u.key[i], b = u.key[p];
-            if ((a > b) == ((i & k) == 0)) { u.key[i] = b; u.key[p] = a; }
-          }
-          __syncthreads();
-        }
-#pragma unroll
-      for (uint32_t r = 0; r < S / T; r++) { const uint32_t i = tid + r * T; lid[cur ^ 1][i] = lid[cur][(uint32_t)(u.key[i] & 2047u)]; }
+      for (uint32_t r = 0; r < S / T; r++) { const uint32_t i = tid + r * T; lid[cur ^ 1][i] = lid[cur][(uint32_t)(u.key[i] & (S - 1u))]; }
     } else {
 #pragma unroll
       for (uint32_t r = 0; r < S / T; r++) {
@@ -315,12 +419,12 @@ __global__ void __launch_bounds__(KD_LDS_T) k_kd_lds(const KdSeg *segs, const fl
     }
   }
 }
-static_assert(KD_LDS_S == 2048 && KD_LDS_S == 2 * KD_LDS_T, "the sort keys keep the position in 11 bits; one compare-exchange per thread and stage");
+static_assert(KD_LDS_S == (1u << KD_LDS_BITS) && KD_LDS_S % (2 * KD_LDS_T) == 0 && 32 + 2 * KD_LDS_BITS <= 64, "sort keys: group, coordinate, position");
 
 static float unsortable_host(uint32_t u) { u ^= ((u >> 31) ? 0x80000000u : 0xFFFFFFFFu); float f; memcpy(&f, &u, 4); return f; }
 
-// bbox6 (optional, host): min xyz, max xyz of all positions
-int rt_kd_build_device(rt_ctx *ctx, const float *d_pos, uint32_t n, int32_t *d_perm, uint8_t *d_dim, float *bbox6) {
+// d_pos: the positions as float4 (w unused); bbox6 (optional, host): min xyz, max xyz of all positions
+int rt_kd_build_device(rt_ctx *ctx, const float4 *d_pos, uint32_t n, int32_t *d_perm, uint8_t *d_dim, float *bbox6) {
   if (n == 0) return rt_fail(ctx, RT_ERR_EMPTY_TREE, "tried to build a k-d tree with no data!");   // kdtree.js:6
   if (n >= 0x7FFFFFFFu) return rt_fail(ctx, RT_ERR_TOO_LARGE, "photon map too large");
   // the levels handled over the whole array: while the longest segment is too long for one workgroup
@@ -340,16 +444,16 @@ int rt_kd_build_device(rt_ctx *ctx, const float *d_pos, uint32_t n, int32_t *d_p
   const size_t n_bb = ((size_t)2 << global_levels) + 2;       // boxes by heap position, levels 0 .. global_levels
   // one grow-only workspace per context
   size_t tmp_bytes = 0;
-  int seg_bits = global_levels + 1;
+  int seg_bits = global_levels;
   if (global_levels)
-    RT_HIP(ctx, rocprim::radix_sort_pairs<RtKdSortConfig>(nullptr, tmp_bytes, (uint64_t *)nullptr, (uint64_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, n, 0,
-                                          32 + seg_bits, ctx->stream));
+    RT_HIP(ctx, kd_level_sort(nullptr, tmp_bytes, nullptr, nullptr, nullptr, nullptr, n, 32 + seg_bits, ctx->stream));
   size_t off = 0;
   auto carve = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
   const bool glob = global_levels > 0;
   const size_t o_idxA = carve((size_t)n * 4), o_idxB = carve(glob ? (size_t)n * 4 : 0), o_keyA = carve(glob ? (size_t)n * 8 : 0), o_keyB = carve(glob ? (size_t)n * 8 : 0);
   const size_t o_pos = carve(glob ? (size_t)n * 4 : 0), o_start = carve(glob ? (size_t)n * 4 : 0), o_len = carve(glob ? (size_t)n * 4 : 0);
   const size_t o_bbmin = carve(n_bb * 12), o_bbmax = carve(n_bb * 12), o_segdim = carve(n_bb), o_segs = carve(work.size() * sizeof(KdSeg)), o_tmp = carve(tmp_bytes);
+  const size_t o_pcur = carve(glob ? (size_t)n * 16 : 0);
   RT_HIP(ctx, ctx->ws_kd.reserve(off));
   char *base = (char *)ctx->ws_kd.p;
   uint32_t *idx_cur = (uint32_t *)(base + o_idxA), *idx_nxt = (uint32_t *)(base + o_idxB);
@@ -358,27 +462,30 @@ int rt_kd_build_device(rt_ctx *ctx, const float *d_pos, uint32_t n, int32_t *d_p
   uint32_t *bbmin = (uint32_t *)(base + o_bbmin), *bbmax = (uint32_t *)(base + o_bbmax);
   uint8_t *segdim = (uint8_t *)(base + o_segdim);
   KdSeg *d_segs = (KdSeg *)(base + o_segs);
-  const uint32_t grid = div_up(n, 256);
-  if (glob) RT_LAUNCH(ctx, "kd_init", k_kd_init, grid, 256, n, idx_cur, sg);
-  else {
+  float4 *pos_cur = (float4 *)(base + o_pcur);               // the positions in the array's current order, from the first split on
+  const uint32_t grid = div_up(n, 256), grid_chunks = div_up(n, 256u * KD_BBOX_ITEMS);
+  if (glob) {
+    const uint32_t n_box_words = (uint32_t)(n_bb * 3);
+    RT_LAUNCH(ctx, "kd_init", k_kd_init, div_up(std::max(n, n_box_words), 256), 256, n, idx_cur, sg, n_box_words, bbmin, bbmax);
+    RT_LAUNCH(ctx, "kd_bbox", k_kd_bbox_root, grid_chunks, 256, n, d_pos, bbmin, bbmax);
+  } else {
     RT_LAUNCH(ctx, "kd_init", k_kd_iota, grid, 256, n, idx_cur);
   }
   RT_HIP(ctx, hipMemcpyAsync(d_segs, work.data(), work.size() * sizeof(KdSeg), hipMemcpyHostToDevice, ctx->stream));
   uint32_t first = 1;
   for (int level = 0; level < global_levels; level++, first <<= 1) {      // heap positions [first, 2 first) form one level
-    const uint32_t count = (2 * (uint64_t)first - 1 <= n) ? first : n - first + 1;
-    RT_LAUNCH(ctx, "kd_bbox_clear", k_kd_bbox_clear, div_up((uint64_t)count * 3, 256), 256, first, count, bbmin, bbmax);
-    RT_LAUNCH(ctx, "kd_bbox", k_kd_bbox, div_up(n, 256u * KD_BBOX_ITEMS), 256, n, d_pos, (const uint32_t *)idx_cur, sg, bbmin, bbmax);
-    RT_LAUNCH(ctx, "kd_keys", k_kd_keys, grid, 256, n, d_pos, (const uint32_t *)idx_cur, sg, first, level, (const uint32_t *)bbmin, (const uint32_t *)bbmax, segdim, keyA);
+    RT_LAUNCH(ctx, "kd_keys", k_kd_keys, grid, 256, n, level == 0 ? d_pos : (const float4 *)pos_cur, sg, first, level, (const uint32_t *)bbmin, (const uint32_t *)bbmax, segdim, keyA);
     {
       KernelTimer timer_(ctx, "kd_sort");
-      RT_HIP(ctx, rocprim::radix_sort_pairs<RtKdSortConfig>(base + o_tmp, tmp_bytes, keyA, keyB, idx_cur, idx_nxt, n, 0, level == 0 ? 32 : 32 + level + 1, ctx->stream));
+      RT_HIP(ctx, kd_level_sort(base + o_tmp, tmp_bytes, keyA, keyB, idx_cur, idx_nxt, n, 32 + level, ctx->stream));
     }
     std::swap(idx_cur, idx_nxt);
-    RT_LAUNCH(ctx, "kd_split", k_kd_split, grid, 256, n, (const uint32_t *)idx_cur, sg, (const uint8_t *)segdim, d_perm, d_dim);
+    // (the workgroups of the lower levels take their subtree's box themselves)
+    RT_LAUNCH(ctx, "kd_split", k_kd_split, grid_chunks, 256, n, d_pos, (const uint32_t *)idx_cur, sg, (const uint8_t *)segdim, d_perm, d_dim, pos_cur,
+              level + 1 < global_levels ? 1 : 0, bbmin, bbmax);
   }
   if (!work.empty())
-    RT_LAUNCH(ctx, "kd_lds", k_kd_lds, (uint32_t)work.size(), KD_LDS_T, (const KdSeg *)d_segs, d_pos, (const uint32_t *)idx_cur, bbmin, bbmax, d_perm, d_dim);
+    RT_LAUNCH(ctx, "kd_lds", k_kd_lds, (uint32_t)work.size(), KD_LDS_T, (const KdSeg *)d_segs, glob ? (const float4 *)pos_cur : d_pos, (const uint32_t *)idx_cur, bbmin, bbmax, d_perm, d_dim);
   RT_HIP(ctx, hipGetLastError());
   RT_HIP(ctx, hipStreamSynchronize(ctx->stream));           // (`work` is read by the copy above until here)
   if (bbox6) {                                              // the root segment's box (heap position 1) is never cleared again
@@ -394,11 +501,13 @@ extern "C" int rt_kd_build(rt_ctx *ctx, const float *pos, uint32_t n, int32_t *p
   if (!ctx) return RT_ERR_INVALID;
   if (n == 0) return rt_fail(ctx, RT_ERR_EMPTY_TREE, "tried to build a k-d tree with no data!");
   RT_HIP(ctx, hipSetDevice(ctx->device));
-  DevMem tpos, tperm, tdim; const void *dpos; void *dperm, *ddim;
+  DevMem tpos, tpos4, tperm, tdim; const void *dpos; void *dperm, *ddim;
   RT_TRY(rt_stage_in(ctx, pos, (size_t)n * 12, tpos, &dpos));
   RT_TRY(rt_stage_out_begin(ctx, perm, (size_t)n * 4, tperm, &dperm));
   RT_TRY(rt_stage_out_begin(ctx, dim, (size_t)n, tdim, &ddim));
-  RT_TRY(rt_kd_build_device(ctx, (const float *)dpos, n, (int32_t *)dperm, (uint8_t *)ddim, nullptr));
+  RT_HIP(ctx, tpos4.reserve((size_t)n * 16));
+  RT_LAUNCH(ctx, "kd_pos4", k_kd_pos4, div_up(n, 256), 256, n, (const float *)dpos, tpos4.as<float4>());
+  RT_TRY(rt_kd_build_device(ctx, tpos4.as<float4>(), n, (int32_t *)dperm, (uint8_t *)ddim, nullptr));
   RT_TRY(rt_stage_out_end(ctx, perm, (size_t)n * 4, tperm));
   RT_TRY(rt_stage_out_end(ctx, dim, (size_t)n, tdim));
   return RT_OK;
@@ -420,12 +529,12 @@ template <int SRC> __device__ __forceinline__ void map_load(const void *src, siz
     for (int d = 0; d < 3; d++) { pos[d] = r[d]; pay[d] = r[3 + d]; pay[3 + d] = r[6 + d]; }
   }
 }
-template <int SRC> __global__ void __launch_bounds__(256) k_map_extract_pos(uint32_t n, const void *src, float *pos3) {
+template <int SRC> __global__ void __launch_bounds__(256) k_map_extract_pos(uint32_t n, const void *src, float4 *pos4) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   float pos[3], pay[6];
   map_load<SRC>(src, i, pos, pay);
-  for (int d = 0; d < 3; d++) pos3[(size_t)i * 3 + d] = pos[d];
+  pos4[i] = make_float4(pos[0], pos[1], pos[2], 0.f);
 }
 template <int SRC> __global__ void __launch_bounds__(256) k_map_permute(uint32_t n, const void *src, const int32_t *perm, const uint8_t *dim,
                                                                         float4 *node, float *pay_out, double *rec64) {
@@ -441,6 +550,33 @@ template <int SRC> __global__ void __launch_bounds__(256) k_map_permute(uint32_t
     for (int c = 0; c < 11; c++) rec64[(size_t)s * 11 + c] = r[c];
   }
 }
+// The same from fp64 records, a workgroup moving 256 records as 256 x 11 doubles: consecutive lanes read consecutive doubles
+// of a record (88 contiguous bytes at a place the permutation picks) and write one contiguous block of the ordered copy;
+// node and payload are then made from the workgroup's staged copy.  (One record per lane, as above, reads eleven doubles
+// 88 bytes apart from its neighbours': 0.29 ms per million photons.)
+__global__ void __launch_bounds__(256) k_map_permute_rec64(uint32_t n, const double *src, const int32_t *perm, const uint8_t *dim,
+                                                           float4 *node, float *pay_out, double *rec64) {
+  __shared__ double stage[256 * 11];
+  __shared__ uint32_t sperm[256];
+  const uint32_t s0 = blockIdx.x * 256u;
+  if (s0 >= n) return;                                       // (workgroup-uniform)
+  const uint32_t cnt = min(256u, n - s0);
+  sperm[threadIdx.x] = threadIdx.x < cnt ? (uint32_t)perm[s0 + threadIdx.x] : 0u;
+  __syncthreads();
+  for (uint32_t k = threadIdx.x; k < cnt * 11u; k += 256u) {
+    const uint32_t r = k / 11u, w = k - r * 11u;
+    const double v = src[(size_t)sperm[r] * 11 + w];
+    stage[k] = v;
+    if (rec64) rec64[(size_t)s0 * 11 + k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x >= cnt) return;
+  const double *r = stage + threadIdx.x * 11u;
+  const uint32_t s = s0 + threadIdx.x;
+  node[s] = make_float4((float)r[0], (float)r[1], (float)r[2], __int_as_float((int)dim[s]));
+  float2 *p = (float2 *)(pay_out + (size_t)s * 6);
+  p[0] = make_float2((float)r[3], (float)r[4]); p[1] = make_float2((float)r[5], (float)(r[7] * r[6])); p[2] = make_float2((float)(r[8] * r[6]), (float)(r[9] * r[6]));
+}
 
 // src: device memory
 int rt_map_build_device(rt_ctx *ctx, const void *src, int src_kind, uint32_t n, rt_photon_map **out) {
@@ -448,7 +584,7 @@ int rt_map_build_device(rt_ctx *ctx, const void *src, int src_kind, uint32_t n, 
   if (n == 0) return rt_fail(ctx, RT_ERR_EMPTY_TREE, "tried to build a k-d tree with no data!");
   DevMem tpos;
   struct Back { rt_ctx *c; DevMem &d; ~Back() { c->pool_give(d); } } tpos_back{ ctx, tpos };      // (the build below synchronises before it returns)
-  RT_HIP(ctx, ctx->pool_take(tpos, (size_t)n * 12));
+  RT_HIP(ctx, ctx->pool_take(tpos, (size_t)n * 16));
   rt_photon_map *m = new rt_photon_map();
   m->ctx = ctx; m->n = n;
   hipError_t e = ctx->pool_take(m->node, (size_t)n * 16);
@@ -460,13 +596,13 @@ int rt_map_build_device(rt_ctx *ctx, const void *src, int src_kind, uint32_t n, 
   if (e == hipSuccess && keep64) e = ctx->pool_take(m->rec64, (size_t)n * 88);
   if (e != hipSuccess) { delete m; return rt_fail(ctx, RT_ERR_HIP, "photon map allocation failed: %s", hipGetErrorString(e)); }
   const uint32_t grid = div_up(n, 256);
-  if (src_kind == MAP_SRC_REC64) RT_LAUNCH(ctx, "map_extract_pos", k_map_extract_pos<MAP_SRC_REC64>, grid, 256, n, src, tpos.as<float>());
-  else if (src_kind == MAP_SRC_FULL32) RT_LAUNCH(ctx, "map_extract_pos", k_map_extract_pos<MAP_SRC_FULL32>, grid, 256, n, src, tpos.as<float>());
-  else RT_LAUNCH(ctx, "map_extract_pos", k_map_extract_pos<MAP_SRC_PACKED>, grid, 256, n, src, tpos.as<float>());
-  int rc = rt_kd_build_device(ctx, tpos.as<float>(), n, m->perm.as<int32_t>(), m->dim.as<uint8_t>(), m->bbox);
+  if (src_kind == MAP_SRC_REC64) RT_LAUNCH(ctx, "map_extract_pos", k_map_extract_pos<MAP_SRC_REC64>, grid, 256, n, src, tpos.as<float4>());
+  else if (src_kind == MAP_SRC_FULL32) RT_LAUNCH(ctx, "map_extract_pos", k_map_extract_pos<MAP_SRC_FULL32>, grid, 256, n, src, tpos.as<float4>());
+  else RT_LAUNCH(ctx, "map_extract_pos", k_map_extract_pos<MAP_SRC_PACKED>, grid, 256, n, src, tpos.as<float4>());
+  int rc = rt_kd_build_device(ctx, tpos.as<float4>(), n, m->perm.as<int32_t>(), m->dim.as<uint8_t>(), m->bbox);
   if (rc != RT_OK) { delete m; return rc; }
   double *r64 = keep64 ? m->rec64.as<double>() : (double *)nullptr;
-  if (src_kind == MAP_SRC_REC64) RT_LAUNCH(ctx, "map_permute", k_map_permute<MAP_SRC_REC64>, grid, 256, n, src, m->perm.as<int32_t>(), m->dim.as<uint8_t>(), m->node.as<float4>(), m->pay.as<float>(), r64);
+  if (src_kind == MAP_SRC_REC64) RT_LAUNCH(ctx, "map_permute", k_map_permute_rec64, grid, 256, n, (const double *)src, m->perm.as<int32_t>(), m->dim.as<uint8_t>(), m->node.as<float4>(), m->pay.as<float>(), r64);
   else if (src_kind == MAP_SRC_FULL32) RT_LAUNCH(ctx, "map_permute", k_map_permute<MAP_SRC_FULL32>, grid, 256, n, src, m->perm.as<int32_t>(), m->dim.as<uint8_t>(), m->node.as<float4>(), m->pay.as<float>(), r64);
   else RT_LAUNCH(ctx, "map_permute", k_map_permute<MAP_SRC_PACKED>, grid, 256, n, src, m->perm.as<int32_t>(), m->dim.as<uint8_t>(), m->node.as<float4>(), m->pay.as<float>(), r64);
   if (hipStreamSynchronize(ctx->stream) != hipSuccess) { delete m; return rt_fail(ctx, RT_ERR_HIP, "photon map build failed"); }
