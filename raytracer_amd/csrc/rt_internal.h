@@ -79,6 +79,7 @@ struct rt_ctx {
     hipEvent_t e = nullptr; (void)hipEventCreate(&e); return e;
   }
   uint32_t *pinned = nullptr;    // small pinned scratch for counters read back each bounce
+  std::vector<uint32_t> kd_work; // the lower-level segments of the kd build in flight (read by a queued copy)
   RtKnobs knobs;
   DevMem ws_kd;                  // kd-tree build workspace (grow-only)
   // Device blocks of freed photon maps, kept for the next map of the same size (a map is six allocations of up to 88 bytes a
@@ -192,4 +193,4 @@ struct rt_photon_map {
 // looks up this device's copy of the static scratch array (rt_kd.hip); called by rt_init with the device current
 int rt_static_scratch_setup(rt_ctx *ctx);
 rt_ctx *rt_lists_ctx(rt_photon_lists *lists);
-int rt_kd_build_device(rt_ctx *ctx, const float4 *d_pos, uint32_t n, int32_t *d_perm, uint8_t *d_dim, float *bbox6);
+int rt_kd_build_device(rt_ctx *ctx, const float4 *d_pos, uint32_t n, int32_t *d_perm, uint8_t *d_dim, bool want_box);

@@ -263,6 +263,10 @@ struct KdSeg { uint32_t pos, start, len; };
 // thread need nothing, pairs inside a wave are exchanged by lane shuffles -- no LDS traffic and no barrier; only the steps
 // across waves (10 of the 66 at S = 2048) go through LDS, one pair per thread and barrier.  Called by all T threads with
 // the keys written and a barrier passed; returns with the sorted keys in LDS behind a barrier.
+// lane-shift move (DPP): every lane of the rows in ROWS takes `v` of the lane CTRL names, or `old` where there is none
+template <int CTRL, int ROWS> __device__ __forceinline__ uint32_t kd_lane_move(uint32_t old, uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, CTRL, ROWS, 0xF, false);
+}
 template <uint32_t S, uint32_t T> __device__ __forceinline__ void kd_lds_sort(unsigned long long *key, uint32_t tid) {
   constexpr uint32_t E = S / T, W = 64u * E;                 // W: elements of one wave
   unsigned long long e[E];
@@ -340,13 +344,13 @@ __global__ void __launch_bounds__(KD_LDS_T) k_kd_lds(const KdSeg *segs, const fl
   }
   int cur = 0;
   bool top = true;
+  for (uint32_t k = tid; k < (S / 2) * 6; k += T) u.bb[k] = (k % 6 < 3) ? 0xFFFFFFFFu : 0u;
   for (uint32_t maxlen = L; maxlen >= 1; maxlen = find_median(maxlen)) {
     __syncthreads();
-    for (uint32_t k = tid; k < (S / 2) * 6; k += T) u.bb[k] = (k % 6 < 3) ? 0xFFFFFFFFu : 0u;
-    __syncthreads();
-    // boxes of the segments with at least two photons: runs of lanes with one segment reduce by shuffles (after the step
-    // `off` a lane holds the bounds of the next 2 off positions of its run), then the first lane of a run adds them to
-    // the segment's box -- one atomic per run, axis and bound instead of one per photon on a few addresses
+    // boxes of the segments with at least two photons: runs of lanes with one segment reduce towards their last lane
+    // (a segmented scan over the wave by lane-shift moves: four steps inside the rows of 16 lanes, two across rows; a
+    // lane takes what arrives iff it comes from its own segment), which adds the bounds to the segment's box -- one atomic
+    // per run, axis and bound instead of one per photon on a few addresses
 #pragma unroll
     for (uint32_t r = 0; r < S / T; r++) {
       const uint32_t i = tid + r * T, lane = tid & 63u;
@@ -354,16 +358,21 @@ __global__ void __launch_bounds__(KD_LDS_T) k_kd_lds(const KdSeg *segs, const fl
       const uint32_t s = active ? (uint32_t)sstart[i] : 0xFFFFFFFFu;
       uint32_t lo[3] = { 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu }, hi[3] = { 0, 0, 0 };
       if (active) { const uint32_t l = lid[cur][i]; for (int d = 0; d < 3; d++) { lo[d] = hi[d] = sortable(crd[d][l]); } }
-      for (uint32_t off = 1; off < 64u && off < maxlen; off <<= 1) {
-        const uint32_t s_there = __shfl_down(s, off, 64);
-        const bool take = lane + off < 64u && s_there == s;
-        for (int d = 0; d < 3; d++) {
-          const uint32_t a = __shfl_down(lo[d], off, 64), b = __shfl_down(hi[d], off, 64);
-          if (take) { lo[d] = min(lo[d], a); hi[d] = max(hi[d], b); }
-        }
-      }
-      const uint32_t s_before = __shfl_up(s, 1, 64);
-      if (active && (lane == 0 || s_before != s))
+#define KD_SEG_STEP(CTRL, ROWS) {                                                                      \
+        const bool take = kd_lane_move<CTRL, ROWS>(0xFFFFFFFEu, s) == s;                                \
+        for (int d = 0; d < 3; d++) {                                                                   \
+          const uint32_t a = kd_lane_move<CTRL, ROWS>(lo[d], lo[d]), b = kd_lane_move<CTRL, ROWS>(hi[d], hi[d]); \
+          if (take) { lo[d] = min(lo[d], a); hi[d] = max(hi[d], b); }                                   \
+        } }
+      if (maxlen > 1) KD_SEG_STEP(0x111, 0xF)                 // row_shr:1 (a lane without a source keeps the first argument)
+      if (maxlen > 2) KD_SEG_STEP(0x112, 0xF)
+      if (maxlen > 4) KD_SEG_STEP(0x114, 0xF)
+      if (maxlen > 8) KD_SEG_STEP(0x118, 0xF)
+      KD_SEG_STEP(0x142, 0xA)                                 // row_bcast:15 into rows 1 and 3
+      KD_SEG_STEP(0x143, 0xC)                                 // row_bcast:31 into rows 2 and 3
+#undef KD_SEG_STEP
+      const uint32_t s_after = __shfl_down(s, 1, 64);
+      if (active && (lane == 63u || s_after != s))
         for (int d = 0; d < 3; d++) { atomicMin(&u.bb[(s >> 1) * 6 + d], lo[d]); atomicMax(&u.bb[(s >> 1) * 6 + 3 + d], hi[d]); }
     }
     __syncthreads();
@@ -417,14 +426,16 @@ __global__ void __launch_bounds__(KD_LDS_T) k_kd_lds(const KdSeg *segs, const fl
       else if (i < s + m) { spos[i] = 2 * sp; slen[i] = (uint16_t)m; }
       else { spos[i] = 2 * sp + 1; sstart[i] = (uint16_t)(s + m + 1); slen[i] = (uint16_t)(l - m - 1); }
     }
+    for (uint32_t k = tid; k < (S / 2) * 6; k += T) u.bb[k] = (k % 6 < 3) ? 0xFFFFFFFFu : 0u;      // (the keys are done with: empty boxes for the next level)
   }
 }
 static_assert(KD_LDS_S == (1u << KD_LDS_BITS) && KD_LDS_S % (2 * KD_LDS_T) == 0 && 32 + 2 * KD_LDS_BITS <= 64, "sort keys: group, coordinate, position");
 
 static float unsortable_host(uint32_t u) { u ^= ((u >> 31) ? 0x80000000u : 0xFFFFFFFFu); float f; memcpy(&f, &u, 4); return f; }
 
-// d_pos: the positions as float4 (w unused); bbox6 (optional, host): min xyz, max xyz of all positions
-int rt_kd_build_device(rt_ctx *ctx, const float4 *d_pos, uint32_t n, int32_t *d_perm, uint8_t *d_dim, float *bbox6) {
+// Queues the build on the context's stream and returns; the caller waits for the stream.  d_pos: the positions as float4
+// (w unused); want_box: min xyz, max xyz of all positions are copied to the context's pinned words (kd_take_box).
+int rt_kd_build_device(rt_ctx *ctx, const float4 *d_pos, uint32_t n, int32_t *d_perm, uint8_t *d_dim, bool want_box) {
   if (n == 0) return rt_fail(ctx, RT_ERR_EMPTY_TREE, "tried to build a k-d tree with no data!");   // kdtree.js:6
   if (n >= 0x7FFFFFFFu) return rt_fail(ctx, RT_ERR_TOO_LARGE, "photon map too large");
   // the levels handled over the whole array: while the longest segment is too long for one workgroup
@@ -439,8 +450,11 @@ int rt_kd_build_device(rt_ctx *ctx, const float4 *d_pos, uint32_t n, int32_t *d_
     }
     segs.swap(next); global_levels++;
   }
-  std::vector<KdSeg> work;
-  for (const KdSeg &g : segs) if (g.len) work.push_back(g);
+  std::vector<uint32_t> &work = ctx->kd_work;                 // (read by a queued copy: it has to outlive this call)
+  work.clear();
+  for (const KdSeg &g : segs) if (g.len) { work.push_back(g.pos); work.push_back(g.start); work.push_back(g.len); }
+  const size_t n_work = work.size() / 3;
+  static_assert(sizeof(KdSeg) == 12, "three words per segment");
   const size_t n_bb = ((size_t)2 << global_levels) + 2;       // boxes by heap position, levels 0 .. global_levels
   // one grow-only workspace per context
   size_t tmp_bytes = 0;
@@ -452,7 +466,7 @@ int rt_kd_build_device(rt_ctx *ctx, const float4 *d_pos, uint32_t n, int32_t *d_
   const bool glob = global_levels > 0;
   const size_t o_idxA = carve((size_t)n * 4), o_idxB = carve(glob ? (size_t)n * 4 : 0), o_keyA = carve(glob ? (size_t)n * 8 : 0), o_keyB = carve(glob ? (size_t)n * 8 : 0);
   const size_t o_pos = carve(glob ? (size_t)n * 4 : 0), o_start = carve(glob ? (size_t)n * 4 : 0), o_len = carve(glob ? (size_t)n * 4 : 0);
-  const size_t o_bbmin = carve(n_bb * 12), o_bbmax = carve(n_bb * 12), o_segdim = carve(n_bb), o_segs = carve(work.size() * sizeof(KdSeg)), o_tmp = carve(tmp_bytes);
+  const size_t o_bbmin = carve(n_bb * 12), o_bbmax = carve(n_bb * 12), o_segdim = carve(n_bb), o_segs = carve(n_work * sizeof(KdSeg)), o_tmp = carve(tmp_bytes);
   const size_t o_pcur = carve(glob ? (size_t)n * 16 : 0);
   RT_HIP(ctx, ctx->ws_kd.reserve(off));
   char *base = (char *)ctx->ws_kd.p;
@@ -471,7 +485,7 @@ int rt_kd_build_device(rt_ctx *ctx, const float4 *d_pos, uint32_t n, int32_t *d_
   } else {
     RT_LAUNCH(ctx, "kd_init", k_kd_iota, grid, 256, n, idx_cur);
   }
-  RT_HIP(ctx, hipMemcpyAsync(d_segs, work.data(), work.size() * sizeof(KdSeg), hipMemcpyHostToDevice, ctx->stream));
+  RT_HIP(ctx, hipMemcpyAsync(d_segs, work.data(), n_work * sizeof(KdSeg), hipMemcpyHostToDevice, ctx->stream));
   uint32_t first = 1;
   for (int level = 0; level < global_levels; level++, first <<= 1) {      // heap positions [first, 2 first) form one level
     RT_LAUNCH(ctx, "kd_keys", k_kd_keys, grid, 256, n, level == 0 ? d_pos : (const float4 *)pos_cur, sg, first, level, (const uint32_t *)bbmin, (const uint32_t *)bbmax, segdim, keyA);
@@ -484,17 +498,18 @@ int rt_kd_build_device(rt_ctx *ctx, const float4 *d_pos, uint32_t n, int32_t *d_
     RT_LAUNCH(ctx, "kd_split", k_kd_split, grid_chunks, 256, n, d_pos, (const uint32_t *)idx_cur, sg, (const uint8_t *)segdim, d_perm, d_dim, pos_cur,
               level + 1 < global_levels ? 1 : 0, bbmin, bbmax);
   }
-  if (!work.empty())
-    RT_LAUNCH(ctx, "kd_lds", k_kd_lds, (uint32_t)work.size(), KD_LDS_T, (const KdSeg *)d_segs, glob ? (const float4 *)pos_cur : d_pos, (const uint32_t *)idx_cur, bbmin, bbmax, d_perm, d_dim);
+  if (n_work)
+    RT_LAUNCH(ctx, "kd_lds", k_kd_lds, (uint32_t)n_work, KD_LDS_T, (const KdSeg *)d_segs, glob ? (const float4 *)pos_cur : d_pos, (const uint32_t *)idx_cur, bbmin, bbmax, d_perm, d_dim);
   RT_HIP(ctx, hipGetLastError());
-  RT_HIP(ctx, hipStreamSynchronize(ctx->stream));           // (`work` is read by the copy above until here)
-  if (bbox6) {                                              // the root segment's box (heap position 1) is never cleared again
-    uint32_t lo[3], hi[3];
-    RT_HIP(ctx, hipMemcpy(lo, bbmin + 3, 12, hipMemcpyDeviceToHost));
-    RT_HIP(ctx, hipMemcpy(hi, bbmax + 3, 12, hipMemcpyDeviceToHost));
-    for (int d = 0; d < 3; d++) { bbox6[d] = unsortable_host(lo[d]); bbox6[3 + d] = unsortable_host(hi[d]); }
+  if (want_box) {                                            // the root segment's box (heap position 1) is never cleared again
+    RT_HIP(ctx, hipMemcpyAsync(ctx->pinned, bbmin + 3, 12, hipMemcpyDeviceToHost, ctx->stream));
+    RT_HIP(ctx, hipMemcpyAsync(ctx->pinned + 3, bbmax + 3, 12, hipMemcpyDeviceToHost, ctx->stream));
   }
   return RT_OK;
+}
+// after the stream has been waited for: the box that a build with want_box left in the context's pinned words
+static void kd_take_box(rt_ctx *ctx, float *bbox6) {
+  for (int d = 0; d < 3; d++) { bbox6[d] = unsortable_host(ctx->pinned[d]); bbox6[3 + d] = unsortable_host(ctx->pinned[3 + d]); }
 }
 
 extern "C" int rt_kd_build(rt_ctx *ctx, const float *pos, uint32_t n, int32_t *perm, uint8_t *dim) {
@@ -507,7 +522,8 @@ extern "C" int rt_kd_build(rt_ctx *ctx, const float *pos, uint32_t n, int32_t *p
   RT_TRY(rt_stage_out_begin(ctx, dim, (size_t)n, tdim, &ddim));
   RT_HIP(ctx, tpos4.reserve((size_t)n * 16));
   RT_LAUNCH(ctx, "kd_pos4", k_kd_pos4, div_up(n, 256), 256, n, (const float *)dpos, tpos4.as<float4>());
-  RT_TRY(rt_kd_build_device(ctx, tpos4.as<float4>(), n, (int32_t *)dperm, (uint8_t *)ddim, nullptr));
+  RT_TRY(rt_kd_build_device(ctx, tpos4.as<float4>(), n, (int32_t *)dperm, (uint8_t *)ddim, false));
+  RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
   RT_TRY(rt_stage_out_end(ctx, perm, (size_t)n * 4, tperm));
   RT_TRY(rt_stage_out_end(ctx, dim, (size_t)n, tdim));
   return RT_OK;
@@ -599,13 +615,14 @@ int rt_map_build_device(rt_ctx *ctx, const void *src, int src_kind, uint32_t n, 
   if (src_kind == MAP_SRC_REC64) RT_LAUNCH(ctx, "map_extract_pos", k_map_extract_pos<MAP_SRC_REC64>, grid, 256, n, src, tpos.as<float4>());
   else if (src_kind == MAP_SRC_FULL32) RT_LAUNCH(ctx, "map_extract_pos", k_map_extract_pos<MAP_SRC_FULL32>, grid, 256, n, src, tpos.as<float4>());
   else RT_LAUNCH(ctx, "map_extract_pos", k_map_extract_pos<MAP_SRC_PACKED>, grid, 256, n, src, tpos.as<float4>());
-  int rc = rt_kd_build_device(ctx, tpos.as<float4>(), n, m->perm.as<int32_t>(), m->dim.as<uint8_t>(), m->bbox);
-  if (rc != RT_OK) { delete m; return rc; }
+  int rc = rt_kd_build_device(ctx, tpos.as<float4>(), n, m->perm.as<int32_t>(), m->dim.as<uint8_t>(), true);
+  if (rc != RT_OK) { (void)hipStreamSynchronize(ctx->stream); delete m; return rc; }
   double *r64 = keep64 ? m->rec64.as<double>() : (double *)nullptr;
   if (src_kind == MAP_SRC_REC64) RT_LAUNCH(ctx, "map_permute", k_map_permute_rec64, grid, 256, n, (const double *)src, m->perm.as<int32_t>(), m->dim.as<uint8_t>(), m->node.as<float4>(), m->pay.as<float>(), r64);
   else if (src_kind == MAP_SRC_FULL32) RT_LAUNCH(ctx, "map_permute", k_map_permute<MAP_SRC_FULL32>, grid, 256, n, src, m->perm.as<int32_t>(), m->dim.as<uint8_t>(), m->node.as<float4>(), m->pay.as<float>(), r64);
   else RT_LAUNCH(ctx, "map_permute", k_map_permute<MAP_SRC_PACKED>, grid, 256, n, src, m->perm.as<int32_t>(), m->dim.as<uint8_t>(), m->node.as<float4>(), m->pay.as<float>(), r64);
   if (hipStreamSynchronize(ctx->stream) != hipSuccess) { delete m; return rt_fail(ctx, RT_ERR_HIP, "photon map build failed"); }
+  kd_take_box(ctx, m->bbox);
   *out = m;
   return RT_OK;
 }
