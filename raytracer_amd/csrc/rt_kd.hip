@@ -82,7 +82,8 @@ __device__ __forceinline__ float unsortable(uint32_t u) {
 }
 
 // per array position: heap position of its segment, or KD_DONE | heap position of the node it has become
-struct SegState { uint32_t *pos, *start, *len; };
+// (start and length of a segment follow from the array's size and the heap position alone: the host tabulates them)
+struct SegState { uint32_t *pos; const uint2 *tab; };
 #define KD_DONE 0x80000000u
 __global__ void __launch_bounds__(256) k_kd_iota(uint32_t n, uint32_t *idx) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -94,7 +95,7 @@ __global__ void __launch_bounds__(256) k_kd_init(uint32_t n, uint32_t *idx, SegS
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n_box_words) { bbmin[i] = 0xFFFFFFFFu; bbmax[i] = 0u; }
   if (i >= n) return;
-  idx[i] = i; sg.pos[i] = 1; sg.start[i] = 0; sg.len[i] = n;
+  idx[i] = i; sg.pos[i] = 1;
 }
 __global__ void __launch_bounds__(256) k_kd_pos4(uint32_t n, const float *pos3, float4 *pos4) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -201,7 +202,7 @@ __global__ void __launch_bounds__(256) k_kd_keys(uint32_t n, const float4 *pos_c
     return;
   }
   const int d = widest_dim3(bbmin + (size_t)sp * 3, bbmax + (size_t)sp * 3);
-  if (i == sg.start[i]) segdim[sp] = (uint8_t)d;
+  if (i == sg.tab[sp].x) segdim[sp] = (uint8_t)d;
   const float4 p = pos_cur[i];
   keys[i] = ((uint64_t)(sp - first) << 32) | sortable(d == 0 ? p.x : (d == 1 ? p.y : p.z));
 }
@@ -229,11 +230,12 @@ __global__ void __launch_bounds__(256) k_kd_split(uint32_t n, const float4 *pos4
     const uint32_t sp = sg.pos[i];
     uint32_t s = 0, len = 0;
     if (!(sp & KD_DONE)) {
-      s = sg.start[i]; len = sg.len[i];
+      const uint2 sl = sg.tab[sp];
+      s = sl.x; len = sl.y;
       const uint32_t m = find_median(len);
       if (i == s + m) { perm[sp - 1] = (int32_t)id; dim[sp - 1] = segdim[sp]; sg.pos[i] = sp | KD_DONE; }
-      else if (i < s + m) { sp_new[r] = 2 * sp; len = m; sg.pos[i] = sp_new[r]; sg.len[i] = len; }
-      else { sp_new[r] = 2 * sp + 1; s = s + m + 1; len = len - m - 1; sg.pos[i] = sp_new[r]; sg.start[i] = s; sg.len[i] = len; }
+      else if (i < s + m) { sp_new[r] = 2 * sp; len = m; sg.pos[i] = sp_new[r]; }
+      else { sp_new[r] = 2 * sp + 1; s = s + m + 1; len = len - m - 1; sg.pos[i] = sp_new[r]; }
     }
     if (r == 0 && threadIdx.x == 0) { head[0] = sp_new[0]; head[1] = s; head[2] = len; }
   }
@@ -440,20 +442,23 @@ int rt_kd_build_device(rt_ctx *ctx, const float4 *d_pos, uint32_t n, int32_t *d_
   if (n >= 0x7FFFFFFFu) return rt_fail(ctx, RT_ERR_TOO_LARGE, "photon map too large");
   // the levels handled over the whole array: while the longest segment is too long for one workgroup
   std::vector<KdSeg> segs = { { 1u, 0u, n } };
+  std::vector<uint32_t> &work = ctx->kd_work;                 // (read by a queued copy: it has to outlive this call)
+  work.assign(2, 0u);                                        // first the table (start, length) by heap position of the levels split over the whole array
   int global_levels = 0;
   for (uint32_t maxlen = n; maxlen > KD_LDS_S; maxlen = find_median(maxlen)) {
     std::vector<KdSeg> next; next.reserve(segs.size() * 2);
     for (const KdSeg &g : segs) {
+      work.push_back(g.start); work.push_back(g.len);        // (heap positions in order: this is entry g.pos)
       if (g.len == 0) { next.push_back({ 2 * g.pos, g.start, 0u }); next.push_back({ 2 * g.pos + 1, g.start, 0u }); continue; }
       const uint32_t m = find_median(g.len);
       next.push_back({ 2 * g.pos, g.start, m }); next.push_back({ 2 * g.pos + 1, g.start + m + 1, g.len - m - 1 });
     }
     segs.swap(next); global_levels++;
   }
-  std::vector<uint32_t> &work = ctx->kd_work;                 // (read by a queued copy: it has to outlive this call)
-  work.clear();
+  if (global_levels == 0) work.clear();
+  const size_t n_tab = work.size() / 2;
   for (const KdSeg &g : segs) if (g.len) { work.push_back(g.pos); work.push_back(g.start); work.push_back(g.len); }
-  const size_t n_work = work.size() / 3;
+  const size_t n_work = (work.size() - 2 * n_tab) / 3;
   static_assert(sizeof(KdSeg) == 12, "three words per segment");
   const size_t n_bb = ((size_t)2 << global_levels) + 2;       // boxes by heap position, levels 0 .. global_levels
   // one grow-only workspace per context
@@ -465,17 +470,17 @@ int rt_kd_build_device(rt_ctx *ctx, const float4 *d_pos, uint32_t n, int32_t *d_
   auto carve = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
   const bool glob = global_levels > 0;
   const size_t o_idxA = carve((size_t)n * 4), o_idxB = carve(glob ? (size_t)n * 4 : 0), o_keyA = carve(glob ? (size_t)n * 8 : 0), o_keyB = carve(glob ? (size_t)n * 8 : 0);
-  const size_t o_pos = carve(glob ? (size_t)n * 4 : 0), o_start = carve(glob ? (size_t)n * 4 : 0), o_len = carve(glob ? (size_t)n * 4 : 0);
-  const size_t o_bbmin = carve(n_bb * 12), o_bbmax = carve(n_bb * 12), o_segdim = carve(n_bb), o_segs = carve(n_work * sizeof(KdSeg)), o_tmp = carve(tmp_bytes);
+  const size_t o_pos = carve(glob ? (size_t)n * 4 : 0);
+  const size_t o_bbmin = carve(n_bb * 12), o_bbmax = carve(n_bb * 12), o_segdim = carve(n_bb), o_segs = carve(work.size() * 4), o_tmp = carve(tmp_bytes);
   const size_t o_pcur = carve(glob ? (size_t)n * 16 : 0);
   RT_HIP(ctx, ctx->ws_kd.reserve(off));
   char *base = (char *)ctx->ws_kd.p;
   uint32_t *idx_cur = (uint32_t *)(base + o_idxA), *idx_nxt = (uint32_t *)(base + o_idxB);
   uint64_t *keyA = (uint64_t *)(base + o_keyA), *keyB = (uint64_t *)(base + o_keyB);
-  SegState sg = { (uint32_t *)(base + o_pos), (uint32_t *)(base + o_start), (uint32_t *)(base + o_len) };
+  SegState sg = { (uint32_t *)(base + o_pos), (const uint2 *)(base + o_segs) };
   uint32_t *bbmin = (uint32_t *)(base + o_bbmin), *bbmax = (uint32_t *)(base + o_bbmax);
   uint8_t *segdim = (uint8_t *)(base + o_segdim);
-  KdSeg *d_segs = (KdSeg *)(base + o_segs);
+  KdSeg *d_segs = (KdSeg *)(base + o_segs + n_tab * 8);
   float4 *pos_cur = (float4 *)(base + o_pcur);               // the positions in the array's current order, from the first split on
   const uint32_t grid = div_up(n, 256), grid_chunks = div_up(n, 256u * KD_BBOX_ITEMS);
   if (glob) {
@@ -485,7 +490,7 @@ int rt_kd_build_device(rt_ctx *ctx, const float4 *d_pos, uint32_t n, int32_t *d_
   } else {
     RT_LAUNCH(ctx, "kd_init", k_kd_iota, grid, 256, n, idx_cur);
   }
-  RT_HIP(ctx, hipMemcpyAsync(d_segs, work.data(), n_work * sizeof(KdSeg), hipMemcpyHostToDevice, ctx->stream));
+  RT_HIP(ctx, hipMemcpyAsync(base + o_segs, work.data(), work.size() * 4, hipMemcpyHostToDevice, ctx->stream));
   uint32_t first = 1;
   for (int level = 0; level < global_levels; level++, first <<= 1) {      // heap positions [first, 2 first) form one level
     RT_LAUNCH(ctx, "kd_keys", k_kd_keys, grid, 256, n, level == 0 ? d_pos : (const float4 *)pos_cur, sg, first, level, (const uint32_t *)bbmin, (const uint32_t *)bbmax, segdim, keyA);
