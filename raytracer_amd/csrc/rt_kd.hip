@@ -266,8 +266,20 @@ struct KdSeg { uint32_t pos, start, len; };
 // across waves (10 of the 66 at S = 2048) go through LDS, one pair per thread and barrier.  Called by all T threads with
 // the keys written and a barrier passed; returns with the sorted keys in LDS behind a barrier.
 // lane-shift move (DPP): every lane of the rows in ROWS takes `v` of the lane CTRL names, or `old` where there is none
-template <int CTRL, int ROWS> __device__ __forceinline__ uint32_t kd_lane_move(uint32_t old, uint32_t v) {
-  return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, CTRL, ROWS, 0xF, false);
+template <int CTRL, int ROWS, int BANKS = 0xF> __device__ __forceinline__ uint32_t kd_lane_move(uint32_t old, uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, CTRL, ROWS, BANKS, false);
+}
+// v of the lane whose number differs in the bit `dist` (wave-uniform, a power of two below 64): lane-shift moves where the
+// partner is in the lane's row of 16 (quad permutes for 1 and 2, a shift either way for 4, a rotation for 8), else through
+// the LDS crossbar
+__device__ __forceinline__ uint32_t kd_lane_xor(uint32_t v, uint32_t dist) {
+  switch (dist) {
+    case 1: return kd_lane_move<0xB1, 0xF>(v, v);                                  // quad_perm [1,0,3,2]
+    case 2: return kd_lane_move<0x4E, 0xF>(v, v);                                  // quad_perm [2,3,0,1]
+    case 4: { const uint32_t t = kd_lane_move<0x104, 0xF, 0x5>(v, v); return kd_lane_move<0x114, 0xF, 0xA>(t, v); }   // row_shl:4 for lanes 0-3, 8-11; row_shr:4 for the others
+    case 8: return kd_lane_move<0x128, 0xF>(v, v);                                 // row_ror:8
+    default: return (uint32_t)__shfl_xor((int)v, (int)dist, 64);
+  }
 }
 template <uint32_t S, uint32_t T> __device__ __forceinline__ void kd_lds_sort(unsigned long long *key, uint32_t tid) {
   constexpr uint32_t E = S / T, W = 64u * E;                 // W: elements of one wave
@@ -287,7 +299,7 @@ template <uint32_t S, uint32_t T> __device__ __forceinline__ void kd_lds_sort(un
       for (uint32_t q = 0; q < E; q++) {
         const uint32_t i = tid * E + q;
         const unsigned long long mine = e[q];
-        const uint32_t olo = (uint32_t)__shfl_xor((int)(uint32_t)mine, (int)(j / E), 64), ohi = (uint32_t)__shfl_xor((int)(uint32_t)(mine >> 32), (int)(j / E), 64);
+        const uint32_t olo = kd_lane_xor((uint32_t)mine, j / E), ohi = kd_lane_xor((uint32_t)(mine >> 32), j / E);
         const unsigned long long other = ((unsigned long long)ohi << 32) | olo;
         const bool want_min = ((i & j) == 0) == ((i & k) == 0);
         e[q] = ((other < mine) == want_min) ? other : mine;
