@@ -634,20 +634,28 @@ def main():
             bufs_ = {}
             frames0_ = torch.empty((group, Hd, Wd, 4), dtype=torch.uint8, device=cdev) if rank == 0 else None
 
-            def frame_group(n):
-                if n not in bufs_:
-                    bufs_[n] = torch.empty((n, rows_, Wd, 4), dtype=torch.uint8, device=dev)
-                engine.out = bufs_[n]
-                parallel.render_sharded_batch(engine, Wd, Hd, n, band=args.band, out=frames0_[:n] if rank == 0 else None)
+            def frame_groups(sizes):
+                """the groups one after the other, a group's gather running beside the next group's tracing (two band buffers)"""
+                pending = None
+                for k, n in enumerate(sizes):
+                    if (n, k & 1) not in bufs_:
+                        bufs_[(n, k & 1)] = torch.empty((n, rows_, Wd, 4), dtype=torch.uint8, device=dev)
+                    engine.out = bufs_[(n, k & 1)]
+                    parts = parallel.trace_bands_batch(engine, Wd, Hd, n, band=args.band)
+                    if pending is not None:
+                        parallel.gather_bands_end(pending[0], Wd, Hd, band=args.band, out=frames0_[:pending[1]] if rank == 0 else None)
+                    pending = (parallel.gather_bands_begin(parts, Hd, band=args.band), n)
+                if pending is not None:
+                    parallel.gather_bands_end(pending[0], Wd, Hd, band=args.band, out=frames0_[:pending[1]] if rank == 0 else None)
 
-            for g0 in range(0, max(n_warm, 1), group):
-                frame_group(min(group, max(n_warm, 1) - g0))
-            if n_frames % group and n_frames > group:
-                frame_group(n_frames % group)    # (the last, shorter batch's buffer exists before the clock starts)
+            sizes_of = lambda total: [min(group, total - g0) for g0 in range(0, total, group)]
+            for k, n in enumerate(sizes_of(n_frames)):  # (every band buffer of the timed run exists before the clock starts)
+                if (n, k & 1) not in bufs_:
+                    bufs_[(n, k & 1)] = torch.empty((n, rows_, Wd, 4), dtype=torch.uint8, device=dev)
+            frame_groups(sizes_of(max(n_warm, 1)))
             barrier()
             t0_ = time.perf_counter()
-            for g0 in range(0, n_frames, group):
-                frame_group(min(group, n_frames - g0))
+            frame_groups(sizes_of(n_frames))
             barrier()
             dt_ = time.perf_counter() - t0_
             tm_ = torch.tensor([dt_], dtype=torch.float64, device=cdev)

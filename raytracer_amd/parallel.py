@@ -207,26 +207,42 @@ def render_sharded(engine, width, height, band=16, out=None):
 _ROWS = {}
 
 
-def render_sharded_batch(engine, width, height, n_frames, band=16, out=None):
-    """n_frames frames at once: every rank traces its row bands of all of them back to back, ONE gather brings the
-    (n_frames, rows_k, width, C) parts to rank 0, which returns the assembled (n_frames, height, width, C) tensor
-    (others None).  One collective and one host wait per batch instead of per frame: a frame's bands take tens of
-    microseconds to trace, less than a collective's latency."""
+def trace_bands_batch(engine, width, height, n_frames, band=16):
+    """this rank's row bands of n_frames frames, traced back to back and finished: (n_frames, rows, width, C)"""
     rank, world = _world()
     if hasattr(engine, "render_bands_batch"):
-        parts = engine.render_bands_batch(width, height, band, world, rank, n_frames)
-    else:
-        parts = torch.stack([engine.render_bands(width, height, band, world, rank) for _ in range(n_frames)])
+        return engine.render_bands_batch(width, height, band, world, rank, n_frames)
+    return torch.stack([engine.render_bands(width, height, band, world, rank) for _ in range(n_frames)])
+
+
+def gather_bands_begin(parts, height, band=16):
+    """starts the ONE gather that brings every rank's (n_frames, rows_k, width, C) bands to rank 0 and returns a handle
+    for gather_bands_end; the collective runs beside whatever the caller queues next (the next batch's tracing).  The
+    caller leaves `parts` alone until gather_bands_end has returned."""
+    rank, world = _world()
     if world == 1:
-        return parts
+        return {"parts": parts, "work": None, "got": None}
     rows_max = max(len(band_rows_of(height, band, world, k)) for k in range(world))
     if parts.shape[1] < rows_max:
         pad = torch.zeros((parts.shape[0], rows_max - parts.shape[1]) + tuple(parts.shape[2:]), dtype=parts.dtype, device=parts.device)
         parts = torch.cat([parts, pad], dim=1)
+    parts = parts.contiguous()
     got = [torch.empty_like(parts) for _ in range(world)] if rank == 0 else None
-    dist.gather(parts.contiguous(), got, dst=0)
+    work = dist.gather(parts, got, dst=0, async_op=True)
+    return {"parts": parts, "work": work, "got": got}
+
+
+def gather_bands_end(handle, width, height, band=16, out=None):
+    """waits for a gather begun with gather_bands_begin; rank 0 returns the assembled (n_frames, height, width, C) frames
+    (in `out` if given), the others None"""
+    rank, world = _world()
+    parts = handle["parts"]
+    if world == 1:
+        return parts
+    handle["work"].wait()
     if rank != 0:
         return None
+    got, n_frames = handle["got"], parts.shape[0]
     frames = out if out is not None else torch.empty((n_frames, height, width) + tuple(parts.shape[3:]), dtype=parts.dtype, device=parts.device)
     for k in range(world):
         key = (height, band, world, k, str(parts.device))
@@ -236,6 +252,16 @@ def render_sharded_batch(engine, width, height, n_frames, band=16, out=None):
     if parts.is_cuda:
         torch.cuda.current_stream().synchronize()
     return frames
+
+
+def render_sharded_batch(engine, width, height, n_frames, band=16, out=None):
+    """n_frames frames at once: every rank traces its row bands of all of them back to back, ONE gather brings the
+    (n_frames, rows_k, width, C) parts to rank 0, which returns the assembled (n_frames, height, width, C) tensor
+    (others None).  One collective and one host wait per batch instead of per frame: a frame's bands take tens of
+    microseconds to trace, less than a collective's latency.  (A caller with several batches overlaps a batch's gather
+    with the next batch's tracing through the three functions above.)"""
+    parts = trace_bands_batch(engine, width, height, n_frames, band)
+    return gather_bands_end(gather_bands_begin(parts, height, band), width, height, band, out)
 
 
 class DeviceEngine:

@@ -97,8 +97,14 @@ def _worker(rank, world, port, out_dir):
         eng.maps = ora.Maps(lists["diffuse"], lists["caustic"])
         frame = parallel.render_sharded(eng, W, H, band=8)
         batch = parallel.render_sharded_batch(eng, W, H, 3, band=8)  # three frames' bands in one collective
+        # two batches with the first one's gather left running while the second is traced
+        h1 = parallel.gather_bands_begin(parallel.trace_bands_batch(eng, W, H, 2, band=8), H, band=8)
+        parts2 = parallel.trace_bands_batch(eng, W, H, 1, band=8)
+        over1 = parallel.gather_bands_end(h1, W, H, band=8)
+        over2 = parallel.gather_bands_end(parallel.gather_bands_begin(parts2, H, band=8), W, H, band=8)
+        over = torch.cat([over1, over2]) if over1 is not None else None
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), frame=frame.numpy() if frame is not None else np.zeros(0),
-                 batch=batch.numpy() if batch is not None else np.zeros(0),
+                 batch=batch.numpy() if batch is not None else np.zeros(0), over=over.numpy() if over is not None else np.zeros(0),
                  attempts1=res["attempts1"], attempts2=res["attempts2"], allgather_bytes=T["allgather_bytes"], **lists)
     finally:
         dist.destroy_process_group()
@@ -148,5 +154,6 @@ def test_world_size_2_matches_single_process(tmp_path):
     assert r1["frame"].size == 0
     # the batched gather: every frame of the batch is that same frame (the oracle engine renders one seed)
     assert r0["batch"].shape == (3,) + post.shape and r1["batch"].size == 0
-    for f in r0["batch"]:
+    assert r0["over"].shape == (3,) + post.shape and r1["over"].size == 0
+    for f in list(r0["batch"]) + list(r0["over"]):
         assert ((f == post) | (np.isnan(f) & np.isnan(post))).all()
