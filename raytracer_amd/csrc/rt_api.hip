@@ -1170,9 +1170,17 @@ static int emit_many_lists(rt_scene *sc, const rt_params *p, int format, rt_phot
   for (int phase = 1; phase <= 2 && !st.capped; phase++) {
     uint64_t attempt = 0;
     const uint64_t cap = 100ull * (phase == 1 ? ND : NC);
+    const uint32_t got0 = phase == 1 ? nd : nc;                // what the list held when the phase began
     while (phase == 1 ? nd < ND : nc < NC) {
-      const uint32_t need = phase == 1 ? ND - nd : NC - nc;
-      uint64_t batch = std::min<uint64_t>(std::max<uint64_t>(4ull * need, 65536), 8u << 20);
+      const uint32_t need = phase == 1 ? ND - nd : NC - nc, got = (phase == 1 ? nd : nc) - got0;
+      // Batch sizes.  Every attempt of a batch is traced, also those behind the attempt that fills the list, so a batch
+      // should end just behind it: a first batch of at most 2^18 attempts measures the phase's yield (photons per attempt;
+      // 0.2 % off at that size), the next one is sized for what is still missing plus 1 %, and whatever a rare shortfall
+      // leaves takes batches of the smallest size.  While nothing has been stored the batches grow as 4 x the need.
+      uint64_t batch = std::max<uint64_t>(4ull * need, 65536);
+      if (attempt == 0) batch = std::min<uint64_t>(batch, 1u << 18);
+      else if (got > 0) batch = std::max<uint64_t>((uint64_t)((double)need * (double)attempt / (double)got * 1.01) + 4096, 65536);
+      batch = std::min<uint64_t>(batch, 8u << 20);
       batch = std::min<uint64_t>(batch, cap + 1 - attempt);
       const uint32_t count = (uint32_t)batch;
       RT_TRY(emit_batch(sc, p, phase, attempt, count));
