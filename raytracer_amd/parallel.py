@@ -114,12 +114,21 @@ def emit_sharded(engine, batch=1 << 22, world_override=None, timings=None):
     for phase in (1, 2):
         a = 0
         limit = 100 * (nd_cap if phase == 1 else nc_cap)            # rayphoton.js:1365, :1377
+        got0 = engine.counts()[phase - 1]                             # what the phase's list held when the phase began
         while not engine.phase_done(phase):
-            # a round runs about four times the attempts the phase's list still needs (every attempt stores at most one
-            # photon, most store none), within [65536 per rank, batch] and the reference's attempt limit
+            # Every attempt of a round is traced, also those behind the attempt that fills the list, so a round should
+            # end just behind it: the first round (at most 2^18 attempts per rank) measures the phase's yield, the next is
+            # sized for what is still missing plus 1 %; while nothing has been stored the rounds run four times the need.
+            # All within [65536 per rank, batch] and the reference's attempt limit.
             nd_now, nc_now = engine.counts()
             need = (nd_cap - nd_now) if phase == 1 else (nc_cap - nc_now)
-            b = int(min(batch, max(4 * need, 65536 * nranks), limit + 1 - a))
+            got = (nd_now if phase == 1 else nc_now) - got0
+            b = max(4 * need, 65536 * nranks)
+            if a == 0:
+                b = min(b, (1 << 18) * nranks)
+            elif got > 0:
+                b = max(int(need * a / got * 1.01) + 4096, 65536 * nranks)
+            b = int(min(batch, b, limit + 1 - a))
             bounds = [a + (b * k) // nranks for k in range(nranks + 1)]   # contiguous sub-ranges in rank order = attempt order
             t0 = time.perf_counter()
             mine = range(nranks) if sim else [rank]
