@@ -8,25 +8,33 @@
 
 // exclusive scan of n block counts by one workgroup of 1024; total goes to *total.
 // item_count (may be null): device-side number of items; when given, n = ceil(*item_count / 256).
-// Each thread owns a contiguous run of counts; run sums are scanned with wave shuffles.
+// Tiles of 4096 counts: a thread takes four consecutive counts (neighbouring threads read neighbouring addresses), the
+// tile's thread sums are scanned with wave shuffles and 16 wave sums, and the running total carries into the next tile.
 static __global__ void __launch_bounds__(1024) k_scan_blocks(uint32_t *block_count, uint32_t n, uint32_t *total,
                                                              const uint32_t *item_count = nullptr) {
   __shared__ uint32_t wave_sum[16];
   if (item_count) n = (*item_count + 255u) / 256u;
-  const uint32_t per = (n + 1023) / 1024;
-  const uint32_t b = threadIdx.x * per, e = (b + per < n) ? b + per : n;
-  uint32_t s = 0;
-  for (uint32_t i = b; i < e; i++) s += block_count[i];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  uint32_t incl = s;                                      // inclusive scan inside the wave
-  for (int off = 1; off < 64; off <<= 1) { uint32_t v = __shfl_up(incl, off, 64); if (lane >= off) incl += v; }
-  if (lane == 63) wave_sum[wv] = incl;
-  __syncthreads();
-  uint32_t base = 0;
-  for (int w = 0; w < wv; w++) base += wave_sum[w];
-  if (threadIdx.x == 1023) *total = base + incl;
-  uint32_t run = base + incl - s;
-  for (uint32_t i = b; i < e; i++) { uint32_t v = block_count[i]; block_count[i] = run; run += v; }
+  uint32_t carry = 0;
+  for (uint32_t tile = 0; tile < n; tile += 4096u) {           // (workgroup-uniform)
+    const uint32_t i0 = tile + threadIdx.x * 4u;
+    uint32_t v[4];
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++) v[k] = i0 + k < n ? block_count[i0 + k] : 0u;
+    const uint32_t s = v[0] + v[1] + v[2] + v[3];
+    uint32_t incl = s;                                      // inclusive scan inside the wave
+    for (int off = 1; off < 64; off <<= 1) { uint32_t o = __shfl_up(incl, off, 64); if (lane >= off) incl += o; }
+    if (lane == 63) wave_sum[wv] = incl;
+    __syncthreads();
+    uint32_t base = carry, all = 0;
+    for (int w = 0; w < 16; w++) { const uint32_t c = wave_sum[w]; if (w < wv) base += c; all += c; }
+    uint32_t run = base + incl - s;
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++) { if (i0 + k < n) block_count[i0 + k] = run; run += v[k]; }
+    carry += all;
+    __syncthreads();                                        // (the wave sums are read before the next tile overwrites them)
+  }
+  if (threadIdx.x == 0) *total = carry;
 }
 
 // Inside a 256-thread workgroup: publish this wave's keep-mask and the workgroup's keep-count.

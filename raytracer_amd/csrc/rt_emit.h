@@ -376,7 +376,13 @@ static __global__ void k_lists_finish(const uint32_t *totals, int phase, uint32_
 // sum of the per-attempt segment counts of attempts [0, upto) of a batch (emitPhoton calls the sequential loop makes)
 static __global__ void __launch_bounds__(256) k_sum_segments(const uint8_t *nseg, uint32_t upto, unsigned long long *out) {
   unsigned long long s = 0;
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < upto; i += gridDim.x * blockDim.x) s += nseg[i];
+  const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x, n16 = upto / 16u;
+  const uint4 *words = (const uint4 *)nseg;                  // (the array starts a device allocation: 16-byte aligned)
+  for (uint32_t i = gtid; i < n16; i += stride) {
+    const uint4 v = words[i];
+    s += __builtin_amdgcn_sad_u8(v.x, 0u, 0u) + __builtin_amdgcn_sad_u8(v.y, 0u, 0u) + __builtin_amdgcn_sad_u8(v.z, 0u, 0u) + __builtin_amdgcn_sad_u8(v.w, 0u, 0u);   // sums of four bytes
+  }
+  for (uint32_t i = n16 * 16u + gtid; i < upto; i += stride) s += nseg[i];
   for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
   if ((threadIdx.x & 63) == 0 && s) atomicAdd(out, s);
 }
