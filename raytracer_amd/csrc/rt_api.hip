@@ -1033,8 +1033,10 @@ void rt_lists_free(rt_photon_lists *L) { if (L) { (void)hipSetDevice(L->ctx->dev
 uint32_t rt_lists_record_words(const rt_photon_lists *L) { return L ? L->W : 0; }
 rt_ctx *rt_lists_ctx(rt_photon_lists *L) { return L->ctx; }
 
-int rt_lists_apply(rt_photon_lists *L, int phase, uint64_t tag_base, const uint32_t *shards, const uint32_t *counts, uint32_t n_shards,
-                   uint32_t stride, rt_lists_info *info) {
+// extent: the merged positions to look at -- n_shards * stride, or fewer when the caller knows that no record lies beyond
+// (one shard whose count the host has read)
+static int lists_apply(rt_photon_lists *L, int phase, uint64_t tag_base, const uint32_t *shards, const uint32_t *counts, uint32_t n_shards,
+                       uint32_t stride, uint32_t extent, rt_lists_info *info) {
   if (!L) return RT_ERR_INVALID;
   rt_ctx *ctx = L->ctx;
   if (phase != 1 && phase != 2) return rt_fail(ctx, RT_ERR_INVALID, "phase must be 1 or 2");
@@ -1044,7 +1046,7 @@ int rt_lists_apply(rt_photon_lists *L, int phase, uint64_t tag_base, const uint3
   DevMem ts, tc; const void *dsh, *dct;
   RT_TRY(rt_stage_in(ctx, shards, (size_t)n_shards * stride * (L->W + 1) * 4, ts, &dsh));
   RT_TRY(rt_stage_in(ctx, counts, (size_t)n_shards * 4, tc, &dct));
-  const uint32_t total = n_shards * stride, blocks = div_up(total, 256);
+  const uint32_t total = std::max(1u, std::min(extent, n_shards * stride)), blocks = div_up(total, 256);
   RT_HIP(ctx, L->blocks.reserve(((size_t)blocks * 2 + 2) * 4));
   uint32_t *bd = L->blocks.as<uint32_t>(), *bcq = bd + blocks, *totals = bcq + blocks;
   ListsState *st = L->state.as<ListsState>();
@@ -1072,6 +1074,11 @@ int rt_lists_apply(rt_photon_lists *L, int phase, uint64_t tag_base, const uint3
     info->last_attempt = info->phase_ended ? tag_base + L->host.last_tag : 0;
   }
   return RT_OK;
+}
+
+int rt_lists_apply(rt_photon_lists *L, int phase, uint64_t tag_base, const uint32_t *shards, const uint32_t *counts, uint32_t n_shards,
+                   uint32_t stride, rt_lists_info *info) {
+  return lists_apply(L, phase, tag_base, shards, counts, n_shards, stride, 0xFFFFFFFFu, info);
 }
 
 int rt_lists_counts(rt_photon_lists *L, uint32_t *n_diffuse, uint32_t *n_caustic) {
@@ -1188,8 +1195,12 @@ static int emit_many_lists(rt_scene *sc, const rt_params *p, int format, rt_phot
       uint32_t *shard = sc->ws_emit_shard.as<uint32_t>(), *n_dev = shard + (size_t)count * (W + 1);
       if (p->precision == RT_PRECISION_F64) RT_TRY(pl_emit_shard<double>(sc, count, format, 0u, count, shard, n_dev));
       else RT_TRY(pl_emit_shard<float>(sc, count, format, 0u, count, shard, n_dev));
+      // (the caps look at the shard's records only, not at a position per attempt: the count is worth a host round trip)
+      RT_HIP(ctx, hipMemcpyAsync(ctx->pinned, n_dev, 4, hipMemcpyDeviceToHost, ctx->stream));
+      RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      const uint32_t n_stored = std::min(ctx->pinned[0], count);
       rt_lists_info info;
-      RT_TRY(rt_lists_apply(L, phase, attempt, shard, n_dev, 1, count, &info));
+      RT_TRY(lists_apply(L, phase, attempt, shard, n_dev, 1, count, n_stored, &info));
       nd = info.n_diffuse; nc = info.n_caustic;
       const uint64_t last_attempt = info.phase_ended ? info.last_attempt : attempt + count - 1;    // last attempt the sequential loop would run
       RT_LAUNCH(ctx, "sum_segments", k_sum_segments, 256, 256, (const uint8_t *)sc->ws_emit_seg.p, (uint32_t)(last_attempt - attempt + 1), seg_exact);

@@ -248,10 +248,14 @@ __global__ void __launch_bounds__(256) k_compact_scatter(const uint8_t *kind, co
 // (RT_SHARD_FULL / RT_SHARD_PACKED: include/rt355.h)
 template <typename T> constexpr uint32_t shard_words(int format) { return format == RT_SHARD_PACKED ? 9u : (uint32_t)(11 * sizeof(T) / 4); }
 
+// (A workgroup's records are made in LDS and written as one run of consecutive words: a lane writing its own record
+// stores ten words 40 bytes apart from its neighbour's.)
 template <typename T, int FORMAT>
 __global__ void __launch_bounds__(256) k_compact_shard(const uint8_t *kind, const T *rec, uint32_t count, const uint32_t *block_offset,
                                                        uint32_t tag_offset, uint32_t cap, uint32_t *shard) {
+  constexpr uint32_t W = shard_words<T>(FORMAT), RW = W + 1;
   __shared__ uint32_t wave_cnt[4];
+  __shared__ uint32_t stage[256 * RW];
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   const uint8_t kd = i < count ? kind[i] : 0;
   const bool m = kd != 0;
@@ -259,23 +263,27 @@ __global__ void __launch_bounds__(256) k_compact_shard(const uint8_t *kind, cons
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   if (lane == 0) wave_cnt[wv] = (uint32_t)__popcll(mask);
   __syncthreads();
-  if (!m) return;
-  uint32_t rank = block_offset[blockIdx.x] + (uint32_t)__popcll(mask & (((unsigned long long)1 << lane) - 1));
-  for (int w = 0; w < wv; w++) rank += wave_cnt[w];
-  if (rank >= cap) return;
-  constexpr uint32_t W = shard_words<T>(FORMAT);
-  const T *r = rec + (size_t)i * RT_REC_STRIDE;
-  uint32_t *o = shard + (size_t)rank * (W + 1);
-  if (FORMAT == RT_SHARD_PACKED) {
-    float *f = (float *)o;
-    f[0] = (float)r[0]; f[1] = (float)r[1]; f[2] = (float)r[2]; f[3] = (float)r[3]; f[4] = (float)r[4]; f[5] = (float)r[5];
-    f[6] = (float)(r[7] * r[6]); f[7] = (float)(r[8] * r[6]); f[8] = (float)(r[9] * r[6]);
-  } else {
-    const uint32_t *src = (const uint32_t *)r;
+  if (m) {
+    uint32_t local = (uint32_t)__popcll(mask & (((unsigned long long)1 << lane) - 1));
+    for (int w = 0; w < wv; w++) local += wave_cnt[w];
+    const T *r = rec + (size_t)i * RT_REC_STRIDE;
+    uint32_t *o = stage + local * RW;
+    if (FORMAT == RT_SHARD_PACKED) {
+      float *f = (float *)o;
+      f[0] = (float)r[0]; f[1] = (float)r[1]; f[2] = (float)r[2]; f[3] = (float)r[3]; f[4] = (float)r[4]; f[5] = (float)r[5];
+      f[6] = (float)(r[7] * r[6]); f[7] = (float)(r[8] * r[6]); f[8] = (float)(r[9] * r[6]);
+    } else {
+      const uint32_t *src = (const uint32_t *)r;
 #pragma unroll
-    for (uint32_t c = 0; c < W; c++) o[c] = src[c];
+      for (uint32_t c = 0; c < W; c++) o[c] = src[c];
+    }
+    o[W] = (tag_offset + i) | (kd == 2 ? 0x80000000u : 0u);
   }
-  o[W] = (tag_offset + i) | (kd == 2 ? 0x80000000u : 0u);
+  __syncthreads();
+  const uint32_t base = block_offset[blockIdx.x], cnt = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+  const uint32_t words = (min(base + cnt, cap) - min(base, cap)) * RW;      // (records beyond the shard's capacity are dropped)
+  uint32_t *out = shard + (size_t)base * RW;
+  for (uint32_t k = threadIdx.x; k < words; k += 256u) out[k] = stage[k];
 }
 
 // State of the capped lists on the device; the host reads it back once per batch.
