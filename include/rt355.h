@@ -127,6 +127,8 @@ void rt_default_params(rt_params *p);
 /* device_ids: HIP ordinals; n == 0 or NULL means device 0.  One context drives one GPU
  * (multi-GPU = one process and one context per GPU). */
 int rt_init(const int *device_ids, int n, rt_ctx **out);
+/* Scenes, photon maps and photon lists of a context are freed before it (freeing a map hands its device blocks to the
+ * context's pool). */
 void rt_shutdown(rt_ctx *ctx);
 const char *rt_last_error(rt_ctx *ctx);     /* ctx may be NULL: last rt_init failure */
 void *rt_stream(rt_ctx *ctx);               /* the hipStream_t work is launched on (see the conventions above) */
