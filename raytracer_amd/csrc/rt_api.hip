@@ -92,7 +92,7 @@ int rt_init(const int *device_ids, int n, rt_ctx **out) {
       return RT_ERR_HIP;
     }
   // the experiment switches: the environment is read here, once per context
-  static const char *names[] = { "tail_threshold", "whole_frame", "bounce_passes", "tail_handoff", "tail_rounds", "tail_persistent", "no_lds", "no_cull", "cull_lists", "primary_tiles", "scan_groups", "raster_order", "bvh", "bvh_one_order", "wave_gather", "defer_gathers", "gather_sort", "gather_split", "knn_heap", "knn_sort",
+  static const char *names[] = { "tail_threshold", "whole_frame", "bounce_passes", "tail_handoff", "tail_rounds", "tail_persistent", "tail_persistent_handoff", "no_lds", "no_cull", "cull_lists", "primary_tiles", "scan_groups", "raster_order", "bvh", "bvh_one_order", "wave_gather", "defer_gathers", "gather_sort", "gather_split", "knn_heap", "knn_sort",
                                  "knn_verbose", "probe", "knn_radius_scale" };
   for (const char *nm : names) {
     std::string env = "RT355_";
@@ -126,6 +126,7 @@ int rt_set_option(rt_ctx *ctx, const char *name, double value) {
   else if (n == "tail_handoff") K.tail_handoff = (int)value;
   else if (n == "tail_rounds") K.tail_rounds = (int)value;
   else if (n == "tail_persistent") K.tail_persistent = (int)value;
+  else if (n == "tail_persistent_handoff") K.tail_persistent_handoff = (int)value;
   else if (n == "no_lds") K.no_lds = value != 0;
   else if (n == "no_cull") K.no_cull = value != 0;
   else if (n == "cull_lists") K.cull_lists = value != 0;

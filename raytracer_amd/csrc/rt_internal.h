@@ -35,6 +35,7 @@ struct RtKnobs {
   int bounce_passes = 0;         // single-bounce passes between the first pass and the tail kernel
   int tail_handoff = 0;          // > 0: tail workgroups down to this many paths (<= 64) hand them on to a further launch
   int tail_rounds = 1;           // how many such further launches (1 .. 3)
+  int tail_persistent_handoff = 0;    // persistent tail: waves down to this many paths (<= 32) hand them to a second launch; 0: they keep them
   int tail_persistent = -1;      // tail kernel with persistent lanes, this many queued paths per lane and workgroup; 0: the compacting
                                  // tail kernel; < 0: by the number of frames in flight (persistent lanes pay from three on)
   int no_lds = 0;                // 1: scans read the primitives through scalar loads instead of the LDS copy

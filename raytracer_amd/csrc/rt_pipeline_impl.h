@@ -271,8 +271,18 @@ static int trace_tile_mode(rt_scene *sc, int slot, const rt_params *p, DevMap md
       if (direct && persistent > 0) {
         const uint32_t per_wg = 256u * (uint32_t)std::min(persistent, 64);
         const uint32_t pblocks = div_up(ub, per_wg) + RT_SUBQ;
-        if (lds) RT_LAUNCH_SMEM(ctx, "tail", (k_tail_persistent<T, true, WHITTED, FULL>), pblocks, 256, smem, S, P, C, md, mc, levels, (const uint32_t *)q_cur, lens, n_subq, cap, ctr, (int)wave_bounces, per_wg);
-        else RT_LAUNCH_SMEM(ctx, "tail", (k_tail_persistent<T, false, WHITTED, FULL>), pblocks, 256, 0, S, P, C, md, mc, levels, (const uint32_t *)q_cur, lens, n_subq, cap, ctr, (int)wave_bounces, per_wg);
+        // Waves that are down to a few paths hand them on to a second launch (see the kernel).  A sub-queue of that launch
+        // takes the paths of every RT_SUBQ-th wave, far fewer than its capacity (>= n_paths / RT_SUBQ) on any frame of size;
+        // a wave that finds no room keeps its paths.
+        const uint32_t ho = (uint32_t)std::min(std::max(K.tail_persistent_handoff, 0), 32);
+        uint32_t *c_out = ctr->subq_count[RT_MAX_BOUNCE_PASSES + 1];
+        if (lds) RT_LAUNCH_SMEM(ctx, "tail", (k_tail_persistent<T, true, WHITTED, FULL>), pblocks, 256, smem, S, P, C, md, mc, levels, (const uint32_t *)q_cur, lens, n_subq, cap, ctr, (int)wave_bounces, per_wg, ho, q_nxt, c_out, C.subq_cap);
+        else RT_LAUNCH_SMEM(ctx, "tail", (k_tail_persistent<T, false, WHITTED, FULL>), pblocks, 256, 0, S, P, C, md, mc, levels, (const uint32_t *)q_cur, lens, n_subq, cap, ctr, (int)wave_bounces, per_wg, ho, q_nxt, c_out, C.subq_cap);
+        if (ho) {
+          const uint32_t rblocks = div_up(pblocks * 4u * ho, 256u) + RT_SUBQ;
+          if (lds) RT_LAUNCH_SMEM(ctx, "tail_rest", (k_tail_persistent<T, true, WHITTED, FULL>), rblocks, 256, smem, S, P, C, md, mc, levels, (const uint32_t *)q_nxt, (const uint32_t *)c_out, (uint32_t)RT_SUBQ, C.subq_cap, ctr, (int)wave_bounces, 256u, 0u, (uint32_t *)nullptr, (uint32_t *)nullptr, 0u);
+          else RT_LAUNCH_SMEM(ctx, "tail_rest", (k_tail_persistent<T, false, WHITTED, FULL>), rblocks, 256, 0, S, P, C, md, mc, levels, (const uint32_t *)q_nxt, (const uint32_t *)c_out, (uint32_t)RT_SUBQ, C.subq_cap, ctr, (int)wave_bounces, 256u, 0u, (uint32_t *)nullptr, (uint32_t *)nullptr, 0u);
+        }
         break;
       }
       for (uint32_t r = 0; r <= rounds; r++) {

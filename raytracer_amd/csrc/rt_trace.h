@@ -1325,9 +1325,17 @@ __global__ void __launch_bounds__(RT_TAIL_THREADS, RT_TAIL_MIN_WAVES) k_tail(Dev
 // nobody has started (a counter in LDS) -- no compaction, no barrier and no LDS traffic for path states inside the loop,
 // and lanes stay busy until the chunk runs dry.  Paths are at different bounces: each lane takes its bounce number from
 // its path's depth (depth and bounce number advance together).
+// Hand-off (handoff > 0): once the chunk is dry, a wave that is down to `handoff` paths or fewer writes their states to
+// the path arrays, appends them to sub-queue (its number % RT_SUBQ) of q_out / c_out (capacity cap_out each) and ends; the
+// host follows with a second, much smaller launch of this kernel over those sub-queues (handoff = 0), where the paths fill
+// whole waves again -- instead of a few lanes per wave following the longest paths while the others idle.
+// (Off by default.  Measured on the 1080p bench frame with four frames in flight: 0.0872 / 0.0860 / 0.0863 / 0.0859 ms per
+// frame with handoff = 8 / 16 / 24 / 32 against 0.0821 ms without -- the other frames' kernels already fill the lanes that
+// a frame's last paths leave idle, and the second launch has to stage the scene again and wait for the first to end.)
 template <typename T, bool LDS, bool WHITTED, bool FULL>
 __global__ void __launch_bounds__(256) k_tail_persistent(DevScene<T> S, PathSoA<T> P, TraceCfg C, DevMap Md, DevMap Mc, T *levels, const uint32_t *queue,
-                                                         const uint32_t *counts, uint32_t n_subq, uint32_t cap, TraceCounters *ctr, int bounce0, uint32_t per_wg) {
+                                                         const uint32_t *counts, uint32_t n_subq, uint32_t cap, TraceCounters *ctr, int bounce0, uint32_t per_wg,
+                                                         uint32_t handoff, uint32_t *q_out, uint32_t *c_out, uint32_t cap_out) {
   extern __shared__ __align__(16) unsigned char rt_lds[];
   __shared__ uint32_t next_path;
   const uint32_t len_raw = subq_load_len(counts, n_subq);   // (in flight while the scene is staged)
@@ -1345,10 +1353,14 @@ __global__ void __launch_bounds__(256) k_tail_persistent(DevScene<T> S, PathSoA<
   PathState<T> st;
   // (taking a path costs the wave two dependent global round trips; loading a lane's next path ahead of time was
   // measured slower: 17 more registers and the loads of paths that the chunk's last lanes never reach)
-  auto take = [&]() {
-    p = queue[first + j];
-    if (p >= C.n_paths) { tally.overflows++; p = 0; }       // (never taken; guards the indexed accesses)
-    st = load_path<T>(P, p);
+  auto take = [&]() {                                       // lane holds queue entry j: its path, or the chunk's next valid one
+    for (;;) {
+      p = queue[first + j];
+      if (p < C.n_paths) { st = load_path<T>(P, p); return; }
+      if (p != 0xFFFFFFFFu) tally.overflows++;              // (never taken; 0xFFFFFFFF: a slot that a hand-off reserved and gave up)
+      j = atomicAdd(&next_path, 1u);
+      if (j >= n) { have = false; p = 0; return; }
+    }
   };
   if (have) take();
   while (have) {
@@ -1361,6 +1373,25 @@ __global__ void __launch_bounds__(256) k_tail_persistent(DevScene<T> S, PathSoA<
       j = atomicAdd(&next_path, 1u);
       have = j < n;
       if (have) take();
+    }
+    if (handoff) {
+      // the chunk has run dry and few lanes of this wave still hold a path: those paths go to the follow-up launch
+      const unsigned long long live = __ballot(have);
+      const uint32_t n_live = (uint32_t)__popcll(live);
+      if (n_live != 0u && n_live <= handoff && *(volatile uint32_t *)&next_path >= n) {
+        const int lane = threadIdx.x & 63, leader = __ffsll((long long)live) - 1;
+        const uint32_t sq_out = (blockIdx.x * 4u + (threadIdx.x >> 6)) % RT_SUBQ;
+        uint32_t base = 0;
+        if (lane == leader) base = atomicAdd(&c_out[sq_out * 16], n_live);
+        base = __shfl(base, leader, 64);
+        const bool fits = base + n_live <= cap_out;           // (else: the wave keeps its paths and marks the slots it reserved)
+        if (have) {
+          const uint32_t pos = base + (uint32_t)__popcll(live & (((unsigned long long)1 << lane) - 1));
+          if (fits) { store_path<T>(P, p, st); q_out[(size_t)sq_out * cap_out + pos] = p; have = false; }
+          else if (pos < cap_out) q_out[(size_t)sq_out * cap_out + pos] = 0xFFFFFFFFu;
+        }
+        if (!fits) handoff = 0u;
+      }
     }
   }
   for (int off = 32; off > 0; off >>= 1) { rays += __shfl_xor(rays, off, 64); last_b = max(last_b, __shfl_xor(last_b, off, 64)); }

@@ -743,12 +743,12 @@ def test_wavefront_and_whole_frame_pipelines_agree(rt, precision):
             for k in ("rays", "shadow_rays", "gathers", "bounces"):
                 assert got["stats"][k] == whole["stats"][k], (k, ho, rounds)
         # the tail kernel with persistent lanes
-        for per_lane in (1, 4, 16):
-            with ctx.option("tail_persistent", per_lane, 0):
+        for per_lane, ho in ((1, 16), (4, 16), (16, 16), (4, 0), (4, 1), (4, 32), (1, 32)):      # ho: waves down to that many paths hand them to a second launch
+            with ctx.option("tail_persistent", per_lane, 0), ctx.option("tail_persistent_handoff", ho, 0):
                 got = sc.trace_tile(p, md, mc)
-            assert same(got["pre"], whole["pre"]) and same(got["post"], whole["post"]), per_lane
+            assert same(got["pre"], whole["pre"]) and same(got["post"], whole["post"]), (per_lane, ho)
             for k in ("rays", "shadow_rays", "gathers", "bounces"):
-                assert got["stats"][k] == whole["stats"][k], (k, per_lane)
+                assert got["stats"][k] == whole["stats"][k], (k, per_lane, ho)
         # single-bounce passes between the first pass and the tail kernel
         for n in (0, 1, 2):
             with ctx.option("bounce_passes", n, 0):
