@@ -399,13 +399,17 @@ RT_D bool gather_map_wave(const DevMap &M, bool need, V3<float> x, V3<float> nrm
   float sr = 0.f, sg = 0.f, sb = 0.f;
   uint32_t m = 0;
   // (a lane without a point: bounds no distance is below)
-  const float lo_lane = need ? r2lo : -1.f, hi_lane = need ? r2hi : -1.f;
+  // fp32 decides for a distance below or above band_mid (r^2) by more than band_half; one within that band may fall on
+  // either side of r^2 in fp64 and sends the batch through the fp64 test (a lane without a point: no distance is below
+  // its bound, none in its band)
+  const float band_mid = need ? 0.5f * (r2lo + r2hi) : -3.0e38f, band_half = need ? 0.5f * (r2hi - r2lo) : -1.f;
+  const float lo_lane = need ? band_mid : -1.f;
   auto consume = [&]() {
     RT_WAVE_SYNC()
     // the batch in fp32; should any (lane, candidate) distance fall inside the band, the batch again with the fp64 test
     // (tried: candidates outside every lane's ball skip their payload reads and sums -- 6.04 against 5.91 ms per frame)
     float br = 0.f, bg = 0.f, bb = 0.f;
-    bool band = false;
+    float nearest = 3.4e38f;                                 // smallest |d^2 - band_mid| of the batch: one subtract and one minimum per candidate
 #ifdef RT_GATHER_PROBE
     uint32_t inb = 0;
     for (uint32_t j = 0; j < m; j++) { const float4 cd = L.cand[j]; const float dx = x.x - cd.x, dy = x.y - cd.y, dz = x.z - cd.z; inb += (dx * dx + dy * dy + dz * dz < lo_lane) ? 1u : 0u; }
@@ -419,10 +423,10 @@ RT_D bool gather_map_wave(const DevMap &M, bool need, V3<float> x, V3<float> nrm
       const float *pl = L.pay + j * 6;
       const float w = fmaxf(pl[0] * nrm.x + pl[1] * nrm.y + pl[2] * nrm.z, 0.f);
       const float wi = d2f < lo_lane ? w : 0.f;
-      band = band || (!(d2f < lo_lane) && d2f < hi_lane);
+      nearest = fminf(nearest, fabsf(d2f - band_mid));
       br += pl[3] * wi; bg += pl[4] * wi; bb += pl[5] * wi;
     }
-    if (__any(band)) {                                   // (wave-uniform; rare)
+    if (__any(nearest <= band_half)) {                   // (wave-uniform; rare)
       br = 0.f; bg = 0.f; bb = 0.f;
       for (uint32_t j = 0; j < m; j++) {
         const float4 cd = L.cand[j];
