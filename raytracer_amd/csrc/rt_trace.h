@@ -416,16 +416,25 @@ RT_D bool gather_map_wave(const DevMap &M, bool need, V3<float> x, V3<float> nrm
     atomicAdd(&g_gather_probe[3], (unsigned long long)inb);
     if (lane == 0) { atomicAdd(&g_gather_probe[2], (unsigned long long)m); atomicAdd(&g_gather_probe[5], 1ull); }
 #endif
-    for (uint32_t j = 0; j < m; j++) {
+    // (the count is the same in every lane: as a scalar it keeps the loop's counter and addresses out of the vector unit;
+    // four candidates per trip: their LDS reads go out together and the running minimum is touched once)
+    const uint32_t mu = (uint32_t)__builtin_amdgcn_readfirstlane((int)m);
+    auto one = [&](uint32_t j) -> float {                 // candidate j into the sums; returns |d^2 - band_mid|
       const float4 cd = L.cand[j];
       const float dx = x.x - cd.x, dy = x.y - cd.y, dz = x.z - cd.z;
       const float d2f = dx * dx + dy * dy + dz * dz;
       const float *pl = L.pay + j * 6;
       const float w = fmaxf(pl[0] * nrm.x + pl[1] * nrm.y + pl[2] * nrm.z, 0.f);
       const float wi = d2f < lo_lane ? w : 0.f;
-      nearest = fminf(nearest, fabsf(d2f - band_mid));
       br += pl[3] * wi; bg += pl[4] * wi; bb += pl[5] * wi;
+      return fabsf(d2f - band_mid);
+    };
+    uint32_t j = 0;
+    for (; j + 4u <= mu; j += 4u) {
+      const float t0 = one(j), t1 = one(j + 1u), t2 = one(j + 2u), t3 = one(j + 3u);
+      nearest = fminf(nearest, fminf(fminf(t0, t1), fminf(t2, t3)));
     }
+    for (; j < mu; j++) nearest = fminf(nearest, one(j));
     if (__any(nearest <= band_half)) {                   // (wave-uniform; rare)
       br = 0.f; bg = 0.f; bb = 0.f;
       for (uint32_t j = 0; j < m; j++) {
