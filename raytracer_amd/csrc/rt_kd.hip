@@ -1070,6 +1070,11 @@ __device__ __forceinline__ uint32_t knn_load_subtree(const DevMap &M, uint32_t t
 // CAP: candidates a wave can hold.  (Tried: units of 64 whose candidates do not fit KNN2_CAP again as a whole with a
 // buffer of 2048 before they are cut up -- a wave's passes grow with its candidates and few such waves fit a CU: the
 // eighths serve a query in 7 ns, that launch took 12.)
+// A count that is the same in every lane, as a scalar: a loop up to it keeps its counter and its addresses out of the
+// vector unit and can be unrolled (the compiler cannot see that a value computed from shuffles or LDS is uniform).
+__device__ __forceinline__ uint32_t wave_uniform(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+#define RT_UNROLL_4 _Pragma("unroll 4")
+#define RT_UNROLL_2 _Pragma("unroll 2")
 template <int CAP>
 __global__ void __launch_bounds__(64) k_gather_knn_wave(DevMap M, const float *hits, uint32_t nq, uint32_t k, float radius_scale, uint32_t t_depth, float *rgb,
                                                         const uint2 *units, const uint32_t *n_units, KnnQueues Q) {
@@ -1135,7 +1140,8 @@ __global__ void __launch_bounds__(64) k_gather_knn_wave(DevMap M, const float *h
       __syncthreads();
       auto d2f = [&](float4 cd) { const float dx = qx - cd.x, dy = qy - cd.y, dz = qz - cd.z; return dx * dx + dy * dy + dz * dz; };
       float dmax = 0.f;
-      for (uint32_t j = 0; j < mt; j++) dmax = fmaxf(dmax, d2f(cand[j]));
+      RT_UNROLL_4
+      for (uint32_t j = 0, n_ = wave_uniform(mt); j < n_; j++) dmax = fmaxf(dmax, d2f(cand[j]));
       float a = 0.f, b = dmax * 1.000002f + 1e-30f; float fa = 0.f, fb = (float)mt;      // #(d2 < a) = fa < k <= fb = #(d2 < b)
       const float kf = (float)k;
       for (int it = 0; it < 3 && __any(fb > kf * 1.06f + 1.f); it++) {
@@ -1143,7 +1149,8 @@ __global__ void __launch_bounds__(64) k_gather_knn_wave(DevMap M, const float *h
         const float f2 = fminf(0.9f, fmaxf(0.02f, (kf * 1.03f + 1.f - fa) / (fb - fa)));
         const float t2 = a + (b - a) * f2, t1 = a + (b - a) * f2 * 0.8f, t3 = a + (b - a) * fminf(0.95f, f2 * 1.3f);
         float c1 = 0.f, c2 = 0.f, c3 = 0.f;
-        for (uint32_t j = 0; j < mt; j++) { const float d = d2f(cand[j]); c1 += d < t1 ? 1.f : 0.f; c2 += d < t2 ? 1.f : 0.f; c3 += d < t3 ? 1.f : 0.f; }
+        RT_UNROLL_4
+        for (uint32_t j = 0, n_ = wave_uniform(mt); j < n_; j++) { const float d = d2f(cand[j]); c1 += d < t1 ? 1.f : 0.f; c2 += d < t2 ? 1.f : 0.f; c3 += d < t3 ? 1.f : 0.f; }
         if (c1 >= kf) { b = t1; fb = c1; } else if (c2 >= kf) { b = t2; fb = c2; a = t1; fa = c1; } else if (c3 >= kf) { b = t3; fb = c3; a = t2; fa = c2; } else { a = t3; fa = c3; }
       }
       rq = sqrtf(b * 1.00001f) * 1.000001f * radius_scale;                   // (margins for the fp32 distance arithmetic: about 1e-6 relative)
@@ -1235,7 +1242,8 @@ __global__ void __launch_bounds__(64) k_gather_knn_wave(DevMap M, const float *h
       const float bl = __double2float_rd(b64 * (1.0 - 1e-6)), bh = __double2float_ru(b64 * (1.0 + 1e-6));
       const float p1f = (float)pt1, p2f = (float)pt2, p3f = (float)pt3;
       uint32_t c_lo = 0, c_hi = 0, f1 = 0, f2 = 0, f3 = 0;
-      for (uint32_t j = 0; j < m; j++) {
+      RT_UNROLL_4
+      for (uint32_t j = 0, n_ = wave_uniform(m); j < n_; j++) {
         const float4 cd = cand[j];
         const float dx = qx - cd.x, dy = qy - cd.y, dz = qz - cd.z;
         const float d = dx * dx + dy * dy + dz * dz;
@@ -1247,7 +1255,8 @@ __global__ void __launch_bounds__(64) k_gather_knn_wave(DevMap M, const float *h
       else if (__any(c_hi < k)) ok = false;
       else {
         c = 0;
-        for (uint32_t j = 0; j < m; j++) {
+        RT_UNROLL_2
+        for (uint32_t j = 0, n_ = wave_uniform(m); j < n_; j++) {
           const float4 cd = cand[j];
           c += sq_dist(x0, x1, x2, (double)cd.x, (double)cd.y, (double)cd.z) < b64 ? 1u : 0u;
         }
@@ -1291,7 +1300,8 @@ __global__ void __launch_bounds__(64) k_gather_knn_wave(DevMap M, const float *h
         if (!(t1 > af)) t1 = 0.5f * (af + t);
         if (!(t3 < bf)) t3 = 0.5f * (t + bf);
         uint32_t c1 = 0, c2 = 0, c3 = 0;
-        for (uint32_t j = 0; j < m; j++) { const float d = d2f(cand[j]); c1 += d < t1 ? 1u : 0u; c2 += d < t ? 1u : 0u; c3 += d < t3 ? 1u : 0u; }
+        RT_UNROLL_4
+        for (uint32_t j = 0, n_ = wave_uniform(m); j < n_; j++) { const float d = d2f(cand[j]); c1 += d < t1 ? 1u : 0u; c2 += d < t ? 1u : 0u; c3 += d < t3 ? 1u : 0u; }
         if (donef || failf || t_hit >= 0.f || !(t1 > af && t1 < t && t < t3 && t3 < bf)) continue;
         if (c1 == kk) t_hit = t1; else if (c2 == kk) t_hit = t; else if (c3 == kk) t_hit = t3;
         else {
@@ -1303,7 +1313,8 @@ __global__ void __launch_bounds__(64) k_gather_knn_wave(DevMap M, const float *h
       // tracking pass: the count below t and the candidate values next to t on either side
       if (t_hit >= 0.f) t = t_hit; else if (!(t > af && t < bf)) t = bf;
       uint32_t cnt = 0, ties = 0, rties = 0; float lmax = -1.f, rmin = 3.4e38f;
-      for (uint32_t j = 0; j < m; j++) {
+      RT_UNROLL_4
+      for (uint32_t j = 0, n_ = wave_uniform(m); j < n_; j++) {
         const float d = d2f(cand[j]);
         const bool lt = d < t, up = lt && d > lmax, eq = lt && d == lmax, dn = !lt && d < rmin, req = !lt && d == rmin;
         cnt += lt ? 1u : 0u;
@@ -1342,7 +1353,7 @@ __global__ void __launch_bounds__(64) k_gather_knn_wave(DevMap M, const float *h
           dst[0] = p0.x; dst[1] = p0.y; dst[2] = p1.x; dst[3] = p1.y; dst[4] = p2.x; dst[5] = p2.y;
         }
         __syncthreads();
-        const uint32_t nc = min(64u, m - base);
+        const uint32_t nc = wave_uniform(min(64u, m - base));
         for (uint32_t jj = 0; jj < nc; jj++) {
           const float4 cd = cand[base + jj];
           const float d = d2f(cd);
@@ -1355,7 +1366,8 @@ __global__ void __launch_bounds__(64) k_gather_knn_wave(DevMap M, const float *h
       }
       // the k-th squared distance in fp64: of the one candidate at lmaxf, or the largest of several
       if (__any(n_kth != 1u)) {
-        for (uint32_t j = 0; j < m; j++) {
+        RT_UNROLL_2
+        for (uint32_t j = 0, n_ = wave_uniform(m); j < n_; j++) {
           const float4 cd = cand[j];
           if (d2f(cd) == lmaxf) dk2 = fmax(dk2, sq_dist(x0, x1, x2, (double)cd.x, (double)cd.y, (double)cd.z));
         }
@@ -1369,10 +1381,12 @@ __global__ void __launch_bounds__(64) k_gather_knn_wave(DevMap M, const float *h
   if (exact) {
   if (fast) {                                                    // (the fp32 pass stood in for the exact first counting pass: here it is)
     c = 0;
-    for (uint32_t j = 0; j < m; j++) { const float4 cd = cand[j]; c += sq_dist(x0, x1, x2, (double)cd.x, (double)cd.y, (double)cd.z) < b64 ? 1u : 0u; }
+    RT_UNROLL_2
+    for (uint32_t j = 0, n_ = wave_uniform(m); j < n_; j++) { const float4 cd = cand[j]; c += sq_dist(x0, x1, x2, (double)cd.x, (double)cd.y, (double)cd.z) < b64 ? 1u : 0u; }
   }
   pc1 = 0; pc2 = 0; pc3 = 0;
-  for (uint32_t j = 0; j < m; j++) {
+  RT_UNROLL_2
+  for (uint32_t j = 0, n_ = wave_uniform(m); j < n_; j++) {
     const float4 cd = cand[j];
     const double d2 = sq_dist(x0, x1, x2, (double)cd.x, (double)cd.y, (double)cd.z);
     pc1 += d2 < pt1 ? 1u : 0u; pc2 += d2 < pt2 ? 1u : 0u; pc3 += d2 < pt3 ? 1u : 0u;
@@ -1406,7 +1420,8 @@ __global__ void __launch_bounds__(64) k_gather_knn_wave(DevMap M, const float *h
       if (!(t1 > a)) t1 = 0.5 * (a + t);
       if (!(t3 < b)) t3 = 0.5 * (t + b);
       uint32_t c1 = 0, c2 = 0, c3 = 0;
-      for (uint32_t j = 0; j < m; j++) {
+      RT_UNROLL_2
+      for (uint32_t j = 0, n_ = wave_uniform(m); j < n_; j++) {
         const float4 cd = cand[j];
         const double d2 = sq_dist(x0, x1, x2, (double)cd.x, (double)cd.y, (double)cd.z);
         c1 += d2 < t1 ? 1u : 0u; c2 += d2 < t ? 1u : 0u; c3 += d2 < t3 ? 1u : 0u;
@@ -1424,7 +1439,8 @@ __global__ void __launch_bounds__(64) k_gather_knn_wave(DevMap M, const float *h
     // ---- tracking pass
     if (!(t > a && t < b)) t = b;                                // a and b are neighbouring doubles: count below b, ties sit at a
     uint32_t cnt = 0, ties = 0, rties = 0; double lmax = -1.0, rmin = __builtin_huge_val();
-    for (uint32_t j = 0; j < m; j++) {
+    RT_UNROLL_2
+    for (uint32_t j = 0, n_ = wave_uniform(m); j < n_; j++) {
       const float4 cd = cand[j];
       const double d2 = sq_dist(x0, x1, x2, (double)cd.x, (double)cd.y, (double)cd.z);
       const bool lt = d2 < t, up = lt && d2 > lmax, eq = lt && d2 == lmax;
@@ -1459,7 +1475,8 @@ __global__ void __launch_bounds__(64) k_gather_knn_wave(DevMap M, const float *h
     uint32_t left = tie ? need : 0;
     for (int guard = 0; guard < CAP && __any(left > 0); guard++) {
       int32_t best = 0x7FFFFFFF;
-      for (uint32_t j = 0; j < m; j++) {
+      RT_UNROLL_2
+      for (uint32_t j = 0, n_ = wave_uniform(m); j < n_; j++) {
         const float4 cd = cand[j];
         const double d2 = sq_dist(x0, x1, x2, (double)cd.x, (double)cd.y, (double)cd.z);
         const int32_t pi = M.perm[__float_as_uint(cd.w)];
@@ -1482,7 +1499,7 @@ __global__ void __launch_bounds__(64) k_gather_knn_wave(DevMap M, const float *h
       dst[0] = p0.x; dst[1] = p0.y; dst[2] = p1.x; dst[3] = p1.y; dst[4] = p2.x; dst[5] = p2.y;
     }
     __syncthreads();
-    const uint32_t nc = min(64u, m - base);
+    const uint32_t nc = wave_uniform(min(64u, m - base));
     for (uint32_t jj = 0; jj < nc; jj++) {
       const float4 cd = cand[base + jj];
       const double d2 = sq_dist(x0, x1, x2, (double)cd.x, (double)cd.y, (double)cd.z);
