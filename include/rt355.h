@@ -139,7 +139,7 @@ int rt_synchronize(rt_ctx *ctx);            /* host wait for everything the cont
  * instead of calling rt_synchronize().  No counterpart in the reference. */
 int rt_join(rt_ctx *ctx);
 /* Experiment / test switches, by name: tail_threshold, whole_frame, bounce_passes, tail_handoff, tail_rounds,
- * tail_persistent, no_lds, no_cull, cull_lists, primary_tiles, raster_order, bvh (-1 by scene size / 0 / 1) and scan_groups (0 / 1)
+ * tail_persistent, tail_persistent_handoff, no_lds, no_cull, cull_lists, primary_tiles, raster_order, bvh (-1 by scene size / 0 / 1) and scan_groups (0 / 1)
  * (both read by rt_scene_upload), bvh_one_order, defer_gathers, gather_sort, gather_split, wave_gather, knn_heap, knn_sort (-1: order the k-nearest queries
  * by position when they arrive scattered / 0 never / 1 always),
  * knn_radius_scale, knn_verbose, probe.  rt_init reads
