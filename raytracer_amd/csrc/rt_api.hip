@@ -1197,9 +1197,12 @@ static int emit_many_lists(rt_scene *sc, const rt_params *p, int format, rt_phot
       if (p->precision == RT_PRECISION_F64) RT_TRY(pl_emit_shard<double>(sc, count, format, 0u, count, shard, n_dev));
       else RT_TRY(pl_emit_shard<float>(sc, count, format, 0u, count, shard, n_dev));
       // (the caps look at the shard's records only, not at a position per attempt: the count is worth a host round trip)
-      RT_HIP(ctx, hipMemcpyAsync(ctx->pinned, n_dev, 4, hipMemcpyDeviceToHost, ctx->stream));
-      RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-      const uint32_t n_stored = std::min(ctx->pinned[0], count);
+      uint32_t n_stored = count;
+      if (count > (1u << 20)) {                              // (a small batch: looking at every position costs less than the wait)
+        RT_HIP(ctx, hipMemcpyAsync(ctx->pinned, n_dev, 4, hipMemcpyDeviceToHost, ctx->stream));
+        RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        n_stored = std::min(ctx->pinned[0], count);
+      }
       rt_lists_info info;
       RT_TRY(lists_apply(L, phase, attempt, shard, n_dev, 1, count, n_stored, &info));
       nd = info.n_diffuse; nc = info.n_caustic;

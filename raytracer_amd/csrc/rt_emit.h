@@ -321,48 +321,57 @@ static __global__ void __launch_bounds__(256) k_lists_count(const uint32_t *shar
 // the caustic list takes records; the attempt that fills it ends the phase.  Pass A (kind 1 in phase 1, kind 2 in
 // phase 2) finds that attempt; pass B (phase 1 only) takes the caustic records before it.
 //   block_off: exclusive scans of the per-workgroup counts; totals[0] = diffuse, totals[1] = caustic records in the batch
+// (The records a workgroup takes are consecutive in their list: they are collected in LDS and written as one run of
+// consecutive words.)
+#define RT_LIST_WORDS_MAX 22u
 template <int PASS>
 __global__ void __launch_bounds__(256) k_lists_take(const uint32_t *shards, const uint32_t *counts, uint32_t n_shards, uint32_t stride, uint32_t W,
                                                     const uint32_t *block_d, const uint32_t *block_c, const uint32_t *totals, int phase,
                                                     uint32_t cap_d, uint32_t cap_c, unsigned long long tag_base, ListsState *st,
                                                     uint32_t *list_d, long long *att_d, uint32_t *list_c, long long *att_c) {
   __shared__ uint32_t cd[4], cc[4];
+  __shared__ uint32_t stage[256 * RT_LIST_WORDS_MAX];
+  __shared__ uint32_t first_rank;                             // list position of the workgroup's first taken record
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   bool valid; const uint32_t tag = merged_tag(shards, counts, n_shards, stride, W, i, valid);
   const bool is_c = valid && (tag >> 31), is_d = valid && !(tag >> 31);
   const unsigned long long md = __ballot(is_d), mc = __ballot(is_c);
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   if (lane == 0) { cd[wv] = (uint32_t)__popcll(md); cc[wv] = (uint32_t)__popcll(mc); }
+  if (threadIdx.x == 0) first_rank = 0xFFFFFFFFu;
   __syncthreads();
   const unsigned long long below = ((unsigned long long)1 << lane) - 1;
-  uint32_t rd = block_d[blockIdx.x] + (uint32_t)__popcll(md & below), rc = block_c[blockIdx.x] + (uint32_t)__popcll(mc & below);
-  for (int w = 0; w < wv; w++) { rd += cd[w]; rc += cc[w]; }      // this record's rank among the batch's diffuse / caustic records
+  uint32_t ld = (uint32_t)__popcll(md & below), lc = (uint32_t)__popcll(mc & below);      // rank among the workgroup's diffuse / caustic records
+  for (int w = 0; w < wv; w++) { ld += cd[w]; lc += cc[w]; }
+  const uint32_t rd = block_d[blockIdx.x] + ld, rc = block_c[blockIdx.x] + lc;           // ... among the batch's
   const uint32_t n_d = st->n_d, n_c = st->n_c;                     // list lengths before this batch
   const uint32_t room_d = cap_d - min(n_d, cap_d), room_c = cap_c - min(n_c, cap_c);
   const long long ph = (long long)phase << 62;
+  // which list this pass fills, and whether this thread's record goes there (the records taken are the first of their
+  // kind in the workgroup: local ranks 0 .. taken - 1)
+  bool take = false; bool to_c = false; uint32_t local = 0, rank = 0;
   if (PASS == 0) {
     if (phase == 1) {
-      if (is_d && rd < room_d) {
-        uint32_t *o = list_d + (size_t)(n_d + rd) * W; const uint32_t *src = shards + (size_t)i * (W + 1);
-        for (uint32_t c = 0; c < W; c++) o[c] = src[c];
-        att_d[n_d + rd] = ph | (long long)(tag_base + (tag & 0x7FFFFFFFu));
-        if (rd + 1 == room_d) { st->last_tag = tag & 0x7FFFFFFFu; st->pad_ = rc; }      // rc: caustic records before the last attempt
-      }
-    } else if (is_c && rc < room_c) {
-      uint32_t *o = list_c + (size_t)(n_c + rc) * W; const uint32_t *src = shards + (size_t)i * (W + 1);
-      for (uint32_t c = 0; c < W; c++) o[c] = src[c];
-      att_c[n_c + rc] = ph | (long long)(tag_base + (tag & 0x7FFFFFFFu));
-      if (rc + 1 == room_c) st->last_tag = tag & 0x7FFFFFFFu;
+      take = is_d && rd < room_d; local = ld; rank = n_d + rd;
+      if (take && rd + 1 == room_d) { st->last_tag = tag & 0x7FFFFFFFu; st->pad_ = rc; }      // rc: caustic records before the last attempt
+    } else {
+      take = is_c && rc < room_c; to_c = true; local = lc; rank = n_c + rc;
+      if (take && rc + 1 == room_c) st->last_tag = tag & 0x7FFFFFFFu;
     }
   } else {                                                        // phase 1, caustic records up to the last attempt
     const uint32_t upto = st->last_tag == 0xFFFFFFFFu ? totals[1] : st->pad_;
-    const uint32_t take = min(upto, room_c);
-    if (is_c && rc < take) {
-      uint32_t *o = list_c + (size_t)(n_c + rc) * W; const uint32_t *src = shards + (size_t)i * (W + 1);
-      for (uint32_t c = 0; c < W; c++) o[c] = src[c];
-      att_c[n_c + rc] = ph | (long long)(tag_base + (tag & 0x7FFFFFFFu));
-    }
+    take = is_c && rc < min(upto, room_c); to_c = true; local = lc; rank = n_c + rc;
   }
+  if (take) {
+    const uint32_t *src = shards + (size_t)i * (W + 1);
+    for (uint32_t c = 0; c < W; c++) stage[local * W + c] = src[c];
+    (to_c ? att_c : att_d)[rank] = ph | (long long)(tag_base + (tag & 0x7FFFFFFFu));
+    if (local == 0) first_rank = rank;
+  }
+  const uint32_t taken = __syncthreads_count(take);
+  if (taken == 0) return;
+  uint32_t *out = (PASS == 0 && phase == 1 ? list_d : list_c) + (size_t)first_rank * W;
+  for (uint32_t k = threadIdx.x; k < taken * W; k += 256u) out[k] = stage[k];
 }
 
 // closes a batch: new list lengths, what was taken (one thread)
