@@ -1,5 +1,5 @@
 #!/bin/bash
-# first GPU call of round 2: VALU issue-rate micro-benchmark, then kernel statistics of the full bench (incl. emission leg)
+# VALU issue-rate micro-benchmark, then kernel statistics of the full bench (incl. the emission leg)
 set -e
 R=$PWD
 mkdir -p $R/gpurun_out/r02a
