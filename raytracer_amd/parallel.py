@@ -201,6 +201,8 @@ def render_sharded(engine, width, height, band=16, out=None):
     parts = [torch.empty_like(part) for _ in range(world)] if rank == 0 else None
     dist.gather(part.contiguous(), parts, dst=0)
     if rank != 0:
+        if part.is_cuda:
+            torch.cuda.current_stream().synchronize()        # (the engine's buffer is free again once the bands have left)
         return None
     frame = out if out is not None else torch.empty((height, width) + tuple(part.shape[2:]), dtype=part.dtype, device=part.device)
     for k in range(world):
@@ -250,6 +252,10 @@ def gather_bands_end(handle, width, height, band=16, out=None):
         return parts
     handle["work"].wait()
     if rank != 0:
+        # (a device collective's wait() orders torch's stream behind it, not the host and not the library's streams, which
+        # will write these bands' buffer again: the host waits here until this rank's bands have left)
+        if parts.is_cuda:
+            torch.cuda.current_stream().synchronize()
         return None
     got, n_frames = handle["got"], parts.shape[0]
     frames = out if out is not None else torch.empty((n_frames, height, width) + tuple(parts.shape[3:]), dtype=parts.dtype, device=parts.device)
