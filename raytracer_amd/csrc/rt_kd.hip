@@ -1556,12 +1556,18 @@ template <int PER_LANE> __device__ __forceinline__ double wave_kth_smallest(cons
   return __longlong_as_double((long long)ans);
 }
 
+#ifndef KNN1_FRONT
+#define KNN1_FRONT 512                                // entries of the single-query walk's stack
+// (Tried: 1024 and 2048 entries, so that a step can always take 64 nodes -- 94 -> 71 walk steps per query on the emitted
+// caustic map, but fewer waves fit a CU: 226 and 189 against 229 M gathers/s.  The walk visits some 2000 nodes for 400
+// candidates: a child is pruned by its distance to the splitting plane alone, not by the distance to its cell.)
+#endif
 template <int CAP1>
 __global__ void __launch_bounds__(64) k_gather_knn_single(DevMap M, const float *hits, uint32_t nq, uint32_t k, uint32_t t_depth, float *rgb,
                                                           const uint2 *units, const uint32_t *n_units, uint32_t *heap_list, uint32_t *heap_count) {
   constexpr int KNN1_PER_LANE = CAP1 / 64;
   __shared__ float4 cand[CAP1];                      // x y z, slot (as bits)
-  __shared__ uint32_t stack[KNN2_FRONT];
+  __shared__ uint32_t stack[KNN1_FRONT];
   const int lane = threadIdx.x;
   if (blockIdx.x >= *n_units) return;                // (the grid is an upper bound)
   const uint32_t q = units[blockIdx.x].x;
@@ -1574,7 +1580,7 @@ __global__ void __launch_bounds__(64) k_gather_knn_single(DevMap M, const float 
   long long pt0 = clock64(); unsigned long long pacc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
 #endif
   uint32_t t_pos = 1; float plane_val = 0.f; unsigned long long path = 0;
-  static_assert(KNN2_FRONT * sizeof(uint32_t) >= 64 * sizeof(float4), "descent staging needs 1 KB");
+  static_assert(KNN1_FRONT * sizeof(uint32_t) >= 64 * sizeof(float4), "descent staging needs 1 KB");
   knn_descend(M, qx, qy, qz, t_depth, (float4 *)&stack[0], lane, t_pos, path, plane_val);
   uint32_t m = knn_load_subtree(M, t_pos, cand, lane, CAP1);
   __syncthreads();
@@ -1636,7 +1642,7 @@ __global__ void __launch_bounds__(64) k_gather_knn_single(DevMap M, const float 
     }
     // (the fuller the stack, the fewer nodes a step takes off its top: those are the deepest, which soon end in leaves,
     // and a step can add at most one entry per node it takes)
-    const uint32_t take = min(min(64u, sp), max(1u, (KNN2_FRONT - sp) / 8u));
+    const uint32_t take = min(min(64u, sp), max(1u, (KNN1_FRONT - sp) / 8u));
     const bool active = (uint32_t)lane < take;
     const uint32_t pos = active ? stack[sp - take + lane] : 1u;              // 1 <= pos <= n by construction
     sp -= take;
@@ -1656,7 +1662,7 @@ __global__ void __launch_bounds__(64) k_gather_knn_single(DevMap M, const float 
     const bool far_l = gl && delta > 0.f, far_r = gr && delta < 0.f, near_l = gl && !(delta > 0.f), near_r = gr && !(delta < 0.f);
     const unsigned long long b0 = __ballot(far_l), b1 = __ballot(far_r), b2 = __ballot(near_l), b3 = __ballot(near_r);
     const uint32_t c0 = (uint32_t)__popcll(b0), c1 = (uint32_t)__popcll(b1), c2 = (uint32_t)__popcll(b2), c3 = (uint32_t)__popcll(b3);
-    if (sp + c0 + c1 + c2 + c3 > KNN2_FRONT) { failed = true; break; }
+    if (sp + c0 + c1 + c2 + c3 > KNN1_FRONT) { failed = true; break; }
     __syncthreads();                                 // (every lane has taken its node)
     if (far_l) stack[sp + lanes_below(b0, lane)] = 2 * pos;
     if (far_r) stack[sp + c0 + lanes_below(b1, lane)] = 2 * pos + 1;
