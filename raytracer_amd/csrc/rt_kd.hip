@@ -1556,11 +1556,15 @@ template <int PER_LANE> __device__ __forceinline__ double wave_kth_smallest(cons
   return __longlong_as_double((long long)ans);
 }
 
+#ifndef KNN1_CELLS
+#define KNN1_CELLS 1                                  // 1: the walk's stack entries carry the query's distance to their cell (see the walk)
+#endif
 #ifndef KNN1_FRONT
 #define KNN1_FRONT 512                                // entries of the single-query walk's stack
 // (Tried: 1024 and 2048 entries, so that a step can always take 64 nodes -- 94 -> 71 walk steps per query on the emitted
 // caustic map, but fewer waves fit a CU: 226 and 189 against 229 M gathers/s.  The walk visits some 2000 nodes for 400
-// candidates: a child is pruned by its distance to the splitting plane alone, not by the distance to its cell.)
+// candidates when a child is pruned by its distance to the splitting plane alone; with the distance to the child's cell
+// (KNN1_CELLS) 41 steps, and 241 M gathers/s with the offsets packed in one word per entry -- 235 with three halves in two.)
 #endif
 template <int CAP1>
 __global__ void __launch_bounds__(64) k_gather_knn_single(DevMap M, const float *hits, uint32_t nq, uint32_t k, uint32_t t_depth, float *rgb,
@@ -1568,6 +1572,11 @@ __global__ void __launch_bounds__(64) k_gather_knn_single(DevMap M, const float 
   constexpr int KNN1_PER_LANE = CAP1 / 64;
   __shared__ float4 cand[CAP1];                      // x y z, slot (as bits)
   __shared__ uint32_t stack[KNN1_FRONT];
+#if KNN1_CELLS
+  // per stack entry: how far the query lies outside the entry's cell along x, y, z, in 1023ths of the first search radius,
+  // rounded down (10 bits each)
+  __shared__ uint32_t soff[KNN1_FRONT];
+#endif
   const int lane = threadIdx.x;
   if (blockIdx.x >= *n_units) return;                // (the grid is an upper bound)
   const uint32_t q = units[blockIdx.x].x;
@@ -1612,7 +1621,15 @@ __global__ void __launch_bounds__(64) k_gather_knn_single(DevMap M, const float 
   }
   __syncthreads();                                   // (the subtree's photons have been consumed)
   m = 0;
-  if (lane == 0) stack[0] = t_pos >> (t_depth - start_level);
+#if KNN1_CELLS
+  const float off_step = reach < 3.0e38f ? reach * (1.0f / 1023.0f) : 0.f, off_inv = off_step > 0.f ? 1.0f / off_step : 0.f;
+#endif
+  if (lane == 0) {
+    stack[0] = t_pos >> (t_depth - start_level);
+#if KNN1_CELLS
+    soff[0] = 0u;                                    // (the ball lies inside that node's cell)
+#endif
+  }
   __syncthreads();
   uint32_t sp = 1; bool failed = false;
   KNN1_PROBE(0)
@@ -1645,29 +1662,54 @@ __global__ void __launch_bounds__(64) k_gather_knn_single(DevMap M, const float 
     const uint32_t take = min(min(64u, sp), max(1u, (KNN1_FRONT - sp) / 8u));
     const bool active = (uint32_t)lane < take;
     const uint32_t pos = active ? stack[sp - take + lane] : 1u;              // 1 <= pos <= n by construction
+#if KNN1_CELLS
+    // The cell of a node bounds its whole subtree: a node whose cell has fallen out of the ball (the ball shrinks when the
+    // buffer is refilled) is dropped with its subtree, and a far child is pushed only if ITS cell reaches the ball -- the
+    // distance to the splitting plane alone keeps whole slabs of the tree alive.  The offsets are lower bounds (rounded
+    // down), tauf has room for the fp32 arithmetic.
+    const uint32_t so = active ? soff[sp - take + lane] : 0u;
+    const float o0 = (float)(so & 1023u) * off_step, o1 = (float)((so >> 10) & 1023u) * off_step, o2 = (float)(so >> 20) * off_step;
+    const bool live = active && o0 * o0 + o1 * o1 + o2 * o2 <= tauf;
+#else
+    const bool live = active;
+#endif
     sp -= take;
     const float4 nd = M.node[pos - 1];
     const float ddx = qx - nd.x, ddy = qy - nd.y, ddz = qz - nd.z;
-    const bool inside = active && ddx * ddx + ddy * ddy + ddz * ddz <= tauf;
+    const bool inside = live && ddx * ddx + ddy * ddy + ddz * ddz <= tauf;
     const unsigned long long mi = __ballot(inside);
     if (inside) cand[m + lanes_below(mi, lane)] = make_float4(nd.x, nd.y, nd.z, __uint_as_float(pos - 1));
     m += (uint32_t)__popcll(mi);
     KNN1_COUNT(6, 1) KNN1_COUNT(7, __popcll(mi))
     const int dim = node_dim(nd);
     const float delta = ((dim == 0) ? ddx : (dim == 1) ? ddy : ddz);        // query minus plane
+#if KNN1_CELLS
+    const float others = (dim == 0) ? o1 * o1 + o2 * o2 : (dim == 1) ? o0 * o0 + o2 * o2 : o0 * o0 + o1 * o1;
+    const bool reachable = others + delta * delta <= tauf;                   // the far child's cell
+    const uint32_t hd = (uint32_t)fminf(fabsf(delta) * off_inv, 1023.f);     // (truncates: a lower bound)
+    const uint32_t so_far = dim == 0 ? (so & ~1023u) | hd : dim == 1 ? (so & ~(1023u << 10)) | (hd << 10) : (so & ~(1023u << 20)) | (hd << 20);
+#else
     const bool reachable = delta * delta <= tauf;
-    const bool gl = active && 2ull * pos <= n && (delta <= 0.f || reachable);
-    const bool gr = active && 2ull * pos + 1 <= n && (delta >= 0.f || reachable);
+#endif
+    const bool gl = live && 2ull * pos <= n && (delta <= 0.f || reachable);
+    const bool gr = live && 2ull * pos + 1 <= n && (delta >= 0.f || reachable);
     // far sides first, near sides on top of them
     const bool far_l = gl && delta > 0.f, far_r = gr && delta < 0.f, near_l = gl && !(delta > 0.f), near_r = gr && !(delta < 0.f);
     const unsigned long long b0 = __ballot(far_l), b1 = __ballot(far_r), b2 = __ballot(near_l), b3 = __ballot(near_r);
     const uint32_t c0 = (uint32_t)__popcll(b0), c1 = (uint32_t)__popcll(b1), c2 = (uint32_t)__popcll(b2), c3 = (uint32_t)__popcll(b3);
     if (sp + c0 + c1 + c2 + c3 > KNN1_FRONT) { failed = true; break; }
     __syncthreads();                                 // (every lane has taken its node)
+#if KNN1_CELLS
+    if (far_l) { const uint32_t at = sp + lanes_below(b0, lane); stack[at] = 2 * pos; soff[at] = so_far; }
+    if (far_r) { const uint32_t at = sp + c0 + lanes_below(b1, lane); stack[at] = 2 * pos + 1; soff[at] = so_far; }
+    if (near_l) { const uint32_t at = sp + c0 + c1 + lanes_below(b2, lane); stack[at] = 2 * pos; soff[at] = so; }
+    if (near_r) { const uint32_t at = sp + c0 + c1 + c2 + lanes_below(b3, lane); stack[at] = 2 * pos + 1; soff[at] = so; }
+#else
     if (far_l) stack[sp + lanes_below(b0, lane)] = 2 * pos;
     if (far_r) stack[sp + c0 + lanes_below(b1, lane)] = 2 * pos + 1;
     if (near_l) stack[sp + c0 + c1 + lanes_below(b2, lane)] = 2 * pos;
     if (near_r) stack[sp + c0 + c1 + c2 + lanes_below(b3, lane)] = 2 * pos + 1;
+#endif
     sp += c0 + c1 + c2 + c3;
     __syncthreads();
   }
