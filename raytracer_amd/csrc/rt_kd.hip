@@ -1844,7 +1844,8 @@ static int gather_knn_run(rt_photon_map *m, const float *dh, uint32_t nq, uint32
   if (launched[2]) {                                                       // single queries: one wave each, streaming
     // (Tried: a 128-entry buffer for k <= 64, so that the search ball shrinks after the first hundred candidates instead of
     // the first two hundred -- 113 against 229 M gathers/s on the emitted caustic map: the extra selections cost more than
-    // the shorter walks save; a 512-entry one: 183 M/s.)
+    // the shorter walks save; a 512-entry one: 183 M/s; one extra selection once 96 or 128 candidates are in: 234 / 235
+    // against 240 M/s.)
     if (4 * k <= 256) {
       RT_LAUNCH(ctx, "gather_knn_single", k_gather_knn_single<256>, launched[2], 64, m->view(), dh, nq, k, t_depth, dout,
                 (const uint2 *)queue[1], (const uint32_t *)(counters + 1), heap_list, counters + 3);
