@@ -927,8 +927,17 @@ __global__ void __launch_bounds__(256) k_primary(DevScene<T> S, PathSoA<T> P, Tr
 // like the tail kernel with persistent lanes.  (Tried on the latter: raised wave priority for waves that carry deep
 // paths -- no difference; 8, 16, 32 queued paths per lane instead of 4 -- 89, 123, 183 us per frame.)
 #define RT_PT_MAX_TILES 8
+// Waves per SIMD the register allocation aims for.  The first pass at 8 (at most 64 registers instead of the 82 it takes
+// when left alone: five waves): 0.0805 against 0.0822 ms per frame with four frames in flight, three runs each; the
+// persistent tail left alone (71 registers, seven waves): capped at 8 it is 4 % slower.
+#ifndef RT_PT_MIN_WAVES
+#define RT_PT_MIN_WAVES 8
+#endif
+#ifndef RT_TP_MIN_WAVES
+#define RT_TP_MIN_WAVES 1
+#endif
 template <bool WHITTED, bool FULL>
-__global__ void __launch_bounds__(256) k_primary_tiles(DevScene<float> S, PathSoA<float> P, TraceCfg C, DevMap Md, DevMap Mc, float *levels,
+__global__ void __launch_bounds__(256, RT_PT_MIN_WAVES) k_primary_tiles(DevScene<float> S, PathSoA<float> P, TraceCfg C, DevMap Md, DevMap Mc, float *levels,
                                                        uint32_t *queue, uint32_t *count_ptr, TraceCounters *ctr, uint32_t n_tiles, uint32_t per_block) {
   extern __shared__ __align__(16) unsigned char rt_lds[];
   __shared__ uint32_t surv[RT_PT_MAX_TILES * 256];
@@ -1346,7 +1355,7 @@ __global__ void __launch_bounds__(RT_TAIL_THREADS, RT_TAIL_MIN_WAVES) k_tail(Dev
 // frame with handoff = 8 / 16 / 24 / 32 against 0.0821 ms without -- the other frames' kernels already fill the lanes that
 // a frame's last paths leave idle, and the second launch has to stage the scene again and wait for the first to end.)
 template <typename T, bool LDS, bool WHITTED, bool FULL>
-__global__ void __launch_bounds__(256) k_tail_persistent(DevScene<T> S, PathSoA<T> P, TraceCfg C, DevMap Md, DevMap Mc, T *levels, const uint32_t *queue,
+__global__ void __launch_bounds__(256, RT_TP_MIN_WAVES) k_tail_persistent(DevScene<T> S, PathSoA<T> P, TraceCfg C, DevMap Md, DevMap Mc, T *levels, const uint32_t *queue,
                                                          const uint32_t *counts, uint32_t n_subq, uint32_t cap, TraceCounters *ctr, int bounce0, uint32_t per_wg,
                                                          uint32_t handoff, uint32_t *q_out, uint32_t *c_out, uint32_t cap_out) {
   extern __shared__ __align__(16) unsigned char rt_lds[];
